@@ -1,0 +1,1215 @@
+// ============================================================================
+// ORACLE -- TEST INFRASTRUCTURE ONLY.  NOT PART OF THE PRODUCT.
+//
+// CPU restatement (C++17, f64, -ffp-contract=off) of the per-pixel radiance
+// path of BlackCloud37/rust-raytracer, one function per row of SURVEY.md s8a.
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+// load this library; the product (rust-raytracer_amd/) never links, imports or
+// calls anything in oracle/.
+//
+// PINNING STATUS
+//   * Vec3 arithmetic: pinned by the reference's own 24 #[test]s
+//     (raytracer/src/vec3.rs:425-564), replayed in tests/test_oracle_vec3.py.
+//   * Everything else (intersection, BVH, scatter, camera, tonemap, images):
+//     PARITY UNPINNED.  The reference cannot be compiled here (no Rust
+//     toolchain, 13 un-vendored crates), is not seedable (rand::thread_rng
+//     everywhere) and its tests hold no golden vector for this path
+//     (SURVEY.md s8c).  These functions follow the cited reference lines
+//     operation by operation and are additionally checked by analytic
+//     known-answer tests authored in this repo (tests/test_oracle_kat.py).
+//
+// DELIBERATE DIVERGENCES FROM THE REFERENCE (all documented in DESIGN.md)
+//   D1. RNG: rand::thread_rng() -> counter-based SplitMix64 stream keyed by
+//       (seed, pixel, sample); draws inside a sample are sequential in the
+//       reference's call order.
+//   D2. sample_ray: on a Diffuse interaction the path CONTINUES
+//       (throughput *= attenuation; ray = scattered), i.e. the two lines the
+//       reference author commented out at photon_mapper.rs:346-347, instead
+//       of the SPPM photon-map lookup at :349-351.
+//   D3. BVHNode::new split axis comes from a seeded stream, not thread_rng.
+//   D4. Rust panics become an error flag (ORC_ERR_*), never an abort.
+//
+// Instrumentation: every AABB / primitive / transform test is counted so the
+// "algorithmic bytes per sample" of SURVEY.md s8d can be computed in the
+// reference's own traversal order.
+// ============================================================================
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <thread>
+#include <vector>
+
+namespace orc {
+
+static const double PI = 3.14159265358979323846264338327950288;          // std::f64::consts::PI
+static const double FRAC_1_PI = 0.318309886183790671537767526745028724;  // std::f64::consts::FRAC_1_PI
+static const double INF = std::numeric_limits<double>::infinity();
+
+struct UnitZero : std::runtime_error {
+    UnitZero() : std::runtime_error("unitizing zero vector") {}
+};
+
+// ----------------------------------------------------------------------------
+// Vec3 -- raytracer/src/vec3.rs:14-19 (struct), :21-185 (methods), :247-424 (ops)
+// ----------------------------------------------------------------------------
+struct Vec3 {
+    double x, y, z;
+    Vec3() : x(0), y(0), z(0) {}
+    Vec3(double a, double b, double c) : x(a), y(b), z(c) {}
+    double operator[](int i) const { return i == 0 ? x : (i == 1 ? y : z); }  // vec3.rs:211-221
+};
+static inline Vec3 v_add(Vec3 a, Vec3 b) { return Vec3(a.x + b.x, a.y + b.y, a.z + b.z); }  // :247-257
+static inline Vec3 v_adds(Vec3 a, double s) { return Vec3(a.x + s, a.y + s, a.z + s); }     // :259-269
+static inline Vec3 v_sub(Vec3 a, Vec3 b) { return Vec3(a.x - b.x, a.y - b.y, a.z - b.z); }  // :291-301
+static inline Vec3 v_subs(Vec3 a, double s) { return Vec3(a.x - s, a.y - s, a.z - s); }     // :303-313
+// Vec3 * Vec3 is the DOT product (quirk Q1), vec3.rs:335-341; left-assoc sum.
+static inline double v_dot(Vec3 a, Vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static inline Vec3 v_muls(Vec3 a, double s) { return Vec3(a.x * s, a.y * s, a.z * s); }  // :343-365 (both orders)
+static inline Vec3 v_divs(Vec3 a, double s) { return Vec3(a.x / s, a.y / s, a.z / s); }  // :377-397 true divides
+static inline Vec3 v_neg(Vec3 a) { return Vec3(-a.x, -a.y, -a.z); }                      // :410-418
+static inline Vec3 v_elemul(Vec3 a, Vec3 b) { return Vec3(a.x * b.x, a.y * b.y, a.z * b.z); }  // :65-71
+static inline Vec3 v_cross(Vec3 a, Vec3 b) {                                                    // :73-79
+    return Vec3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+static inline double v_sqlen(Vec3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }  // :61-63
+static inline double v_len(Vec3 a) { return std::sqrt(v_sqlen(a)); }                // :81-83
+static inline Vec3 v_unit(Vec3 a) {                                                 // :85-90 (panic -> throw, D4)
+    double l = v_len(a);
+    if (l == 0.) throw UnitZero();
+    return v_divs(a, l);
+}
+static inline bool v_near_zero(Vec3 a) {  // :92-95
+    const double S = 1e-8;
+    return (std::fabs(a.x) < S) && (std::fabs(a.y) < S) && (std::fabs(a.z) < S);
+}
+static inline double v_max(Vec3 a) { return std::fmax(std::fmax(a.x, a.y), a.z); }  // :57-59
+
+// ----------------------------------------------------------------------------
+// RNG (divergence D1).  Spec "rtamd-rng-1" -- restated independently in the
+// product (rust-raytracer_amd/csrc/common/rng.h); pinned against each other by
+// tests/golden/rng_kat.json.
+//   SplitMix64 (Steele, Lea, Flood 2014; public-domain reference by Vigna).
+//   stream key:  s0 = mix(mix(seed + G*(pixel+1)) + H*(sample+1))
+//   gen::<f64>() = (u64 >> 11) * 2^-53            in [0,1)
+//   gen_range(lo..hi) = lo + (hi - lo) * gen::<f64>()
+// ----------------------------------------------------------------------------
+struct Rng {
+    uint64_t s;
+    static inline uint64_t mix(uint64_t z) {
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+        return z ^ (z >> 31);
+    }
+    Rng() : s(0) {}
+    Rng(uint64_t seed, uint64_t pixel, uint64_t sample) {
+        uint64_t h = mix(seed + 0x9E3779B97F4A7C15ULL * (pixel + 1));
+        s = mix(h + 0xD1B54A32D192ED03ULL * (sample + 1));
+    }
+    inline uint64_t next_u64() {
+        s += 0x9E3779B97F4A7C15ULL;
+        return mix(s);
+    }
+    inline double gen_f64() { return (double)(next_u64() >> 11) * (1.0 / 9007199254740992.0); }
+    inline double gen_range(double lo, double hi) { return lo + (hi - lo) * gen_f64(); }
+    inline uint32_t gen_below3() { return (uint32_t)(((next_u64() >> 32) * 3ULL) >> 32); }  // gen_range(0..3)
+};
+
+// vec3.rs:111-129 -- Marsaglia; returns a point ON the unit sphere (quirk Q3).
+static inline Vec3 random_in_unit_sphere(Rng& rng) {
+    double u, v, r2;
+    for (;;) {
+        u = rng.gen_range(-1., 1.);
+        v = rng.gen_range(-1., 1.);
+        r2 = u * u + v * v;
+        if (r2 <= 1.) break;
+    }
+    return Vec3(2. * u * std::sqrt(1. - r2), 2. * v * std::sqrt(1. - r2), 1. - 2. * r2);
+}
+static inline Vec3 random_unit_vector(Rng& rng) { return v_unit(random_in_unit_sphere(rng)); }  // :140-142
+static inline Vec3 random_in_hemisphere(Rng& rng, Vec3 n) {                                    // :144-151
+    Vec3 s = random_in_unit_sphere(rng);
+    return (v_dot(s, n) > 0.0) ? s : v_neg(s);
+}
+static inline Vec3 random_in_unit_disk(Rng& rng) {  // :153-162
+    for (;;) {
+        double a = rng.gen_range(-1.0, 1.0);
+        double b = rng.gen_range(-1.0, 1.0);
+        Vec3 p(a, b, 0.);
+        if (v_sqlen(p) >= 1.) continue;
+        return p;
+    }
+}
+static inline Vec3 reflect(Vec3 v_in, Vec3 n) {  // :163-165   v - (2*(v.n))*n
+    return v_sub(v_in, v_muls(n, 2. * v_dot(v_in, n)));
+}
+static inline Vec3 refract(Vec3 uv, Vec3 n, double etai_over_etat) {  // :167-172
+    double cos_theta = std::fmin(v_dot(v_neg(uv), n), 1.0);
+    Vec3 r_out_perp = v_muls(v_add(uv, v_muls(n, cos_theta)), etai_over_etat);
+    Vec3 r_out_parallel = v_muls(n, -std::sqrt(std::fabs(1.0 - v_sqlen(r_out_perp))));
+    return v_add(r_out_perp, r_out_parallel);
+}
+
+// 4x4 matrix, row-major; stands in for nalgebra::Matrix4<f64> (transform.rs, vec3.rs:174-184)
+struct Mat4 {
+    double m[4][4];
+};
+static Mat4 mat_mul(const Mat4& a, const Mat4& b) {
+    Mat4 c;
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+            double acc = a.m[i][0] * b.m[0][j];
+            for (int k = 1; k < 4; k++) acc = acc + a.m[i][k] * b.m[k][j];
+            c.m[i][j] = acc;
+        }
+    return c;
+}
+// General 4x4 inverse by cofactors (the MESA/GLU formula nalgebra's 4x4
+// try_inverse specialisation uses); returns false when det == 0.
+static bool mat_inverse(const Mat4& a, Mat4& out) {
+    // column-major flat view, as in the GLU routine
+    double m[16], inv[16];
+    for (int c = 0; c < 4; c++)
+        for (int r = 0; r < 4; r++) m[c * 4 + r] = a.m[r][c];
+    inv[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
+    inv[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] - m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
+    inv[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] + m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
+    inv[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] - m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
+    inv[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] - m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
+    inv[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] + m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
+    inv[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] - m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
+    inv[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] + m[12] * m[1] * m[10] - m[12] * m[2] * m[9];
+    inv[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] + m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
+    inv[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] - m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
+    inv[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] + m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
+    inv[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] - m[12] * m[1] * m[6] + m[12] * m[2] * m[5];
+    inv[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] - m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
+    inv[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] + m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
+    inv[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
+    inv[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
+    double det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12];
+    if (det == 0.) return false;
+    double inv_det = 1.0 / det;
+    for (int c = 0; c < 4; c++)
+        for (int r = 0; r < 4; r++) out.m[r][c] = inv[c * 4 + r] * inv_det;
+    return true;
+}
+static inline Vec3 transform_point(Vec3 p, const Mat4& t) {  // vec3.rs:174-178 (w = 1)
+    return Vec3(t.m[0][0] * p.x + t.m[0][1] * p.y + t.m[0][2] * p.z + t.m[0][3] * 1.,
+                t.m[1][0] * p.x + t.m[1][1] * p.y + t.m[1][2] * p.z + t.m[1][3] * 1.,
+                t.m[2][0] * p.x + t.m[2][1] * p.y + t.m[2][2] * p.z + t.m[2][3] * 1.);
+}
+static inline Vec3 transform_dir(Vec3 p, const Mat4& t) {  // vec3.rs:180-184 (w = 0)
+    return Vec3(t.m[0][0] * p.x + t.m[0][1] * p.y + t.m[0][2] * p.z + t.m[0][3] * 0.,
+                t.m[1][0] * p.x + t.m[1][1] * p.y + t.m[1][2] * p.z + t.m[1][3] * 0.,
+                t.m[2][0] * p.x + t.m[2][1] * p.y + t.m[2][2] * p.z + t.m[2][3] * 0.);
+}
+
+// ----------------------------------------------------------------------------
+// Ray -- raytracer/src/ray.rs:3-15
+// ----------------------------------------------------------------------------
+struct Ray {
+    Vec3 orig, dir;
+    Vec3 at(double t) const { return v_add(orig, v_muls(dir, t)); }
+};
+
+// Test counters (instrumentation only; feeds SURVEY s8d B_alg).
+struct Counters {
+    uint64_t n_aabb = 0, n_sphere = 0, n_rect = 0, n_tri = 0, n_xform = 0;
+    uint64_t n_segments = 0;  // World::hit calls
+    uint64_t n_samples = 0;
+    void add(const Counters& o) {
+        n_aabb += o.n_aabb; n_sphere += o.n_sphere; n_rect += o.n_rect; n_tri += o.n_tri;
+        n_xform += o.n_xform; n_segments += o.n_segments; n_samples += o.n_samples;
+    }
+};
+// Per-thread traversal context: RNG stream of the current sample + counters.
+struct Ctx {
+    Rng rng;
+    Counters cnt;
+};
+
+struct Material;
+
+// ----------------------------------------------------------------------------
+// HitRecord -- raytracer/src/objects/hit.rs:7-48
+// ----------------------------------------------------------------------------
+struct HitRecord {
+    Vec3 p, normal;
+    double t = 0;
+    bool front_face = false;
+    const Material* mat = nullptr;
+    double u = 0, v = 0;
+    int prim_id = -1;  // instrumentation: id of the primitive object that produced the hit
+
+    // hit.rs:16-39: p = r.at(t); face test on the un-normalised dir; normal re-normalised (Q6).
+    static HitRecord make(double t, Vec3 outward_normal, const Ray& r, const Material* mat, double u, double v, int prim) {
+        HitRecord h;
+        h.p = r.at(t);
+        h.front_face = v_dot(r.dir, outward_normal) < 0.;
+        Vec3 n = h.front_face ? outward_normal : v_neg(outward_normal);
+        h.normal = v_unit(n);
+        h.t = t;
+        h.mat = mat;
+        h.u = u;
+        h.v = v;
+        h.prim_id = prim;
+        return h;
+    }
+    // hit.rs:41-48
+    void set_face_normal(const Ray& r, Vec3 outward_normal) {
+        front_face = v_dot(r.dir, outward_normal) < 0.;
+        normal = front_face ? v_unit(outward_normal) : v_neg(v_unit(outward_normal));
+    }
+};
+
+// ----------------------------------------------------------------------------
+// Textures -- raytracer/src/material.rs:18-20, 48-84
+// ----------------------------------------------------------------------------
+struct Texture {
+    virtual ~Texture() {}
+    virtual Vec3 get_color(const HitRecord& rec) const = 0;
+};
+struct ConstantTexture : Texture {  // material.rs:48,52-56
+    Vec3 c;
+    explicit ConstantTexture(Vec3 c_) : c(c_) {}
+    Vec3 get_color(const HitRecord&) const override { return c; }
+};
+struct CheckerTexture : Texture {  // material.rs:49,58-68 ; .0 when sines < 0
+    const Texture *t0, *t1;
+    CheckerTexture(const Texture* a, const Texture* b) : t0(a), t1(b) {}
+    Vec3 get_color(const HitRecord& rec) const override {
+        Vec3 p = rec.p;
+        double sines = std::sin(10. * p.x) * std::sin(10. * p.y) * std::sin(10. * p.z);
+        return (sines < 0.) ? t0->get_color(rec) : t1->get_color(rec);
+    }
+};
+struct ImageTexture : Texture {  // material.rs:50,70-84 ; Q11: x==width at u==1 panics in Rust -> clamped here
+    int w, h;
+    std::vector<uint8_t> rgb;
+    ImageTexture(int w_, int h_, const uint8_t* d) : w(w_), h(h_), rgb(d, d + (size_t)w_ * h_ * 3) {}
+    Vec3 get_color(const HitRecord& rec) const override {
+        double u = rec.u, v = rec.v;
+        u = std::fmin(std::fmax(u, 0.), 1.);
+        v = 1. - std::fmin(std::fmax(v, 0.), 1.);
+        long x = (long)std::floor((double)w * u);
+        long y = (long)std::floor((double)h * v);
+        if (x > w - 1) x = w - 1;  // Q11 clamp (documented divergence: Rust would panic)
+        if (y > h - 1) y = h - 1;
+        const uint8_t* px = &rgb[((size_t)y * w + x) * 3];
+        return Vec3(px[0] / 255., px[1] / 255., px[2] / 255.);  // vec3.rs:233-238
+    }
+};
+
+// ----------------------------------------------------------------------------
+// Materials -- raytracer/src/material.rs:10-46 (trait), :86-212 (impls)
+// ----------------------------------------------------------------------------
+enum Interaction { Diffuse, Specular, Absorb, Reflect, Refract };  // material.rs:10-16
+struct ScatterResult {
+    Interaction kind;
+    bool has_ray, has_att;
+    Ray ray;
+    Vec3 att;
+};
+struct Material {
+    virtual ~Material() {}
+    virtual Vec3 bsdf(Vec3 r_dir, const HitRecord& rec) const = 0;
+    virtual ScatterResult scatter(const Ray& r, const HitRecord& rec, Ctx& cx) const = 0;
+    virtual Vec3 emitted(const HitRecord&) const { return Vec3(0, 0, 0); }  // material.rs:24-26
+};
+// material.rs:92-98
+static inline Vec3 scattered_direction(Vec3 n, Ctx& cx) {
+    Vec3 d = v_add(n, random_unit_vector(cx.rng));
+    if (v_near_zero(d)) d = n;
+    return d;
+}
+struct Lambertian : Material {  // material.rs:88-113
+    const Texture* albedo;
+    explicit Lambertian(const Texture* a) : albedo(a) {}
+    Vec3 bsdf(Vec3, const HitRecord& rec) const override { return albedo->get_color(rec); }
+    ScatterResult scatter(const Ray& r, const HitRecord& rec, Ctx& cx) const override {
+        Ray s{rec.p, scattered_direction(rec.normal, cx)};
+        return ScatterResult{Diffuse, true, true, s, bsdf(r.dir, rec)};
+    }
+};
+struct Metal : Material {  // material.rs:115-139 ; RNG drawn even for fuzz == 0 (Q4); Absorb when pointing inward (Q15)
+    const Texture* albedo;
+    double fuzz;
+    Metal(const Texture* a, double f) : albedo(a), fuzz(f) {}
+    Vec3 bsdf(Vec3, const HitRecord& rec) const override { return albedo->get_color(rec); }
+    ScatterResult scatter(const Ray& r, const HitRecord& rec, Ctx& cx) const override {
+        Vec3 reflected = reflect(v_unit(r.dir), rec.normal);
+        Ray s{rec.p, v_add(reflected, v_muls(random_in_unit_sphere(cx.rng), fuzz))};
+        if (v_dot(s.dir, rec.normal) > 0.) return ScatterResult{Specular, true, true, s, bsdf(r.dir, rec)};
+        return ScatterResult{Absorb, false, false, Ray{}, Vec3()};
+    }
+};
+struct Dielectric : Material {  // material.rs:141-188
+    double ir;
+    const Texture* albedo;
+    Dielectric(double i, const Texture* a) : ir(i), albedo(a) {}
+    static double reflectance(double cosine, double ref_idx) {  // :150-154 Schlick; powi(2), powi(5)
+        double q = (1. - ref_idx) / (1. + ref_idx);
+        double r0 = q * q;
+        double b = 1. - cosine;
+        double b2 = b * b;
+        double b4 = b2 * b2;
+        double b5 = b * b4;  // powi(5) = a * (a^2)^2 (compiler-rt __powidf2 / LLVM powi expansion order)
+        return r0 + (1. - r0) * b5;
+    }
+    Vec3 bsdf(Vec3, const HitRecord& rec) const override { return albedo->get_color(rec); }
+    ScatterResult scatter(const Ray& r, const HitRecord& rec, Ctx& cx) const override {
+        Vec3 attenuation = bsdf(r.dir, rec);
+        double refraction_ratio = rec.front_face ? (1.0 / ir) : ir;
+        Vec3 unit_direction = v_unit(r.dir);
+        double cos_theta = std::fmin(v_dot(v_neg(unit_direction), rec.normal), 1.0);
+        double sin_theta = std::sqrt(1.0 - cos_theta * cos_theta);
+        bool cannot_refract = refraction_ratio * sin_theta > 1.0;
+        Vec3 direction;
+        Interaction kind;
+        // short-circuit: the random number is consumed only when refraction is possible (Q16)
+        if (cannot_refract || reflectance(cos_theta, refraction_ratio) > cx.rng.gen_f64()) {
+            direction = reflect(unit_direction, rec.normal);
+            kind = Reflect;
+        } else {
+            direction = refract(unit_direction, rec.normal, refraction_ratio);
+            kind = Refract;
+        }
+        return ScatterResult{kind, true, true, Ray{rec.p, direction}, attenuation};
+    }
+};
+struct DiffuseLight : Material {  // material.rs:190-212 ; Q10
+    const Texture* emit;
+    explicit DiffuseLight(const Texture* e) : emit(e) {}
+    Vec3 bsdf(Vec3, const HitRecord&) const override { return v_muls(Vec3(1, 1, 1), FRAC_1_PI); }
+    ScatterResult scatter(const Ray& r, const HitRecord& rec, Ctx& cx) const override {
+        Ray s{rec.p, scattered_direction(rec.normal, cx)};
+        return ScatterResult{Diffuse, true, true, s, bsdf(r.dir, rec)};
+    }
+    Vec3 emitted(const HitRecord& rec) const override { return emit->get_color(rec); }
+};
+
+// ----------------------------------------------------------------------------
+// AABB -- raytracer/src/objects/aabb.rs:5-45
+// ----------------------------------------------------------------------------
+struct AABB {
+    Vec3 minimum, maximum;
+    // aabb.rs:15-32 ; f64::max/min ignore NaN -> fmax/fmin (NOT std::max)
+    bool hit(const Ray& r, double t_min, double t_max, Ctx& cx) const {
+        cx.cnt.n_aabb++;
+        double mn = t_min, mx = t_max;
+        for (int a = 0; a < 3; a++) {
+            double inv_d = 1.0 / r.dir[a];
+            double t0 = (minimum[a] - r.orig[a]) * inv_d;
+            double t1 = (maximum[a] - r.orig[a]) * inv_d;
+            if (inv_d < 0.0) std::swap(t0, t1);
+            mn = std::fmax(mn, t0);
+            mx = std::fmin(mx, t1);
+            if (mx <= mn) return false;
+        }
+        return true;
+    }
+    static AABB surrounding_box(const AABB& a, const AABB& b) {  // aabb.rs:33-45
+        Vec3 small(std::fmin(a.minimum.x, b.minimum.x), std::fmin(a.minimum.y, b.minimum.y), std::fmin(a.minimum.z, b.minimum.z));
+        Vec3 big(std::fmax(a.maximum.x, b.maximum.x), std::fmax(a.maximum.y, b.maximum.y), std::fmax(a.maximum.z, b.maximum.z));
+        return AABB{small, big};
+    }
+};
+
+// ----------------------------------------------------------------------------
+// Hitable -- raytracer/src/objects/hit.rs:51-54
+// ----------------------------------------------------------------------------
+struct Hitable {
+    int id = -1;
+    virtual ~Hitable() {}
+    virtual bool hit(const Ray& r, double t_min, double t_max, HitRecord& out, Ctx& cx) const = 0;
+    virtual bool bounding_box(AABB& out) const = 0;
+};
+
+// impl Hitable for Vec<Arc<dyn Hitable>> -- hit.rs:56-93
+struct HitableList : Hitable {
+    std::vector<const Hitable*> items;
+    bool hit(const Ray& r, double t_min, double t_max, HitRecord& out, Ctx& cx) const override {
+        double closest = t_max;
+        bool any = false;
+        HitRecord tmp;
+        for (const Hitable* o : items) {
+            if (o->hit(r, t_min, closest, tmp, cx)) {
+                closest = tmp.t;
+                out = tmp;
+                any = true;
+            }
+        }
+        return any;
+    }
+    bool bounding_box(AABB& out) const override {
+        if (items.empty()) return false;
+        bool first = true;
+        AABB acc{Vec3(), Vec3()};
+        for (const Hitable* o : items) {
+            AABB b;
+            if (!o->bounding_box(b)) return false;
+            acc = first ? b : AABB::surrounding_box(acc, b);
+            first = false;
+        }
+        out = acc;
+        return true;
+    }
+};
+
+// Sphere -- raytracer/src/objects/sphere.rs:8-62
+struct Sphere : Hitable {
+    Vec3 center;
+    double radius;
+    const Material* material;
+    static void get_uv(Vec3 p, double& u, double& v) {  // :16-20
+        double theta = std::acos(-p.y);
+        double phi = std::atan2(-p.z, p.x) + PI;
+        u = phi * FRAC_1_PI * 0.5;
+        v = theta * FRAC_1_PI;
+    }
+    bool hit(const Ray& r, double t_min, double t_max, HitRecord& out, Ctx& cx) const override {  // :24-55
+        cx.cnt.n_sphere++;
+        Vec3 oc = v_sub(r.orig, center);
+        double a = v_sqlen(r.dir);
+        double half_b = v_dot(oc, r.dir);
+        double c = v_sqlen(oc) - radius * radius;
+        double discriminant = half_b * half_b - a * c;  // half_b.powf(2.0)
+        if (discriminant < 0.) return false;
+        double sqrt_d = std::sqrt(discriminant);
+        double root = (-half_b - sqrt_d) / a;
+        if (!(root >= t_min && root <= t_max)) root = (-half_b + sqrt_d) / a;
+        if (!(root >= t_min && root <= t_max)) return false;
+        Vec3 p = r.at(root);
+        Vec3 outward = v_divs(v_sub(p, center), radius);
+        double u, v;
+        get_uv(outward, u, v);  // computed for every candidate, as the reference does (:52)
+        out = HitRecord::make(root, outward, r, material, u, v, id);
+        return true;
+    }
+    bool bounding_box(AABB& out) const override {  // :56-61
+        out = AABB{v_sub(center, Vec3(radius, radius, radius)), v_add(center, Vec3(radius, radius, radius))};
+        return true;
+    }
+};
+
+// XY/XZ/YZ rectangles -- raytracer/src/objects/rectangle.rs:7-117.
+// axis = the constant axis (2: XY rect, 1: XZ rect, 0: YZ rect).
+// No guard on a zero direction component: t may be NaN/inf and every reject
+// comparison is then false -> Some(t = NaN); restated literally.
+struct Rect : Hitable {
+    int axis;
+    double a0, b0, a1, b1, k;
+    const Material* material;
+    bool hit(const Ray& r, double t_min, double t_max, HitRecord& out, Ctx& cx) const override {
+        cx.cnt.n_rect++;
+        double t = (k - r.orig[axis]) / r.dir[axis];
+        if (t < t_min || t > t_max) return false;
+        Vec3 p = r.at(t);
+        double a, b;
+        Vec3 n;
+        if (axis == 2) { a = p.x; b = p.y; n = Vec3(0., 0., 1.); }       // :15-34
+        else if (axis == 1) { a = p.x; b = p.z; n = Vec3(0., 1., 0.); }  // :53-72
+        else { a = p.y; b = p.z; n = Vec3(1., 0., 0.); }                 // :90-109
+        if (a < a0 || a > a1 || b < b0 || b > b1) return false;
+        out = HitRecord::make(t, n, r, material, (a - a0) / (a1 - a0), (b - b0) / (b1 - b0), id);
+        return true;
+    }
+    bool bounding_box(AABB& out) const override {  // :35-41, :73-79, :110-116
+        const double BIAS = 0.0001;
+        if (axis == 2) out = AABB{Vec3(a0, b0, k - BIAS), Vec3(a1, b1, k + BIAS)};
+        else if (axis == 1) out = AABB{Vec3(a0, k - BIAS, b0), Vec3(a1, k + BIAS, b1)};
+        else out = AABB{Vec3(k - BIAS, a0, b0), Vec3(k + BIAS, a1, b1)};
+        return true;
+    }
+};
+
+// Cube -- raytracer/src/objects/cube.rs:9-70 : 6 rects scanned as a list; bbox = (min,max)
+struct Cube : Hitable {
+    Vec3 box_min, box_max;
+    HitableList sides;
+    bool hit(const Ray& r, double t_min, double t_max, HitRecord& out, Ctx& cx) const override {
+        return sides.hit(r, t_min, t_max, out, cx);
+    }
+    bool bounding_box(AABB& out) const override {
+        out = AABB{box_min, box_max};
+        return true;
+    }
+};
+
+// BVHNode -- raytracer/src/objects/bvh.rs:29-106
+struct BVHNode : Hitable {
+    const Hitable *left = nullptr, *right = nullptr;
+    AABB box;
+    bool hit(const Ray& r, double t_min, double t_max, HitRecord& out, Ctx& cx) const override {  // :86-102
+        if (!box.hit(r, t_min, t_max, cx)) return false;
+        HitRecord hl, hr;
+        bool l = left->hit(r, t_min, t_max, hl, cx);
+        double left_t_max = l ? hl.t : t_max;
+        bool rr = right->hit(r, t_min, left_t_max, hr, cx);
+        if (rr) { out = hr; return true; }
+        if (l) { out = hl; return true; }
+        return false;
+    }
+    bool bounding_box(AABB& out) const override {
+        out = box;
+        return true;
+    }
+};
+
+// Triangle -- raytracer/src/objects/mesh.rs:8-142
+struct MeshData {
+    std::vector<Vec3> positions, normals;
+};
+struct Triangle : Hitable {
+    size_t a, b, c;
+    const MeshData* md;
+    AABB box;
+    const Material* material;
+    void init_box() {  // mesh.rs:29-42 : +-0.1 padding in object space (Q9)
+        const Vec3 &pa = md->positions[a], &pb = md->positions[b], &pc = md->positions[c];
+        Vec3 mx(std::fmax(std::fmax(pa.x, pb.x), pc.x) + 0.1, std::fmax(std::fmax(pa.y, pb.y), pc.y) + 0.1, std::fmax(std::fmax(pa.z, pb.z), pc.z) + 0.1);
+        Vec3 mn(std::fmin(std::fmin(pa.x, pb.x), pc.x) - 0.1, std::fmin(std::fmin(pa.y, pb.y), pc.y) - 0.1, std::fmin(std::fmin(pa.z, pb.z), pc.z) - 0.1);
+        box = AABB{mn, mx};
+    }
+    bool hit(const Ray& ray, double t_min, double t_max, HitRecord& out, Ctx& cx) const override {  // :57-137
+        cx.cnt.n_tri++;
+        const Vec3 &pa = md->positions[a], &pb = md->positions[b], &pc = md->positions[c];
+        const Vec3 &na = md->normals[a], &nb = md->normals[b], &nc = md->normals[c];
+        Vec3 e0 = v_sub(pb, pa), e1 = v_sub(pc, pa);
+        Vec3 s0 = v_cross(ray.dir, e1);
+        double dd = v_dot(s0, e0);
+        if (dd == 0.0) return false;
+        double div = 1.0 / dd;
+        Vec3 d = v_sub(ray.orig, pa);
+        double b1 = v_dot(d, s0) * div;
+        if (b1 < 0.0 || b1 > 1.0) return false;
+        Vec3 s1 = v_cross(d, e0);
+        double b2 = v_dot(ray.dir, s1) * div;
+        if (b2 < 0.0 || b1 + b2 > 1.0) return false;
+        double t = v_dot(e1, s1) * div;
+        if (t < t_min || t > t_max) return false;
+        double b0 = 1.0 - b1 - b2;
+        Vec3 n = v_unit(v_add(v_add(v_muls(na, b0), v_muls(nb, b1)), v_muls(nc, b2)));
+        out = HitRecord::make(t, n, ray, material, 0.0, 0.0, id);
+        return true;
+    }
+    bool bounding_box(AABB& out) const override {
+        out = box;
+        return true;
+    }
+};
+
+// Mesh -- raytracer/src/objects/mesh.rs:144-208 : per-mesh inner BVHNode
+struct Mesh : Hitable {
+    std::unique_ptr<MeshData> md;
+    const Hitable* bvh = nullptr;
+    bool hit(const Ray& r, double t_min, double t_max, HitRecord& out, Ctx& cx) const override {
+        return bvh->hit(r, t_min, t_max, out, cx);
+    }
+    bool bounding_box(AABB& out) const override { return bvh->bounding_box(out); }
+};
+
+// Transform -- raytracer/src/objects/transform.rs:9-169
+struct Transform : Hitable {
+    const Hitable* obj;
+    Mat4 trans, inverse_trans;
+    bool has_box = false;
+    AABB box;
+    bool hit(const Ray& r, double t_min, double t_max, HitRecord& out, Ctx& cx) const override {  // :152-165
+        cx.cnt.n_xform++;
+        Ray trans_r{transform_point(r.orig, inverse_trans), transform_dir(r.dir, inverse_trans)};
+        HitRecord rec;
+        if (!obj->hit(trans_r, t_min, t_max, rec, cx)) return false;
+        Vec3 outward_normal = transform_dir(rec.normal, trans);  // M, not inverse-transpose (Q7)
+        rec.p = transform_point(rec.p, trans);
+        rec.set_face_normal(trans_r, outward_normal);  // object-space ray vs world normal (Q8)
+        out = rec;
+        return true;
+    }
+    bool bounding_box(AABB& out) const override {
+        if (!has_box) return false;
+        out = box;
+        return true;
+    }
+};
+
+// ----------------------------------------------------------------------------
+// Camera -- raytracer/src/camera.rs:11-64
+// ----------------------------------------------------------------------------
+struct Camera {
+    Vec3 origin, lower_left_corner, horizontal, vertical, u, v, w;
+    double lens_radius = 0;
+    void init(Vec3 look_from, Vec3 look_at, Vec3 vup, double vfov, double aspect_ratio, double aperture, double focus_dist) {
+        double theta = vfov * PI / 180.;  // degrees_to_radians, vec3.rs:10-12
+        double h = std::tan(theta / 2.);
+        double viewport_height = 2.0 * h;
+        double viewport_width = aspect_ratio * viewport_height;
+        w = v_unit(v_sub(look_from, look_at));
+        u = v_unit(v_cross(vup, w));
+        v = v_cross(w, u);
+        origin = look_from;
+        horizontal = v_muls(u, focus_dist * viewport_width);
+        vertical = v_muls(v, focus_dist * viewport_height);
+        lower_left_corner = v_sub(v_sub(v_sub(origin, v_divs(horizontal, 2.)), v_divs(vertical, 2.)), v_muls(w, focus_dist));
+        lens_radius = aperture / 2.;
+    }
+    // camera.rs:57-64 ; the lens sample is drawn even when lens_radius == 0 (Q4)
+    Ray get_ray(double s, double t, Rng& rng) const {
+        Vec3 rd = v_muls(random_in_unit_disk(rng), lens_radius);
+        Vec3 offset = v_add(v_muls(u, rd.x), v_muls(v, rd.y));
+        Vec3 o = v_add(origin, offset);
+        Vec3 d = v_sub(v_sub(v_add(v_add(lower_left_corner, v_muls(horizontal, s)), v_muls(vertical, t)), origin), offset);
+        return Ray{o, d};
+    }
+};
+
+// ----------------------------------------------------------------------------
+// World + Integrator::sample_ray
+//   world.rs:27-29 ; integrator/photon_mapper.rs:327-365 with divergence D2.
+// ----------------------------------------------------------------------------
+struct Scene {
+    std::vector<std::unique_ptr<Texture>> textures;
+    std::vector<std::unique_ptr<Material>> materials;
+    std::vector<std::unique_ptr<Hitable>> objects;
+    const Hitable* root = nullptr;
+    Camera cam;
+    bool cam_set = false;
+    std::string err;
+};
+
+static Vec3 sample_ray(const Scene& sc, Ray ray, int max_depth, double t_min, Ctx& cx) {
+    Vec3 throughput(1, 1, 1);
+    Vec3 radiance(0, 0, 0);
+    Ray curr = ray;
+    int depth = max_depth;
+    HitRecord rec;
+    for (;;) {
+        cx.cnt.n_segments++;
+        if (!sc.root->hit(curr, t_min, INF, rec, cx)) break;  // miss => black background
+        if (depth <= 0) break;                                // Q12: test after the hit
+        depth -= 1;
+        radiance = v_add(radiance, v_elemul(throughput, rec.mat->emitted(rec)));  // Le, no face test
+        ScatterResult sr = rec.mat->scatter(curr, rec, cx);
+        if (sr.has_ray && sr.has_att) {
+            // D2: Diffuse continues exactly like Specular/Reflect/Refract
+            throughput = v_elemul(throughput, sr.att);
+            curr = sr.ray;
+        } else {
+            break;  // Absorb
+        }
+    }
+    return radiance;
+}
+
+struct RenderArgs {
+    int width, height, spp, max_depth;
+    double t_min;
+    uint64_t seed;
+    int x0, y0, x1, y1;  // pixel window [x0,x1) x [y0,y1) rendered with the full-frame camera mapping
+};
+
+// Camera::capture_image -- camera.rs:66-128.  n_jobs row bands executed FIFO by
+// n_workers threads; per-pixel sample loop :96-102.  Output: linear radiance
+// (sum / spp) f64 RGB, row-major, y down, window-local indexing.
+static int render(const Scene& sc, const RenderArgs& a, int n_jobs, int n_workers, double* out_rgb, Counters* total) {
+    if (!sc.root || !sc.cam_set) return -1;
+    const int wh = a.y1 - a.y0, ww = a.x1 - a.x0;
+    if (n_jobs < 1) n_jobs = 1;
+    if (n_workers < 1) n_workers = 1;
+    std::atomic<int> next_job{0};
+    std::atomic<int> err{0};
+    std::mutex mu;
+    Counters sum;
+    auto worker = [&]() {
+        Ctx cx;
+        for (;;) {
+            int i = next_job.fetch_add(1);
+            if (i >= n_jobs) break;
+            int row_begin = a.y0 + (int)((long)wh * i / n_jobs);      // camera.rs:85
+            int row_end = a.y0 + (int)((long)wh * (i + 1) / n_jobs);  // camera.rs:86
+            try {
+                for (int x = a.x0; x < a.x1; x++) {  // x is the OUTER loop, camera.rs:91
+                    for (int y = row_begin; y < row_end; y++) {
+                        Vec3 pixel(0, 0, 0);
+                        for (int s = 0; s < a.spp; s++) {
+                            cx.rng = Rng(a.seed, (uint64_t)y * (uint64_t)a.width + (uint64_t)x, (uint64_t)s);
+                            double u = ((double)x + cx.rng.gen_f64()) / (double)(a.width - 1);
+                            double v = ((double)y + cx.rng.gen_f64()) / (double)(a.height - 1);
+                            Ray r = sc.cam.get_ray(u, 1.0 - v, cx.rng);
+                            pixel = v_add(pixel, sample_ray(sc, r, a.max_depth, a.t_min, cx));
+                            cx.cnt.n_samples++;
+                        }
+                        pixel = v_divs(pixel, (double)a.spp);
+                        double* o = out_rgb + ((size_t)(y - a.y0) * ww + (x - a.x0)) * 3;
+                        o[0] = pixel.x; o[1] = pixel.y; o[2] = pixel.z;
+                    }
+                }
+            } catch (const UnitZero&) {
+                err.store(-2);
+            }
+        }
+        std::lock_guard<std::mutex> g(mu);
+        sum.add(cx.cnt);
+    };
+    std::vector<std::thread> th;
+    for (int i = 0; i < n_workers; i++) th.emplace_back(worker);
+    for (auto& t : th) t.join();
+    if (total) *total = sum;
+    return err.load();
+}
+
+// From<Vec3> for Rgb<u8> -- vec3.rs:223-231 : floor(clamp(sqrt(c),0,1)*255); NaN -> 0 (saturating cast)
+static inline uint8_t tonemap_channel(double c) {
+    double s = std::sqrt(c);
+    if (s < 0.) s = 0.;        // f64::clamp: NaN stays NaN
+    else if (s > 1.) s = 1.;
+    double f = std::floor(s * 255.);
+    if (!(f == f)) return 0;   // NaN as u8 == 0
+    if (f <= 0.) return 0;
+    if (f >= 255.) return 255;
+    return (uint8_t)f;
+}
+
+// BVHNode::construct / ::new / box_compare -- bvh.rs:34-83 (axis from a seeded stream, D3)
+static const Hitable* bvh_construct(Scene& sc, const Hitable* l, const Hitable* r) {
+    AABB bl, br;
+    if (!l->bounding_box(bl) || !r->bounding_box(br)) throw std::runtime_error("No bounding box in bvh_node constructor.");
+    auto n = std::make_unique<BVHNode>();
+    n->left = l;
+    n->right = r;
+    n->box = AABB::surrounding_box(bl, br);
+    n->id = (int)sc.objects.size();
+    const Hitable* p = n.get();
+    sc.objects.push_back(std::move(n));
+    return p;
+}
+static const Hitable* bvh_new(Scene& sc, std::vector<const Hitable*> objs, Rng& rng) {
+    int axis = (int)rng.gen_below3();  // bvh.rs:61-62
+    auto less = [axis](const Hitable* a, const Hitable* b) {  // box_compare: only "Less" is observable to a stable sort
+        AABB ba, bb;
+        if (!a->bounding_box(ba) || !b->bounding_box(bb)) throw std::runtime_error("No bounding box in bvh_node constructor.");
+        return ba.minimum[axis] < bb.minimum[axis];
+    };
+    size_t n = objs.size();
+    if (n == 0) throw std::runtime_error("BVHNode::new on an empty list");
+    if (n == 1) return bvh_construct(sc, objs[0], objs[0]);  // Q14: same object in both children
+    if (n == 2) {
+        if (less(objs[0], objs[1])) return bvh_construct(sc, objs[0], objs[1]);  // .is_le() is true only for Less
+        return bvh_construct(sc, objs[1], objs[0]);
+    }
+    std::stable_sort(objs.begin(), objs.end(), less);  // slice::sort_by is a stable merge sort
+    size_t mid = n / 2;
+    std::vector<const Hitable*> lo(objs.begin(), objs.begin() + mid), hi(objs.begin() + mid, objs.end());
+    const Hitable* l = bvh_new(sc, lo, rng);
+    const Hitable* r = bvh_new(sc, hi, rng);
+    return bvh_construct(sc, l, r);
+}
+
+}  // namespace orc
+
+// ============================================================================
+// C API for the ctypes harness (tests / smoke / cpu_baseline only)
+// ============================================================================
+using namespace orc;
+
+#define ORC_OK 0
+#define ORC_ERR_ARG -1
+#define ORC_ERR_UNIT_ZERO -2
+#define ORC_ERR_BUILD -3
+
+template <class T>
+static int push_obj(Scene& sc, std::unique_ptr<T> o) {
+    o->id = (int)sc.objects.size();
+    sc.objects.push_back(std::move(o));
+    return (int)sc.objects.size() - 1;
+}
+
+extern "C" {
+
+void* orc_scene_new() { return new Scene(); }
+void orc_scene_free(void* s) { delete (Scene*)s; }
+const char* orc_last_error(void* s) { return ((Scene*)s)->err.c_str(); }
+
+int orc_tex_constant(void* s, double r, double g, double b) {
+    Scene& sc = *(Scene*)s;
+    sc.textures.emplace_back(new ConstantTexture(Vec3(r, g, b)));
+    return (int)sc.textures.size() - 1;
+}
+int orc_tex_checker(void* s, int t0, int t1) {
+    Scene& sc = *(Scene*)s;
+    if (t0 < 0 || t1 < 0 || t0 >= (int)sc.textures.size() || t1 >= (int)sc.textures.size()) return ORC_ERR_ARG;
+    sc.textures.emplace_back(new CheckerTexture(sc.textures[t0].get(), sc.textures[t1].get()));
+    return (int)sc.textures.size() - 1;
+}
+int orc_tex_image(void* s, int w, int h, const uint8_t* rgb) {
+    Scene& sc = *(Scene*)s;
+    if (w <= 0 || h <= 0 || !rgb) return ORC_ERR_ARG;
+    sc.textures.emplace_back(new ImageTexture(w, h, rgb));
+    return (int)sc.textures.size() - 1;
+}
+static const Texture* tex(Scene& sc, int t) { return (t >= 0 && t < (int)sc.textures.size()) ? sc.textures[t].get() : nullptr; }
+static const Material* mat(Scene& sc, int m) { return (m >= 0 && m < (int)sc.materials.size()) ? sc.materials[m].get() : nullptr; }
+static const Hitable* obj(Scene& sc, int o) { return (o >= 0 && o < (int)sc.objects.size()) ? sc.objects[o].get() : nullptr; }
+
+int orc_mat_lambertian(void* s, int t) {
+    Scene& sc = *(Scene*)s;
+    if (!tex(sc, t)) return ORC_ERR_ARG;
+    sc.materials.emplace_back(new Lambertian(tex(sc, t)));
+    return (int)sc.materials.size() - 1;
+}
+int orc_mat_metal(void* s, int t, double fuzz) {
+    Scene& sc = *(Scene*)s;
+    if (!tex(sc, t)) return ORC_ERR_ARG;
+    sc.materials.emplace_back(new Metal(tex(sc, t), fuzz));
+    return (int)sc.materials.size() - 1;
+}
+int orc_mat_dielectric(void* s, double ir, int t) {
+    Scene& sc = *(Scene*)s;
+    if (!tex(sc, t)) return ORC_ERR_ARG;
+    sc.materials.emplace_back(new Dielectric(ir, tex(sc, t)));
+    return (int)sc.materials.size() - 1;
+}
+int orc_mat_diffuse_light(void* s, int t) {
+    Scene& sc = *(Scene*)s;
+    if (!tex(sc, t)) return ORC_ERR_ARG;
+    sc.materials.emplace_back(new DiffuseLight(tex(sc, t)));
+    return (int)sc.materials.size() - 1;
+}
+
+int orc_sphere(void* s, double cx, double cy, double cz, double r, int m) {
+    Scene& sc = *(Scene*)s;
+    if (!mat(sc, m)) return ORC_ERR_ARG;
+    auto o = std::make_unique<Sphere>();
+    o->center = Vec3(cx, cy, cz);
+    o->radius = r;
+    o->material = mat(sc, m);
+    return push_obj(sc, std::move(o));
+}
+// axis: 2 = XYRectangle{xy0,xy1,z}, 1 = XZRectangle{xz0,xz1,y}, 0 = YZRectangle{yz0,yz1,x}
+int orc_rect(void* s, int axis, double a0, double b0, double a1, double b1, double k, int m) {
+    Scene& sc = *(Scene*)s;
+    if (!mat(sc, m) || axis < 0 || axis > 2) return ORC_ERR_ARG;
+    auto o = std::make_unique<Rect>();
+    o->axis = axis; o->a0 = a0; o->b0 = b0; o->a1 = a1; o->b1 = b1; o->k = k;
+    o->material = mat(sc, m);
+    return push_obj(sc, std::move(o));
+}
+static std::unique_ptr<Rect> mk_rect(int axis, double a0, double b0, double a1, double b1, double k, const Material* m) {
+    auto o = std::make_unique<Rect>();
+    o->axis = axis; o->a0 = a0; o->b0 = b0; o->a1 = a1; o->b1 = b1; o->k = k; o->material = m;
+    return o;
+}
+int orc_cube(void* s, const double* mn, const double* mx, int m) {  // cube.rs:16-61 side order
+    Scene& sc = *(Scene*)s;
+    if (!mat(sc, m)) return ORC_ERR_ARG;
+    const Material* mm = mat(sc, m);
+    auto c = std::make_unique<Cube>();
+    c->box_min = Vec3(mn[0], mn[1], mn[2]);
+    c->box_max = Vec3(mx[0], mx[1], mx[2]);
+    int ids[6];
+    ids[0] = push_obj(sc, mk_rect(2, mn[0], mn[1], mx[0], mx[1], mn[2], mm));
+    ids[1] = push_obj(sc, mk_rect(2, mn[0], mn[1], mx[0], mx[1], mx[2], mm));
+    ids[2] = push_obj(sc, mk_rect(1, mn[0], mn[2], mx[0], mx[2], mn[1], mm));
+    ids[3] = push_obj(sc, mk_rect(1, mn[0], mn[2], mx[0], mx[2], mx[1], mm));
+    ids[4] = push_obj(sc, mk_rect(0, mn[1], mn[2], mx[1], mx[2], mn[0], mm));
+    ids[5] = push_obj(sc, mk_rect(0, mn[1], mn[2], mx[1], mx[2], mx[0], mm));
+    for (int i = 0; i < 6; i++) c->sides.items.push_back(sc.objects[ids[i]].get());
+    return push_obj(sc, std::move(c));
+}
+int orc_list(void* s, int n, const int* ids) {
+    Scene& sc = *(Scene*)s;
+    auto l = std::make_unique<HitableList>();
+    for (int i = 0; i < n; i++) {
+        if (!obj(sc, ids[i])) return ORC_ERR_ARG;
+        l->items.push_back(obj(sc, ids[i]));
+    }
+    return push_obj(sc, std::move(l));
+}
+int orc_bvh_construct(void* s, int l, int r) {
+    Scene& sc = *(Scene*)s;
+    if (!obj(sc, l) || !obj(sc, r)) return ORC_ERR_ARG;
+    try {
+        return bvh_construct(sc, obj(sc, l), obj(sc, r))->id;
+    } catch (const std::exception& e) {
+        sc.err = e.what();
+        return ORC_ERR_BUILD;
+    }
+}
+int orc_bvh_new(void* s, int n, const int* ids, uint64_t seed) {
+    Scene& sc = *(Scene*)s;
+    std::vector<const Hitable*> v;
+    for (int i = 0; i < n; i++) {
+        if (!obj(sc, ids[i])) return ORC_ERR_ARG;
+        v.push_back(obj(sc, ids[i]));
+    }
+    try {
+        Rng rng(seed, 0xB7E151628AED2A6AULL, 0);  // BVH-build stream (spec rtamd-rng-1, "bvh" key)
+        return bvh_new(sc, v, rng)->id;
+    } catch (const std::exception& e) {
+        sc.err = e.what();
+        return ORC_ERR_BUILD;
+    }
+}
+// Mesh::load_obj's result given already-parsed arrays (positions/normals: n_vert*3 f64; idx: n_tri*3)
+int orc_mesh(void* s, int n_vert, const double* pos, const double* nrm, int n_tri, const uint32_t* idx, int m, uint64_t seed) {
+    Scene& sc = *(Scene*)s;
+    if (!mat(sc, m) || n_vert <= 0 || n_tri <= 0 || !pos || !nrm || !idx) return ORC_ERR_ARG;
+    auto me = std::make_unique<Mesh>();
+    me->md = std::make_unique<MeshData>();
+    for (int i = 0; i < n_vert; i++) {
+        me->md->positions.emplace_back(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]);
+        me->md->normals.emplace_back(nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2]);
+    }
+    std::vector<const Hitable*> tris;
+    for (int i = 0; i < n_tri; i++) {
+        for (int k = 0; k < 3; k++)
+            if (idx[3 * i + k] >= (uint32_t)n_vert) return ORC_ERR_ARG;
+        auto t = std::make_unique<Triangle>();
+        t->a = idx[3 * i]; t->b = idx[3 * i + 1]; t->c = idx[3 * i + 2];
+        t->md = me->md.get();
+        t->material = mat(sc, m);
+        t->init_box();
+        int id = push_obj(sc, std::move(t));
+        tris.push_back(sc.objects[id].get());
+    }
+    try {
+        Rng rng(seed, 0xB7E151628AED2A6AULL, 0);
+        me->bvh = bvh_new(sc, tris, rng);
+    } catch (const std::exception& e) {
+        sc.err = e.what();
+        return ORC_ERR_BUILD;
+    }
+    return push_obj(sc, std::move(me));
+}
+// Transform::new -- transform.rs:17-148 : M = T * S * Rx * Ry * Rz
+int orc_transform(void* s, const double* rot_deg, const double* scale, const double* translate, int o) {
+    Scene& sc = *(Scene*)s;
+    if (!obj(sc, o)) return ORC_ERR_ARG;
+    double rx = rot_deg[0] * PI / 180., ry = rot_deg[1] * PI / 180., rz = rot_deg[2] * PI / 180.;
+    Mat4 T = {{{1., 0., 0., translate[0]}, {0., 1., 0., translate[1]}, {0., 0., 1., translate[2]}, {0., 0., 0., 1.}}};
+    Mat4 S = {{{scale[0], 0., 0., 0.}, {0., scale[1], 0., 0.}, {0., 0., scale[2], 0.}, {0., 0., 0., 1.}}};
+    Mat4 RX = {{{1., 0., 0., 0.}, {0., std::cos(rx), -std::sin(rx), 0.}, {0., std::sin(rx), std::cos(rx), 0.}, {0., 0., 0., 1.}}};
+    Mat4 RY = {{{std::cos(ry), 0., std::sin(ry), 0.}, {0., 1., 0., 0.}, {-std::sin(ry), 0., std::cos(ry), 0.}, {0., 0., 0., 1.}}};
+    Mat4 RZ = {{{std::cos(rz), -std::sin(rz), 0., 0.}, {std::sin(rz), std::cos(rz), 0., 0.}, {0., 0., 1., 0.}, {0., 0., 0., 1.}}};
+    Mat4 M = mat_mul(mat_mul(mat_mul(mat_mul(T, S), RX), RY), RZ);
+    auto t = std::make_unique<Transform>();
+    t->obj = obj(sc, o);
+    t->trans = M;
+    AABB bb;
+    if (t->obj->bounding_box(bb)) {  // :110-136 : 8 transformed corners
+        double mn[3] = {INF, INF, INF}, mx[3] = {-INF, -INF, -INF};
+        for (int i = 0; i < 2; i++)
+            for (int j = 0; j < 2; j++)
+                for (int k = 0; k < 2; k++) {
+                    double fi = i, fj = j, fk = k;
+                    Vec3 tester(fi * bb.maximum.x + (1. - fi) * bb.minimum.x, fj * bb.maximum.y + (1. - fj) * bb.minimum.y, fk * bb.maximum.z + (1. - fk) * bb.minimum.z);
+                    tester = transform_point(tester, M);
+                    for (int c = 0; c < 3; c++) {
+                        mn[c] = std::fmin(mn[c], tester[c]);
+                        mx[c] = std::fmax(mx[c], tester[c]);
+                    }
+                }
+        t->box = AABB{Vec3(mn[0], mn[1], mn[2]), Vec3(mx[0], mx[1], mx[2])};
+        t->has_box = true;
+    }
+    if (!mat_inverse(M, t->inverse_trans)) {
+        sc.err = "Invalid transform matrix";  // transform.rs:146
+        return ORC_ERR_BUILD;
+    }
+    return push_obj(sc, std::move(t));
+}
+int orc_set_camera(void* s, const double* from, const double* at, const double* vup, double vfov, double aspect, double aperture, double focus) {
+    Scene& sc = *(Scene*)s;
+    try {
+        sc.cam.init(Vec3(from[0], from[1], from[2]), Vec3(at[0], at[1], at[2]), Vec3(vup[0], vup[1], vup[2]), vfov, aspect, aperture, focus);
+    } catch (const UnitZero&) {
+        return ORC_ERR_UNIT_ZERO;
+    }
+    sc.cam_set = true;
+    return ORC_OK;
+}
+// camera basis readback (origin, llc, horizontal, vertical, u, v, w, lens_radius) = 22 doubles
+int orc_get_camera(void* s, double* out) {
+    Scene& sc = *(Scene*)s;
+    if (!sc.cam_set) return ORC_ERR_ARG;
+    const Vec3* vs[7] = {&sc.cam.origin, &sc.cam.lower_left_corner, &sc.cam.horizontal, &sc.cam.vertical, &sc.cam.u, &sc.cam.v, &sc.cam.w};
+    for (int i = 0; i < 7; i++) { out[3 * i] = vs[i]->x; out[3 * i + 1] = vs[i]->y; out[3 * i + 2] = vs[i]->z; }
+    out[21] = sc.cam.lens_radius;
+    return ORC_OK;
+}
+int orc_set_root(void* s, int o) {
+    Scene& sc = *(Scene*)s;
+    if (!obj(sc, o)) return ORC_ERR_ARG;
+    sc.root = obj(sc, o);
+    return ORC_OK;
+}
+int orc_bounding_box(void* s, int o, double* out6) {
+    Scene& sc = *(Scene*)s;
+    AABB b;
+    if (!obj(sc, o) || !obj(sc, o)->bounding_box(b)) return ORC_ERR_ARG;
+    out6[0] = b.minimum.x; out6[1] = b.minimum.y; out6[2] = b.minimum.z;
+    out6[3] = b.maximum.x; out6[4] = b.maximum.y; out6[5] = b.maximum.z;
+    return ORC_OK;
+}
+
+// counters out: n_aabb, n_sphere, n_rect, n_tri, n_xform, n_segments, n_samples
+int orc_render(void* s, int width, int height, int spp, int max_depth, double t_min, uint64_t seed, int x0, int y0, int x1, int y1,
+               int n_jobs, int n_workers, double* out_rgb, uint64_t* counters7) {
+    Scene& sc = *(Scene*)s;
+    if (width <= 0 || height <= 0 || spp <= 0 || x0 < 0 || y0 < 0 || x1 > width || y1 > height || x1 <= x0 || y1 <= y0 || !out_rgb) return ORC_ERR_ARG;
+    RenderArgs a{width, height, spp, max_depth, t_min, seed, x0, y0, x1, y1};
+    Counters c;
+    int rc = render(sc, a, n_jobs, n_workers, out_rgb, &c);
+    if (counters7) {
+        counters7[0] = c.n_aabb; counters7[1] = c.n_sphere; counters7[2] = c.n_rect; counters7[3] = c.n_tri;
+        counters7[4] = c.n_xform; counters7[5] = c.n_segments; counters7[6] = c.n_samples;
+    }
+    return rc;
+}
+
+// One World::hit for an explicit ray: out = {hit(0/1), t, p[3], normal[3], front_face, u, v, prim_id}
+int orc_hit(void* s, int o, const double* orig, const double* dir, double t_min, double t_max, double* out12) {
+    Scene& sc = *(Scene*)s;
+    const Hitable* h = (o < 0) ? sc.root : obj(sc, o);
+    if (!h) return ORC_ERR_ARG;
+    Ctx cx;
+    HitRecord rec;
+    Ray r{Vec3(orig[0], orig[1], orig[2]), Vec3(dir[0], dir[1], dir[2])};
+    bool ok;
+    try {
+        ok = h->hit(r, t_min, t_max, rec, cx);
+    } catch (const UnitZero&) {
+        return ORC_ERR_UNIT_ZERO;
+    }
+    out12[0] = ok ? 1. : 0.;
+    if (ok) {
+        out12[1] = rec.t;
+        out12[2] = rec.p.x; out12[3] = rec.p.y; out12[4] = rec.p.z;
+        out12[5] = rec.normal.x; out12[6] = rec.normal.y; out12[7] = rec.normal.z;
+        out12[8] = rec.front_face ? 1. : 0.;
+        out12[9] = rec.u; out12[10] = rec.v;
+        out12[11] = (double)rec.prim_id;
+    }
+    return ORC_OK;
+}
+// AABB::hit on an explicit box (KAT helper)
+int orc_aabb_hit(const double* box6, const double* orig, const double* dir, double t_min, double t_max) {
+    AABB b{Vec3(box6[0], box6[1], box6[2]), Vec3(box6[3], box6[4], box6[5])};
+    Ctx cx;
+    Ray r{Vec3(orig[0], orig[1], orig[2]), Vec3(dir[0], dir[1], dir[2])};
+    return b.hit(r, t_min, t_max, cx) ? 1 : 0;
+}
+// Material::scatter + emitted on an explicit hit (KAT helper).
+// in: ray o/d, p, normal, front_face, u, v; rng key; out: kind, has, ray o/d, att, emitted, draws
+int orc_scatter(void* s, int m, const double* ray6, const double* p3, const double* n3, int front_face, double u, double v,
+                uint64_t seed, uint64_t pixel, uint64_t sample, double* out14) {
+    Scene& sc = *(Scene*)s;
+    if (!mat(sc, m)) return ORC_ERR_ARG;
+    Ctx cx;
+    cx.rng = Rng(seed, pixel, sample);
+    HitRecord rec;
+    rec.p = Vec3(p3[0], p3[1], p3[2]);
+    rec.normal = Vec3(n3[0], n3[1], n3[2]);
+    rec.front_face = front_face != 0;
+    rec.u = u; rec.v = v;
+    rec.mat = mat(sc, m);
+    Ray r{Vec3(ray6[0], ray6[1], ray6[2]), Vec3(ray6[3], ray6[4], ray6[5])};
+    try {
+        Vec3 e = rec.mat->emitted(rec);
+        ScatterResult sr = rec.mat->scatter(r, rec, cx);
+        out14[0] = (double)sr.kind;
+        out14[1] = (sr.has_ray && sr.has_att) ? 1. : 0.;
+        out14[2] = sr.ray.orig.x; out14[3] = sr.ray.orig.y; out14[4] = sr.ray.orig.z;
+        out14[5] = sr.ray.dir.x; out14[6] = sr.ray.dir.y; out14[7] = sr.ray.dir.z;
+        out14[8] = sr.att.x; out14[9] = sr.att.y; out14[10] = sr.att.z;
+        out14[11] = e.x; out14[12] = e.y; out14[13] = e.z;
+    } catch (const UnitZero&) {
+        return ORC_ERR_UNIT_ZERO;
+    }
+    return ORC_OK;
+}
+// Camera ray for (pixel x,y; sample s): out = orig[3], dir[3]
+int orc_camera_ray(void* s, int width, int height, int x, int y, uint64_t seed, uint64_t sample, double* out6) {
+    Scene& sc = *(Scene*)s;
+    if (!sc.cam_set) return ORC_ERR_ARG;
+    Rng rng(seed, (uint64_t)y * (uint64_t)width + (uint64_t)x, sample);
+    double u = ((double)x + rng.gen_f64()) / (double)(width - 1);
+    double v = ((double)y + rng.gen_f64()) / (double)(height - 1);
+    Ray r = sc.cam.get_ray(u, 1.0 - v, rng);
+    out6[0] = r.orig.x; out6[1] = r.orig.y; out6[2] = r.orig.z;
+    out6[3] = r.dir.x; out6[4] = r.dir.y; out6[5] = r.dir.z;
+    return ORC_OK;
+}
+
+void orc_tonemap_u8(const double* rgb, size_t n_channels, uint8_t* out) {
+    for (size_t i = 0; i < n_channels; i++) out[i] = tonemap_channel(rgb[i]);
+}
+// RNG KAT: first n u64 and f64 draws of stream (seed, pixel, sample)
+void orc_rng_stream(uint64_t seed, uint64_t pixel, uint64_t sample, int n, uint64_t* out_u64) {
+    Rng r(seed, pixel, sample);
+    for (int i = 0; i < n; i++) out_u64[i] = r.next_u64();
+}
+void orc_rng_f64(uint64_t seed, uint64_t pixel, uint64_t sample, int n, double* out) {
+    Rng r(seed, pixel, sample);
+    for (int i = 0; i < n; i++) out[i] = r.gen_f64();
+}
+// Sampling helpers KAT: which = 0 in_unit_sphere, 1 unit_vector, 2 in_unit_disk, 3 in_hemisphere(n)
+int orc_sample_helper(int which, uint64_t seed, uint64_t pixel, uint64_t sample, const double* n3, double* out3) {
+    Rng r(seed, pixel, sample);
+    Vec3 v;
+    try {
+        switch (which) {
+            case 0: v = random_in_unit_sphere(r); break;
+            case 1: v = random_unit_vector(r); break;
+            case 2: v = random_in_unit_disk(r); break;
+            case 3: v = random_in_hemisphere(r, Vec3(n3[0], n3[1], n3[2])); break;
+            default: return ORC_ERR_ARG;
+        }
+    } catch (const UnitZero&) {
+        return ORC_ERR_UNIT_ZERO;
+    }
+    out3[0] = v.x; out3[1] = v.y; out3[2] = v.z;
+    return ORC_OK;
+}
+
+// Vec3 KAT entry (replays raytracer/src/vec3.rs:425-564).
+// op: 0 add 1 add_f64 2 sub 3 sub_f64 4 dot 5 mul_f64 6 div 7 elemul 8 cross 9 neg
+//     10 squared_length 11 length 12 unit 13 reflect 14 refract(s = eta)
+// returns ORC_ERR_UNIT_ZERO where Rust would panic.
+int orc_vec3_op(int op, const double* a3, const double* b3, double s, double* out3) {
+    Vec3 a(a3[0], a3[1], a3[2]), b(0, 0, 0), r(0, 0, 0);
+    if (b3) b = Vec3(b3[0], b3[1], b3[2]);
+    try {
+        switch (op) {
+            case 0: r = v_add(a, b); break;
+            case 1: r = v_adds(a, s); break;
+            case 2: r = v_sub(a, b); break;
+            case 3: r = v_subs(a, s); break;
+            case 4: r = Vec3(v_dot(a, b), 0, 0); break;
+            case 5: r = v_muls(a, s); break;
+            case 6: r = v_divs(a, s); break;
+            case 7: r = v_elemul(a, b); break;
+            case 8: r = v_cross(a, b); break;
+            case 9: r = v_neg(a); break;
+            case 10: r = Vec3(v_sqlen(a), 0, 0); break;
+            case 11: r = Vec3(v_len(a), 0, 0); break;
+            case 12: r = v_unit(a); break;
+            case 13: r = reflect(a, b); break;
+            case 14: r = refract(a, b, s); break;
+            default: return ORC_ERR_ARG;
+        }
+    } catch (const UnitZero&) {
+        return ORC_ERR_UNIT_ZERO;
+    }
+    out3[0] = r.x; out3[1] = r.y; out3[2] = r.z;
+    return ORC_OK;
+}
+double orc_schlick(double cosine, double ref_idx) { return Dielectric::reflectance(cosine, ref_idx); }
+
+}  // extern "C"
