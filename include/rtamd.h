@@ -1,0 +1,204 @@
+/*
+ * rtamd.h -- C ABI of the MI355X-native radiance path (librtamd.so).
+ *
+ * Drop-in boundary for ONE hot path of BlackCloud37/rust-raytracer: the
+ * per-pixel radiance loop  Camera::capture_image -> Integrator::sample_ray ->
+ * World::hit -> {BVHNode,AABB,Sphere,Rect,Triangle,Transform}::hit ->
+ * Material::{emitted,scatter}.  The reference has no FFI of its own (SURVEY.md
+ * s8b), so every entry point below names the Rust item it stands in for
+ * (paths relative to /root/reference/raytracer/src).  The cut is at
+ * capture_image granularity: the host walks its Hitable/Material/Texture graph
+ * once through the rt_texture_* / rt_material_* / rt_object_* builders (one per
+ * reference constructor), commits, and calls rt_render.
+ *
+ * Conventions
+ *   - plain C, pointers + sizes only; no C++/torch types cross this boundary.
+ *   - every function returns RT_OK (0) / a non-negative id, or a negative
+ *     rt_status; rt_last_error() gives the message (thread-local).  Nothing
+ *     aborts or unwinds across the boundary (the reference's panic sites map
+ *     to error codes, listed per function).
+ *   - the library owns what it copies at build/commit; the caller owns every
+ *     buffer it passes in.  An rt_scene is immutable after rt_scene_commit and
+ *     may then be rendered from several host threads concurrently.
+ *   - all geometry and radiance is f64, as in the reference (vec3.rs:15-19).
+ *   - there is NO CPU fallback: without a HIP device the render entry points
+ *     fail with RT_ERR_NO_DEVICE.
+ */
+#ifndef RTAMD_H
+#define RTAMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTAMD_ABI_VERSION 1
+
+typedef enum rt_status {
+    RT_OK = 0,
+    RT_ERR_ARG = -1,          /* bad argument / unknown id */
+    RT_ERR_UNIT_ZERO = -2,    /* Vec3::unit of a zero vector      (vec3.rs:88 panic)      */
+    RT_ERR_NO_BBOX = -3,      /* "No bounding box in bvh_node constructor" (bvh.rs:43,57) */
+    RT_ERR_SINGULAR = -4,     /* "Invalid transform matrix"       (transform.rs:146)      */
+    RT_ERR_IO = -5,           /* file cannot be read ("Failed to load OBJ file", mesh.rs:158) */
+    RT_ERR_SCHEMA = -6,       /* scene file does not follow the schema of data/ (.json/.yaml) */
+    RT_ERR_NO_NORMALS = -7,   /* mesh without vertex normals      (mesh.rs:62 index panic) */
+    RT_ERR_NOT_COMMITTED = -8,
+    RT_ERR_NO_DEVICE = -9,    /* no HIP device / HIP runtime error: there is no CPU fallback */
+    RT_ERR_UNSUPPORTED = -10,
+    RT_ERR_HIP = -11
+} rt_status;
+
+typedef struct rt_scene rt_scene; /* opaque: World's object graph + its flattened device form */
+
+/* Camera::new arguments (camera.rs:24-32); data/<scene>.json "camera" block. */
+typedef struct rt_camera {
+    double look_from[3];
+    double look_at[3];
+    double vup[3];
+    double vfov;       /* degrees */
+    double aspect;     /* CONFIGS.aspect_ratio (main.rs:35) */
+    double aperture;
+    double focus_dist;
+} rt_camera;
+
+/* capture_image's compile-time constants made run-time (SURVEY.md s5 "Config / flags"). */
+typedef struct rt_params {
+    int32_t width;       /* CONFIGS.width  (main.rs:34) default 800 */
+    int32_t height;      /* CONFIGS.height (main.rs:45) default 800 */
+    int32_t spp;         /* sample_per_pixel (camera.rs:73) default 256 */
+    int32_t max_depth;   /* photon_mapper.rs:334 default 50 */
+    double t_min;        /* photon_mapper.rs:335 default 0.001 */
+    uint64_t seed;       /* rtamd-rng-1 stream seed (replaces thread_rng) */
+    int32_t rank;        /* image-tile partition: this call renders tiles t with t % world == rank */
+    int32_t world;       /* 1 = whole image */
+    int32_t spp_chunk;   /* samples per pixel per kernel launch; 0 = auto */
+    int32_t kernel;      /* 0 = auto; 1 = reference-order f64 kernel */
+    int32_t device;      /* HIP device ordinal; -1 = current */
+    int32_t reserved;
+} rt_params;
+
+typedef struct rt_stats {
+    double seconds;          /* wall time of the call (host clock) */
+    double kernel_ms;        /* sum of path-trace kernel launch durations (HIP events on the launch stream) */
+    double reduce_ms;        /* sum of ordered-reduction kernel durations */
+    uint64_t samples;        /* pixel-samples traced by this call (this rank) */
+    int32_t launches;        /* path-trace kernel launches */
+    int32_t kernel_used;     /* which kernel ran */
+    int32_t scene_in_lds;    /* 1 if the flattened scene was staged into LDS */
+    int32_t block_threads;
+    int32_t grid_blocks;
+    int32_t spp_chunk;
+    uint64_t scene_bytes;    /* flattened scene size */
+    uint64_t reserved[4];
+} rt_stats;
+
+/* ---- library ------------------------------------------------------------ */
+int rt_abi_version(void);
+const char* rt_last_error(void);
+void rt_default_params(rt_params* p);           /* the reference's constants, see rt_params */
+int rt_device_count(void);                      /* HIP devices visible; 0 without a GPU */
+
+/* ---- scene graph builders (one per reference constructor) ---------------- */
+int rt_scene_create(rt_scene** out);
+void rt_scene_destroy(rt_scene* s);
+
+/* material.rs:48-50  ConstantTexture(Vec3) / CheckerTexture(t0,t1) / ImageTexture(rgb8, row-major, top row first) */
+int rt_texture_constant(rt_scene* s, const double color[3]);
+int rt_texture_checker(rt_scene* s, int t0, int t1);
+int rt_texture_image(rt_scene* s, int width, int height, const uint8_t* rgb);
+/* material.rs:88-212  Lambertian::new / Metal::new / Dielectric::new / DiffuseLight::new */
+int rt_material_lambertian(rt_scene* s, int albedo_tex);
+int rt_material_metal(rt_scene* s, int albedo_tex, double fuzz);
+int rt_material_dielectric(rt_scene* s, double ir, int albedo_tex);
+int rt_material_diffuse_light(rt_scene* s, int emit_tex);
+
+/* objects/sphere.rs:9-13 */
+int rt_object_sphere(rt_scene* s, const double center[3], double radius, int material);
+/* objects/rectangle.rs:7-12,44-49,82-87 : {a0,b0}=xy0|xz0|yz0, {a1,b1}=xy1|xz1|yz1, k = z|y|x */
+int rt_object_rect_xy(rt_scene* s, double x0, double y0, double x1, double y1, double z, int material);
+int rt_object_rect_xz(rt_scene* s, double x0, double z0, double x1, double z1, double y, int material);
+int rt_object_rect_yz(rt_scene* s, double y0, double z0, double y1, double z1, double x, int material);
+/* objects/cube.rs:16 Cube::new(box_min, box_max, mat) */
+int rt_object_cube(rt_scene* s, const double box_min[3], const double box_max[3], int material);
+/* light.rs:74-86,134-146 : a light seen as a Hitable = primitive + DiffuseLight(ConstantTexture(flux)) */
+int rt_object_sphere_light(rt_scene* s, const double center[3], double radius, const double flux[3]);
+int rt_object_xz_rect_light(rt_scene* s, double x0, double z0, double x1, double z1, double y, const double flux[3]);
+/* objects/mesh.rs:149 Mesh::load_obj given parsed arrays: positions/normals n_vert*3, indices n_tri*3.
+ * normals == NULL -> RT_ERR_NO_NORMALS unless synthesize_normals != 0 (area-weighted smooth normals). */
+int rt_object_mesh(rt_scene* s, int n_vert, const double* positions, const double* normals, int n_tri, const uint32_t* indices,
+                   int material, int synthesize_normals, uint64_t bvh_seed);
+/* Mesh::load_obj(path, material): tobj{single_index, triangulate} semantics, models[0] */
+int rt_object_mesh_obj(rt_scene* s, const char* obj_path, int material, int synthesize_normals, uint64_t bvh_seed);
+/* objects/transform.rs:17 Transform::new(rotate_in_degree, scale, translate, obj): M = T*S*Rx*Ry*Rz */
+int rt_object_transform(rt_scene* s, const double rotate_deg[3], const double scale[3], const double translate[3], int object);
+/* impl Hitable for Vec<Arc<dyn Hitable>> (objects/hit.rs:56-93) */
+int rt_object_list(rt_scene* s, int n, const int* objects);
+/* BVHNode::construct(left,right) (bvh.rs:47-58) and BVHNode::new(src_objects) (bvh.rs:60-83; split axes from
+ * the seeded rtamd-rng-1 "bvh" stream instead of thread_rng) */
+int rt_object_bvh_node(rt_scene* s, int left, int right);
+int rt_object_bvh_build(rt_scene* s, int n, const int* objects, uint64_t bvh_seed);
+/* Hitable::bounding_box (objects/hit.rs:53): out = min[3], max[3]; RT_ERR_NO_BBOX for None */
+int rt_object_bounding_box(const rt_scene* s, int object, double out_min_max[6]);
+
+/* World::new(hitable_list, cam, lights) (world.rs:15-25): root = BVHNode::new(list) */
+int rt_world_new(rt_scene* s, int n, const int* objects, uint64_t bvh_seed);
+/* root = an existing object (e.g. the HitableList of a scene file) */
+int rt_scene_set_root(rt_scene* s, int object);
+/* scene.rs:16-112 cornell_box_scene(): the reference's only built-in scene, numbers verbatim.
+ * cube_obj_path = "data/mesh/cube.obj" of the reference. */
+int rt_scene_cornell_box(rt_scene* s, const char* cube_obj_path, double aspect_ratio, uint64_t bvh_seed, rt_camera* cam_out);
+/* data/<name>.json|.yaml loader (schema SURVEY.md sA.1; README.md:86-89 Track 5). File BVH topology is kept
+ * verbatim, the redundant "bounding_box" is recomputed as BVHNode::construct does. Creates AND commits. */
+int rt_scene_load_file(const char* path, rt_scene** out, rt_camera* cam_out);
+/* flatten the graph into the linear device form (DFS pre-order program, SoA tables) */
+int rt_scene_commit(rt_scene* s);
+
+/* introspection of the flattened form (tests, INTEGRATION) */
+typedef struct rt_scene_info {
+    int32_t n_nodes, n_boxes, n_spheres, n_rects, n_tris, n_xforms, n_materials, n_textures;
+    int32_t n_verts, max_depth, committed, reserved;
+    uint64_t bytes;
+} rt_scene_info;
+int rt_scene_info_get(const rt_scene* s, rt_scene_info* out);
+
+/* ---- the hot path -------------------------------------------------------- */
+/* Camera::capture_image (camera.rs:66-128) minus the u8 conversion: linear radiance (sum/spp), f64 RGB,
+ * row-major, y down, into caller-owned HOST memory out_rgb[height*width*3].  world > 1 renders only this
+ * rank's tiles (others left 0). */
+int rt_render(const rt_scene* s, const rt_camera* cam, const rt_params* p, double* out_rgb, rt_stats* stats);
+
+/* Same, device-resident: renders this rank's 8x8 tiles into d_tiles (DEVICE memory,
+ * rt_tiles_owned(p)*64*3 f64, tile-major) on `hip_stream` (hipStream_t as void*, NULL = default stream).
+ * The call returns after the work has completed on that stream. */
+int rt_render_tiles_device(const rt_scene* s, const rt_camera* cam, const rt_params* p, double* d_tiles, void* hip_stream,
+                           rt_stats* stats);
+int64_t rt_tiles_total(const rt_params* p);   /* ceil(W/8)*ceil(H/8) */
+int64_t rt_tiles_owned(const rt_params* p);   /* tiles t in [0,total) with t % world == rank */
+/* the stitch of camera.rs:115-123: scatter gathered tile-major buffers (rank-major: rank 0's tiles, rank 1's, ...
+ * each padded to rt_tiles_owned of rank 0) into a row-major frame; both pointers DEVICE memory. */
+int rt_assemble_frame_device(const rt_params* p, const double* d_gathered, int64_t tiles_per_rank_stride, double* d_frame,
+                             void* hip_stream);
+
+/* From<Vec3> for Rgb<u8> (vec3.rs:223-231): floor(clamp(sqrt(c),0,1)*255), NaN -> 0.  Host buffers. */
+int rt_tonemap_u8(const double* rgb, size_t n_channels, uint8_t* out);
+/* RgbImage::save("output/test.png") (main.rs:55): 8-bit RGB PNG */
+int rt_write_png(const char* path, int width, int height, const uint8_t* rgb);
+
+/* ---- diagnostics used by the parity tests ------------------------------- */
+/* rtamd-rng-1: first n u64 draws of stream (seed, pixel, sample) computed ON THE DEVICE */
+int rt_debug_rng_device(uint64_t seed, uint64_t pixel, uint64_t sample, int n, uint64_t* out_host);
+/* host-side restatement of the same stream (used by BVHNode::new's axis draws) */
+int rt_debug_rng_host(uint64_t seed, uint64_t pixel, uint64_t sample, int n, uint64_t* out_host);
+/* device f64 sqrt / divide, element-wise, for the correctly-rounded check: op 0 = sqrt(a), 1 = a/b */
+int rt_debug_math_device(int op, size_t n, const double* a_host, const double* b_host, double* out_host);
+/* closest hit of explicit world-space rays through the device traversal: rays n*6 (orig,dir);
+ * out n*12 = {hit, t, p[3], normal[3], front_face, u, v, leaf_node} */
+int rt_debug_hit_device(const rt_scene* s, size_t n, const double* rays_host, double t_min, double t_max, double* out_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTAMD_H */

@@ -1,0 +1,485 @@
+// extern "C" entry points of librtamd.so (declared in include/rtamd.h).
+// Every function converts C++ exceptions into rt_status codes; nothing unwinds
+// across the boundary.
+#include <chrono>
+#include <cstring>
+#include <new>
+
+#include "common/rng.h"
+#include "device/device.h"
+#include "host/scene.h"
+#include "rtamd.h"
+
+using namespace rtamd;
+
+static thread_local std::string g_err;
+
+rt_scene::~rt_scene() { free_device_copies(*this); }
+
+template <class F>
+static int guard(F&& f) {
+    try {
+        return f();
+    } catch (const RtError& e) {
+        g_err = e.msg;
+        return e.code;
+    } catch (const std::bad_alloc&) {
+        g_err = "out of memory";
+        return RT_ERR_ARG;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return RT_ERR_ARG;
+    } catch (...) {
+        g_err = "unknown error";
+        return RT_ERR_ARG;
+    }
+}
+#define REQUIRE(c, msg) \
+    if (!(c)) throw RtError(RT_ERR_ARG, msg)
+
+static void not_committed_only(const rt_scene* s) {
+    REQUIRE(s, "null scene");
+    if (s->committed) throw RtError(RT_ERR_ARG, "scene is immutable after rt_scene_commit");
+}
+
+extern "C" {
+
+int rt_abi_version(void) { return RTAMD_ABI_VERSION; }
+const char* rt_last_error(void) { return g_err.c_str(); }
+
+void rt_default_params(rt_params* p) {
+    if (!p) return;
+    std::memset(p, 0, sizeof(*p));
+    p->width = 800;      // main.rs:34
+    p->height = 800;     // main.rs:45 (aspect 1)
+    p->spp = 256;        // camera.rs:73
+    p->max_depth = 50;   // photon_mapper.rs:334
+    p->t_min = 0.001;    // photon_mapper.rs:335
+    p->seed = 1;
+    p->rank = 0;
+    p->world = 1;
+    p->spp_chunk = 0;
+    p->kernel = 0;
+    p->device = -1;
+}
+int rt_device_count(void) { return device_count(); }
+
+int rt_scene_create(rt_scene** out) {
+    return guard([&] {
+        REQUIRE(out, "null out pointer");
+        *out = new rt_scene();
+        return (int)RT_OK;
+    });
+}
+void rt_scene_destroy(rt_scene* s) { delete s; }
+
+int rt_texture_constant(rt_scene* s, const double color[3]) {
+    return guard([&] {
+        not_committed_only(s);
+        REQUIRE(color, "null color");
+        return add_texture_constant(*s, color);
+    });
+}
+int rt_texture_checker(rt_scene* s, int t0, int t1) {
+    return guard([&] {
+        not_committed_only(s);
+        return add_texture_checker(*s, t0, t1);
+    });
+}
+int rt_texture_image(rt_scene* s, int width, int height, const uint8_t* rgb) {
+    return guard([&] {
+        not_committed_only(s);
+        return add_texture_image(*s, width, height, rgb);
+    });
+}
+int rt_material_lambertian(rt_scene* s, int tex) {
+    return guard([&] {
+        not_committed_only(s);
+        return add_material(*s, MAT_LAMBERTIAN, tex, 0.);
+    });
+}
+int rt_material_metal(rt_scene* s, int tex, double fuzz) {
+    return guard([&] {
+        not_committed_only(s);
+        return add_material(*s, MAT_METAL, tex, fuzz);
+    });
+}
+int rt_material_dielectric(rt_scene* s, double ir, int tex) {
+    return guard([&] {
+        not_committed_only(s);
+        return add_material(*s, MAT_DIELECTRIC, tex, ir);
+    });
+}
+int rt_material_diffuse_light(rt_scene* s, int tex) {
+    return guard([&] {
+        not_committed_only(s);
+        return add_material(*s, MAT_DIFFUSE_LIGHT, tex, 0.);
+    });
+}
+
+int rt_object_sphere(rt_scene* s, const double center[3], double radius, int material) {
+    return guard([&] {
+        not_committed_only(s);
+        REQUIRE(center, "null center");
+        return add_sphere(*s, center, radius, material);
+    });
+}
+int rt_object_rect_xy(rt_scene* s, double x0, double y0, double x1, double y1, double z, int material) {
+    return guard([&] {
+        not_committed_only(s);
+        return add_rect(*s, 2, x0, y0, x1, y1, z, material);
+    });
+}
+int rt_object_rect_xz(rt_scene* s, double x0, double z0, double x1, double z1, double y, int material) {
+    return guard([&] {
+        not_committed_only(s);
+        return add_rect(*s, 1, x0, z0, x1, z1, y, material);
+    });
+}
+int rt_object_rect_yz(rt_scene* s, double y0, double z0, double y1, double z1, double x, int material) {
+    return guard([&] {
+        not_committed_only(s);
+        return add_rect(*s, 0, y0, z0, y1, z1, x, material);
+    });
+}
+int rt_object_cube(rt_scene* s, const double box_min[3], const double box_max[3], int material) {
+    return guard([&] {
+        not_committed_only(s);
+        REQUIRE(box_min && box_max, "null box");
+        return add_cube(*s, box_min, box_max, material);
+    });
+}
+int rt_object_sphere_light(rt_scene* s, const double center[3], double radius, const double flux[3]) {
+    return guard([&] {  // SphereDiffuseLight::new, light.rs:74-86
+        not_committed_only(s);
+        REQUIRE(center && flux, "null argument");
+        int m = add_material(*s, MAT_DIFFUSE_LIGHT, add_texture_constant(*s, flux), 0.);
+        return add_sphere(*s, center, radius, m);
+    });
+}
+int rt_object_xz_rect_light(rt_scene* s, double x0, double z0, double x1, double z1, double y, const double flux[3]) {
+    return guard([&] {  // XZRectLight::new, light.rs:134-146 (scale only feeds photon power)
+        not_committed_only(s);
+        REQUIRE(flux, "null flux");
+        int m = add_material(*s, MAT_DIFFUSE_LIGHT, add_texture_constant(*s, flux), 0.);
+        return add_rect(*s, 1, x0, z0, x1, z1, y, m);
+    });
+}
+int rt_object_mesh(rt_scene* s, int n_vert, const double* positions, const double* normals, int n_tri, const uint32_t* indices,
+                   int material, int synthesize_normals_flag, uint64_t bvh_seed) {
+    return guard([&] {
+        not_committed_only(s);
+        return add_mesh(*s, n_vert, positions, normals, n_tri, indices, material, synthesize_normals_flag != 0, bvh_seed);
+    });
+}
+int rt_object_mesh_obj(rt_scene* s, const char* obj_path, int material, int synthesize_normals_flag, uint64_t bvh_seed) {
+    return guard([&] {
+        not_committed_only(s);
+        REQUIRE(obj_path, "null path");
+        ObjMesh m = load_obj_file(obj_path);
+        return add_mesh(*s, (int)(m.pos.size() / 3), m.pos.data(), m.has_normals ? m.nrm.data() : nullptr, (int)(m.idx.size() / 3),
+                        m.idx.data(), material, synthesize_normals_flag != 0, bvh_seed);
+    });
+}
+int rt_object_transform(rt_scene* s, const double rotate_deg[3], const double scale[3], const double translate[3], int object) {
+    return guard([&] {
+        not_committed_only(s);
+        REQUIRE(rotate_deg && scale && translate, "null argument");
+        return add_transform(*s, rotate_deg, scale, translate, object);
+    });
+}
+int rt_object_list(rt_scene* s, int n, const int* objects) {
+    return guard([&] {
+        not_committed_only(s);
+        REQUIRE(n >= 0 && (n == 0 || objects), "bad list");
+        return add_list(*s, n, objects);
+    });
+}
+int rt_object_bvh_node(rt_scene* s, int left, int right) {
+    return guard([&] {
+        not_committed_only(s);
+        check_obj(*s, left);
+        check_obj(*s, right);
+        return add_bvh_node(*s, left, right);
+    });
+}
+int rt_object_bvh_build(rt_scene* s, int n, const int* objects, uint64_t bvh_seed) {
+    return guard([&] {
+        not_committed_only(s);
+        REQUIRE(n > 0 && objects, "BVHNode::new needs a non-empty list");
+        return add_bvh_build(*s, std::vector<int>(objects, objects + n), bvh_seed);
+    });
+}
+int rt_object_bounding_box(const rt_scene* s, int object, double out_min_max[6]) {
+    return guard([&] {
+        REQUIRE(s && out_min_max, "null argument");
+        Box b;
+        if (!bounding_box(*s, object, b)) throw RtError(RT_ERR_NO_BBOX, "object has no bounding box");
+        for (int i = 0; i < 3; i++) {
+            out_min_max[i] = b.mn[i];
+            out_min_max[3 + i] = b.mx[i];
+        }
+        return (int)RT_OK;
+    });
+}
+int rt_world_new(rt_scene* s, int n, const int* objects, uint64_t bvh_seed) {
+    return guard([&] {
+        not_committed_only(s);
+        REQUIRE(n > 0 && objects, "World::new needs a non-empty list");
+        s->root = add_bvh_build(*s, std::vector<int>(objects, objects + n), bvh_seed);
+        return s->root;
+    });
+}
+int rt_scene_set_root(rt_scene* s, int object) {
+    return guard([&] {
+        not_committed_only(s);
+        check_obj(*s, object);
+        s->root = object;
+        return (int)RT_OK;
+    });
+}
+int rt_scene_cornell_box(rt_scene* s, const char* cube_obj_path, double aspect_ratio, uint64_t bvh_seed, rt_camera* cam_out) {
+    return guard([&] {  // scene.rs:16-112, numbers verbatim
+        not_committed_only(s);
+        REQUIRE(cube_obj_path, "null path");
+        auto ctex = [&](double r, double g, double b) {
+            const double c[3] = {r, g, b};
+            return add_texture_constant(*s, c);
+        };
+        int red = add_material(*s, MAT_LAMBERTIAN, ctex(0.75, 0.25, 0.25), 0.);
+        int white = add_material(*s, MAT_LAMBERTIAN, ctex(0.75, 0.75, 0.75), 0.);
+        int blue = add_material(*s, MAT_LAMBERTIAN, ctex(0.25, 0.25, 0.75), 0.);
+        int light = add_material(*s, MAT_DIFFUSE_LIGHT, ctex(1., 1., 1.), 0.);  // XZRectLight::new(.., flux (1,1,1), 1e6)
+        std::vector<int> items;
+        items.push_back(add_rect(*s, 0, 0.0, 0.0, 555.0, 555.0, 555., red));
+        items.push_back(add_rect(*s, 0, 0., 0., 555., 555., 0., blue));
+        items.push_back(add_rect(*s, 1, 0., 0., 555., 555., 0., white));
+        items.push_back(add_rect(*s, 1, 0., 0., 555., 555., 555., white));
+        items.push_back(add_rect(*s, 2, 0., 0., 555., 555., 555., white));
+        const double c1[3] = {140., 100., 240.}, c2[3] = {400., 100., 360.};
+        items.push_back(add_sphere(*s, c1, 100., add_material(*s, MAT_DIELECTRIC, ctex(0.999, 0.999, 0.999), 1.5)));
+        items.push_back(add_sphere(*s, c2, 100., add_material(*s, MAT_METAL, ctex(0.999, 0.999, 0.999), 0.)));
+        items.push_back(add_rect(*s, 1, 213., 227., 343., 332., 554., light));
+        ObjMesh m = load_obj_file(cube_obj_path);
+        if (!m.has_normals) throw RtError(RT_ERR_NO_NORMALS, "cube.obj without normals");
+        int mesh = add_mesh(*s, (int)(m.pos.size() / 3), m.pos.data(), m.nrm.data(), (int)(m.idx.size() / 3), m.idx.data(), white, false,
+                            bvh_seed);
+        const double rot[3] = {0., 0., 0.}, sc[3] = {1. * 50., 1. * 50., 1. * 50.}, tr[3] = {100., 50., 100.};
+        items.push_back(add_transform(*s, rot, sc, tr, mesh));
+        const double bmin[3] = {300., 0., 100.}, bmax[3] = {380., 100., 180.};
+        items.push_back(add_cube(*s, bmin, bmax, white));
+        s->root = add_bvh_build(*s, items, bvh_seed);
+        if (cam_out) {
+            rt_camera c = {{278., 278., -800.}, {278., 278., 278.}, {0., 1., 0.}, 50., aspect_ratio, 0.0, 10.0};
+            *cam_out = c;
+        }
+        return (int)RT_OK;
+    });
+}
+int rt_scene_load_file(const char* path, rt_scene** out, rt_camera* cam_out) {
+    return guard([&] {
+        REQUIRE(path && out, "null argument");
+        *out = load_scene_file(path, cam_out);
+        return (int)RT_OK;
+    });
+}
+int rt_scene_commit(rt_scene* s) {
+    return guard([&] {
+        REQUIRE(s, "null scene");
+        if (s->committed) return (int)RT_OK;
+        flatten(*s);
+        return (int)RT_OK;
+    });
+}
+int rt_scene_info_get(const rt_scene* s, rt_scene_info* out) {
+    return guard([&] {
+        REQUIRE(s && out, "null argument");
+        *out = s->flat.info;
+        out->committed = s->committed ? 1 : 0;
+        return (int)RT_OK;
+    });
+}
+
+// ---- render --------------------------------------------------------------
+static RenderPlan make_plan(const rt_params* p) {
+    REQUIRE(p, "null params");
+    REQUIRE(p->width > 0 && p->height > 0, "width/height must be positive");
+    REQUIRE(p->spp > 0, "spp must be positive");
+    REQUIRE(p->max_depth >= 0, "max_depth must be >= 0");
+    REQUIRE(p->world >= 1 && p->rank >= 0 && p->rank < p->world, "bad rank/world");
+    REQUIRE(p->kernel == 0 || p->kernel == 1, "unknown kernel id");
+    RenderPlan pl;
+    pl.width = p->width; pl.height = p->height; pl.spp = p->spp; pl.max_depth = p->max_depth;
+    pl.t_min = p->t_min; pl.seed = p->seed; pl.rank = p->rank; pl.world = p->world;
+    pl.tiles_x = (p->width + TILE_W - 1) / TILE_W;
+    pl.tiles_y = (p->height + TILE_H - 1) / TILE_H;
+    pl.tiles_total = (int64_t)pl.tiles_x * pl.tiles_y;
+    pl.tiles_owned = (pl.tiles_total - p->rank + p->world - 1) / p->world;
+    if (pl.tiles_owned < 0) pl.tiles_owned = 0;
+    pl.kernel = 1;
+    // sample-buffer budget: <= ~1.5 GiB per launch
+    int chunk = p->spp_chunk;
+    if (chunk <= 0) {
+        int64_t per_spp = std::max<int64_t>(1, pl.tiles_owned) * TILE_PIX * 3 * 8;
+        int64_t c = (int64_t(3) << 29) / per_spp;
+        chunk = (int)std::max<int64_t>(1, std::min<int64_t>(c, 64));
+    }
+    if (chunk > p->spp) chunk = p->spp;
+    pl.spp_chunk = chunk;
+    // one work unit = 64 pixels x sub_spp samples; keep >= ~8 units per resident wave when possible
+    pl.sub_spp = std::min(chunk, 16);
+    return pl;
+}
+
+int64_t rt_tiles_total(const rt_params* p) {
+    if (!p || p->width <= 0 || p->height <= 0) return RT_ERR_ARG;
+    return (int64_t)((p->width + TILE_W - 1) / TILE_W) * ((p->height + TILE_H - 1) / TILE_H);
+}
+int64_t rt_tiles_owned(const rt_params* p) {
+    if (!p || p->width <= 0 || p->height <= 0 || p->world < 1 || p->rank < 0 || p->rank >= p->world) return RT_ERR_ARG;
+    int64_t total = rt_tiles_total(p);
+    return (total - p->rank + p->world - 1) / p->world;
+}
+
+int rt_render_tiles_device(const rt_scene* s, const rt_camera* cam, const rt_params* p, double* d_tiles, void* hip_stream,
+                           rt_stats* stats) {
+    return guard([&] {
+        REQUIRE(s && cam && d_tiles, "null argument");
+        if (!s->committed) throw RtError(RT_ERR_NOT_COMMITTED, "rt_scene_commit has not been called");
+        if (device_count() < 1) throw RtError(RT_ERR_NO_DEVICE, "no HIP device: librtamd has no CPU fallback");
+        auto t0 = std::chrono::steady_clock::now();
+        RenderPlan pl = make_plan(p);
+        CameraDev cd = make_camera(*cam);
+        if (stats) std::memset(stats, 0, sizeof(*stats));
+        render_tiles(*s, cd, pl, d_tiles, hip_stream, stats);
+        if (stats) {
+            stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            // pixels actually inside the image among this rank's tiles
+            uint64_t px = 0;
+            for (int64_t lt = 0; lt < pl.tiles_owned; lt++) {
+                int64_t t = lt * pl.world + pl.rank;
+                int tx = (int)(t % pl.tiles_x), ty = (int)(t / pl.tiles_x);
+                int w = std::min(TILE_W, pl.width - tx * TILE_W), h = std::min(TILE_H, pl.height - ty * TILE_H);
+                px += (uint64_t)w * h;
+            }
+            stats->samples = px * (uint64_t)pl.spp;
+        }
+        return (int)RT_OK;
+    });
+}
+
+int rt_assemble_frame_device(const rt_params* p, const double* d_gathered, int64_t tiles_per_rank_stride, double* d_frame,
+                             void* hip_stream) {
+    return guard([&] {
+        REQUIRE(d_gathered && d_frame, "null argument");
+        RenderPlan pl = make_plan(p);
+        assemble_frame(pl, d_gathered, tiles_per_rank_stride, d_frame, hip_stream);
+        return (int)RT_OK;
+    });
+}
+
+int rt_render(const rt_scene* s, const rt_camera* cam, const rt_params* p, double* out_rgb, rt_stats* stats) {
+    return guard([&] {
+        REQUIRE(s && cam && p && out_rgb, "null argument");
+        if (!s->committed) throw RtError(RT_ERR_NOT_COMMITTED, "rt_scene_commit has not been called");
+        if (device_count() < 1) throw RtError(RT_ERR_NO_DEVICE, "no HIP device: librtamd has no CPU fallback");
+        auto t0 = std::chrono::steady_clock::now();
+        if (p->device >= 0) dev_set_device(p->device);
+        RenderPlan pl = make_plan(p);
+        CameraDev cd = make_camera(*cam);
+        if (stats) std::memset(stats, 0, sizeof(*stats));
+        struct Buf {
+            void* p = nullptr;
+            ~Buf() {
+                if (p) dev_free(p);
+            }
+        } tiles, frame;
+        size_t tile_bytes = (size_t)std::max<int64_t>(1, pl.tiles_owned) * TILE_PIX * 3 * sizeof(double);
+        size_t frame_bytes = (size_t)pl.width * pl.height * 3 * sizeof(double);
+        tiles.p = dev_alloc(tile_bytes);
+        frame.p = dev_alloc(frame_bytes);
+        rt_stats st{};
+        render_tiles(*s, cd, pl, (double*)tiles.p, nullptr, &st);
+        if (pl.world == 1) {
+            assemble_frame(pl, (const double*)tiles.p, pl.tiles_owned, (double*)frame.p, nullptr);
+            dev_copy_to_host(out_rgb, frame.p, frame_bytes);
+        } else {
+            // only this rank's tiles: others stay 0 in the caller's frame
+            std::vector<double> h((size_t)pl.tiles_owned * TILE_PIX * 3);
+            dev_copy_to_host(h.data(), tiles.p, h.size() * sizeof(double));
+            std::memset(out_rgb, 0, frame_bytes);
+            for (int64_t lt = 0; lt < pl.tiles_owned; lt++) {
+                int64_t t = lt * pl.world + pl.rank;
+                int tx = (int)(t % pl.tiles_x), ty = (int)(t / pl.tiles_x);
+                for (int pix = 0; pix < TILE_PIX; pix++) {
+                    int x = tx * TILE_W + (pix & 7), y = ty * TILE_H + (pix >> 3);
+                    if (x >= pl.width || y >= pl.height) continue;
+                    for (int c = 0; c < 3; c++) out_rgb[((size_t)y * pl.width + x) * 3 + c] = h[((size_t)lt * TILE_PIX + pix) * 3 + c];
+                }
+            }
+        }
+        if (stats) {
+            *stats = st;
+            stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            uint64_t px = 0;
+            for (int64_t lt = 0; lt < pl.tiles_owned; lt++) {
+                int64_t t = lt * pl.world + pl.rank;
+                int tx = (int)(t % pl.tiles_x), ty = (int)(t / pl.tiles_x);
+                px += (uint64_t)std::min(TILE_W, pl.width - tx * TILE_W) * std::min(TILE_H, pl.height - ty * TILE_H);
+            }
+            stats->samples = px * (uint64_t)pl.spp;
+        }
+        return (int)RT_OK;
+    });
+}
+
+int rt_tonemap_u8(const double* rgb, size_t n_channels, uint8_t* out) {
+    return guard([&] {
+        REQUIRE((rgb && out) || n_channels == 0, "null argument");
+        for (size_t i = 0; i < n_channels; i++) out[i] = tonemap_channel(rgb[i]);
+        return (int)RT_OK;
+    });
+}
+int rt_write_png(const char* path, int width, int height, const uint8_t* rgb) {
+    return guard([&] {
+        REQUIRE(path, "null path");
+        write_png(path, width, height, rgb);
+        return (int)RT_OK;
+    });
+}
+
+int rt_debug_rng_device(uint64_t seed, uint64_t pixel, uint64_t sample, int n, uint64_t* out_host) {
+    return guard([&] {
+        REQUIRE(n > 0 && out_host, "bad argument");
+        if (device_count() < 1) throw RtError(RT_ERR_NO_DEVICE, "no HIP device");
+        debug_rng_device(seed, pixel, sample, n, out_host);
+        return (int)RT_OK;
+    });
+}
+int rt_debug_rng_host(uint64_t seed, uint64_t pixel, uint64_t sample, int n, uint64_t* out_host) {
+    return guard([&] {
+        REQUIRE(n > 0 && out_host, "bad argument");
+        Rng r;
+        r.seed_stream(seed, pixel, sample);
+        for (int i = 0; i < n; i++) out_host[i] = r.next_u64();
+        return (int)RT_OK;
+    });
+}
+int rt_debug_math_device(int op, size_t n, const double* a_host, const double* b_host, double* out_host) {
+    return guard([&] {
+        REQUIRE(n > 0 && a_host && out_host && (op == 0 || (op == 1 && b_host)), "bad argument");
+        if (device_count() < 1) throw RtError(RT_ERR_NO_DEVICE, "no HIP device");
+        debug_math_device(op, n, a_host, b_host, out_host);
+        return (int)RT_OK;
+    });
+}
+int rt_debug_hit_device(const rt_scene* s, size_t n, const double* rays_host, double t_min, double t_max, double* out_host) {
+    return guard([&] {
+        REQUIRE(s && n > 0 && rays_host && out_host, "bad argument");
+        if (device_count() < 1) throw RtError(RT_ERR_NO_DEVICE, "no HIP device");
+        debug_hit_device(*s, n, rays_host, t_min, t_max, out_host);
+        return (int)RT_OK;
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,39 @@
+// Host-callable launch interface of the HIP kernels (device/kernels.hip).
+#pragma once
+#include <cstdint>
+
+#include "../common/flat.h"
+#include "../host/scene.h"
+
+namespace rtamd {
+
+static const int TILE_W = 8, TILE_H = 8, TILE_PIX = 64;  // one 8x8 pixel tile == one wave64 of primary rays
+
+struct RenderPlan {
+    int width, height, spp, max_depth;
+    double t_min;
+    uint64_t seed;
+    int rank, world;
+    int tiles_x, tiles_y;
+    int64_t tiles_total, tiles_owned;
+    int spp_chunk;  // samples per pixel per launch (sample-buffer capacity)
+    int sub_spp;    // samples per pixel per work unit (one wave drains 64*sub_spp paths)
+    int kernel;
+};
+
+// Renders plan.tiles_owned tiles into d_tiles (device, tile-major f64 RGB) on `stream`; blocks until done.
+// Throws RtError.
+void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& plan, double* d_tiles, void* stream, rt_stats* st);
+void assemble_frame(const RenderPlan& plan, const double* d_gathered, int64_t tiles_per_rank_stride, double* d_frame, void* stream);
+void debug_rng_device(uint64_t seed, uint64_t pixel, uint64_t sample, int n, uint64_t* out_host);
+void debug_math_device(int op, size_t n, const double* a, const double* b, double* out);
+void debug_hit_device(const rt_scene& s, size_t n, const double* rays, double t_min, double t_max, double* out);
+int device_count();
+// thin HIP wrappers so abi.cpp stays free of HIP headers
+void* dev_alloc(size_t n);
+void dev_free(void* p);
+void dev_copy_to_host(void* dst, const void* src, size_t n);
+void dev_set_device(int d);
+void free_device_copies(rt_scene& s);
+
+}  // namespace rtamd

@@ -1,0 +1,861 @@
+// HIP kernels of the radiance path for gfx950 (MI355X, wave64).
+//
+// pt_kernel  -- persistent path tracer.  One wave owns a work unit = (8x8 pixel
+//   tile, sub-range of sample indices) and drains its pool of 64*sub_spp paths
+//   with in-wave path regeneration: a lane whose path ended immediately pulls the
+//   next (pixel, sample) of the pool (wave64 ballot + prefix popcount), so lanes
+//   stay busy although path lengths vary from 1 to 50 segments.  The flattened
+//   scene (common/flat.h) is staged once per workgroup into LDS when it fits
+//   (its traversal tables; scene_500: 96 KB of the CU's 160 KB), otherwise read through L2.
+//   Each finished path stores its radiance to the per-sample buffer; nothing is
+//   accumulated out of order.
+// reduce_kernel -- per pixel, adds the launch's samples IN SAMPLE ORDER into the
+//   f64 accumulator: the reference's `pixel_color += sample` loop (camera.rs:96-101),
+//   which makes the image independent of how work was scheduled.
+// finalize / assemble -- `pixel_color /= spp` (camera.rs:102) and the tile stitch
+//   (camera.rs:115-123).
+//
+// Arithmetic: f64 throughout, compiled with -ffp-contract=off, IEEE divide and
+// sqrt; every expression keeps the reference's operation order (file:line cited
+// per function) so results are bit-identical to the CPU oracle.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <vector>
+
+#include "../common/flat.h"
+#include "../common/rng.h"
+#include "device.h"
+
+namespace rtamd {
+
+#define PT_BLOCK 512
+
+#define HIP_CHECK(expr)                                                                                  \
+    do {                                                                                                 \
+        hipError_t _e = (expr);                                                                          \
+        if (_e != hipSuccess)                                                                            \
+            throw RtError((_e == hipErrorNoDevice || _e == hipErrorInvalidDevice) ? RT_ERR_NO_DEVICE : RT_ERR_HIP, \
+                          std::string(#expr) + ": " + hipGetErrorString(_e));                            \
+    } while (0)
+
+// ---------------------------------------------------------------- math ----
+struct D3 {
+    double x, y, z;
+};
+#define DEV __device__ __forceinline__
+DEV D3 mk(double x, double y, double z) { D3 r; r.x = x; r.y = y; r.z = z; return r; }
+DEV D3 add(D3 a, D3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+DEV D3 sub(D3 a, D3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+DEV D3 muls(D3 a, double s) { return mk(a.x * s, a.y * s, a.z * s); }
+DEV D3 divs(D3 a, double s) { return mk(a.x / s, a.y / s, a.z / s); }
+DEV D3 neg(D3 a) { return mk(-a.x, -a.y, -a.z); }
+DEV D3 elemul(D3 a, D3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+DEV double dot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }  // vec3.rs:335-341
+DEV double sqlen(D3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }     // vec3.rs:61-63
+DEV D3 cross(D3 a, D3 b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+DEV double comp(D3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+// Vec3::unit, vec3.rs:85-90 ; the panic becomes a sticky error flag
+DEV D3 unit(D3 a, int* err) {
+    double l = sqrt(sqlen(a));
+    if (l == 0.) atomicOr(err, 1);
+    return divs(a, l);
+}
+DEV bool near_zero(D3 a) {  // vec3.rs:92-95
+    const double S = 1e-8;
+    return (fabs(a.x) < S) && (fabs(a.y) < S) && (fabs(a.z) < S);
+}
+DEV D3 reflect(D3 v, D3 n) { return sub(v, muls(n, 2. * dot(v, n))); }  // vec3.rs:163-165
+DEV D3 refract(D3 uv, D3 n, double eta) {                              // vec3.rs:167-172
+    double cos_theta = fmin(dot(neg(uv), n), 1.0);
+    D3 perp = muls(add(uv, muls(n, cos_theta)), eta);
+    D3 par = muls(n, -sqrt(fabs(1.0 - sqlen(perp))));
+    return add(perp, par);
+}
+DEV D3 random_in_unit_sphere(Rng& rng) {  // vec3.rs:111-129 (Marsaglia; a point ON the sphere, Q3)
+    double u, v, r2;
+    for (;;) {
+        u = rng.gen_range(-1., 1.);
+        v = rng.gen_range(-1., 1.);
+        r2 = u * u + v * v;
+        if (r2 <= 1.) break;
+    }
+    double q = sqrt(1. - r2);
+    return mk(2. * u * q, 2. * v * q, 1. - 2. * r2);
+}
+DEV D3 random_in_unit_disk(Rng& rng) {  // vec3.rs:153-162
+    for (;;) {
+        double a = rng.gen_range(-1.0, 1.0);
+        double b = rng.gen_range(-1.0, 1.0);
+        if (a * a + b * b + 0. * 0. >= 1.) continue;
+        return mk(a, b, 0.);
+    }
+}
+DEV D3 xf_point(const double* t, D3 p) {  // vec3.rs:174-178 (w = 1)
+    return mk(t[0] * p.x + t[1] * p.y + t[2] * p.z + t[3] * 1., t[4] * p.x + t[5] * p.y + t[6] * p.z + t[7] * 1.,
+              t[8] * p.x + t[9] * p.y + t[10] * p.z + t[11] * 1.);
+}
+DEV D3 xf_dir(const double* t, D3 p) {  // vec3.rs:180-184 (w = 0)
+    return mk(t[0] * p.x + t[1] * p.y + t[2] * p.z + t[3] * 0., t[4] * p.x + t[5] * p.y + t[6] * p.z + t[7] * 0.,
+              t[8] * p.x + t[9] * p.y + t[10] * p.z + t[11] * 0.);
+}
+
+// ------------------------------------------------------------- scene ------
+struct Acc {  // typed views into the blob (LDS or global; the address space is inferred per instantiation)
+    const uint2* meta;
+    const double2* boxes;    // 3 x double2 per box: (minx,miny) (minz,maxx) (maxy,maxz)
+    const double2* spheres;  // 2 x double2: (cx,cy) (cz,r)
+    const int* sphere_mat;
+    const double2* rects;    // 3 x double2: (a0,b0) (a1,b1) (k,-)
+    const int* rect_mat;
+    const uint4* tris;       // a,b,c,mat
+    const double* xforms;    // 32 per transform: M^-1 then M, row-major
+    const MatDev* mats;
+    const TexDev* texs;
+    const double* vpos;
+    const double* vnrm;
+    const uint8_t* texels;   // always global
+    uint32_t n_nodes;
+};
+template <class P>
+DEV Acc make_acc(P hot, const char* gbase, const FlatView& v) {  // hot: LDS copy or the global blob; cold part always global
+    Acc a;
+    a.meta = (const uint2*)(hot + v.off_meta);
+    a.boxes = (const double2*)(hot + v.off_boxes);
+    a.spheres = (const double2*)(hot + v.off_spheres);
+    a.rects = (const double2*)(hot + v.off_rects);
+    a.tris = (const uint4*)(hot + v.off_tris);
+    a.xforms = (const double*)(hot + v.off_xforms);
+    a.vpos = (const double*)(hot + v.off_vpos);
+    a.sphere_mat = (const int*)(gbase + v.off_sphere_mat);
+    a.rect_mat = (const int*)(gbase + v.off_rect_mat);
+    a.mats = (const MatDev*)(gbase + v.off_mats);
+    a.texs = (const TexDev*)(gbase + v.off_texs);
+    a.vnrm = (const double*)(gbase + v.off_vnrm);
+    a.texels = (const uint8_t*)(gbase + v.off_texels);
+    a.n_nodes = v.n_nodes;
+    return a;
+}
+
+struct CamK {
+    D3 origin, llc, horizontal, vertical, u, v;
+    double lens_radius;
+};
+struct RenderK {
+    int width, height, max_depth;
+    double t_min;
+    uint64_t seed;
+    int s_begin, s_end;  // sample indices of this launch
+    int sub_spp, subs_per_tile, n_units;
+    int tiles_x, rank, world;
+    int chunk_spp;  // sample-buffer stride
+};
+
+// ------------------------------------------------------ intersection ------
+// AABB::hit, aabb.rs:15-32, with 1/dir hoisted out of the node loop (same values).
+// min only grows and max only shrinks across the three axes, so testing `max <= min`
+// once at the end decides exactly as the reference's per-axis early returns do.
+DEV bool aabb_hit(const double2* b, D3 o, D3 inv, double t_min, double t_max) {
+    double2 v0 = b[0], v1 = b[1], v2 = b[2];
+    double mn = t_min, mx = t_max;
+    {
+        double t0 = (v0.x - o.x) * inv.x, t1 = (v1.y - o.x) * inv.x;
+        if (inv.x < 0.0) { double s = t0; t0 = t1; t1 = s; }
+        mn = fmax(mn, t0);
+        mx = fmin(mx, t1);
+    }
+    {
+        double t0 = (v0.y - o.y) * inv.y, t1 = (v2.x - o.y) * inv.y;
+        if (inv.y < 0.0) { double s = t0; t0 = t1; t1 = s; }
+        mn = fmax(mn, t0);
+        mx = fmin(mx, t1);
+    }
+    {
+        double t0 = (v1.x - o.z) * inv.z, t1 = (v2.y - o.z) * inv.z;
+        if (inv.z < 0.0) { double s = t0; t0 = t1; t1 = s; }
+        mn = fmax(mn, t0);
+        mx = fmin(mx, t1);
+    }
+    return !(mx <= mn);
+}
+// Sphere::hit's root selection, sphere.rs:24-43 ; a = |dir|^2 hoisted per ray
+DEV bool sphere_hit(const double2* s, D3 o, D3 d, double a, double t_min, double t_max, double& t_out) {
+    double2 c0 = s[0], c1 = s[1];
+    D3 oc = mk(o.x - c0.x, o.y - c0.y, o.z - c1.x);
+    double radius = c1.y;
+    double half_b = dot(oc, d);
+    double c = sqlen(oc) - radius * radius;
+    double disc = half_b * half_b - a * c;
+    if (disc < 0.) return false;
+    double sq = sqrt(disc);
+    double root = (-half_b - sq) / a;
+    if (!(root >= t_min && root <= t_max)) root = (-half_b + sq) / a;
+    if (!(root >= t_min && root <= t_max)) return false;
+    t_out = root;
+    return true;
+}
+// XY/XZ/YZRectangle::hit, rectangle.rs:15-34,53-72,90-109 (axis = constant axis).
+// No zero-direction guard: NaN/inf t falls through the rejects exactly as in the reference.
+DEV bool rect_hit(const double2* r, int axis, D3 o, D3 d, double t_min, double t_max, double& t_out) {
+    double2 r0 = r[0], r1 = r[1], r2 = r[2];
+    double t = (r2.x - comp(o, axis)) / comp(d, axis);
+    if (t < t_min || t > t_max) return false;
+    D3 p = add(o, muls(d, t));
+    double a, b;
+    if (axis == 2) { a = p.x; b = p.y; }
+    else if (axis == 1) { a = p.x; b = p.z; }
+    else { a = p.y; b = p.z; }
+    if (a < r0.x || a > r1.x || b < r0.y || b > r1.y) return false;
+    t_out = t;
+    return true;
+}
+DEV D3 ld3(const double* p, uint32_t i) { return mk(p[3 * i], p[3 * i + 1], p[3 * i + 2]); }
+// Triangle::hit, mesh.rs:57-102 ; returns t and the barycentrics b1,b2
+DEV bool tri_hit(const Acc& A, uint4 tr, D3 o, D3 dir, double t_min, double t_max, double& t_out, double& b1o, double& b2o) {
+    D3 pa = ld3(A.vpos, tr.x), pb = ld3(A.vpos, tr.y), pc = ld3(A.vpos, tr.z);
+    D3 e0 = sub(pb, pa), e1 = sub(pc, pa);
+    D3 s0 = cross(dir, e1);
+    double dd = dot(s0, e0);
+    if (dd == 0.0) return false;
+    double div = 1.0 / dd;
+    D3 d = sub(o, pa);
+    double b1 = dot(d, s0) * div;
+    if (b1 < 0.0 || b1 > 1.0) return false;
+    D3 s1 = cross(d, e0);
+    double b2 = dot(dir, s1) * div;
+    if (b2 < 0.0 || b1 + b2 > 1.0) return false;
+    double t = dot(e1, s1) * div;
+    if (t < t_min || t > t_max) return false;
+    t_out = t;
+    b1o = b1;
+    b2o = b2;
+    return true;
+}
+
+struct Hit {
+    double t;
+    int node;  // DFS index of the winning leaf, -1 = miss
+    int xf;    // enclosing Transform (xform index) or -1
+};
+
+// World::hit -> BVHNode::hit / Vec::hit / Transform::hit, flattened (common/flat.h).
+// Visits nodes in the reference's own order; a leaf is accepted when t_min <= t <= best
+// (inclusive, so a later leaf wins an exact tie -- sphere.rs:36, rectangle.rs:20, mesh.rs:96).
+template <bool GENERAL>
+DEV Hit traverse(const Acc& A, D3 wo, D3 wd, double t_min, double t_max) {
+    D3 o = wo, d = wd;
+    D3 inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+    double a = sqlen(d);
+    Hit h;
+    h.t = t_max;
+    h.node = -1;
+    h.xf = -1;
+    int cur_xf = -1;
+    uint32_t n = 0;
+    const uint32_t N = A.n_nodes;
+    while (n < N) {
+        uint2 m = A.meta[n];
+        uint32_t kind = m.x & NK_MASK, pl = m.x >> NK_BITS;
+        if (kind == NK_BOX) {
+            n = aabb_hit(A.boxes + 3 * pl, o, inv, t_min, h.t) ? n + 1 : m.y;
+        } else if (kind == NK_SPHERE) {
+            double t;
+            if (sphere_hit(A.spheres + 2 * pl, o, d, a, t_min, h.t, t)) {
+                h.t = t;
+                h.node = (int)n;
+                h.xf = cur_xf;
+            }
+            n++;
+        } else if (GENERAL) {
+            if (kind == NK_RECT_YZ || kind == NK_RECT_XZ || kind == NK_RECT_XY) {
+                double t;
+                if (rect_hit(A.rects + 3 * pl, (int)kind - (int)NK_RECT_YZ, o, d, t_min, h.t, t)) {
+                    h.t = t;
+                    h.node = (int)n;
+                    h.xf = cur_xf;
+                }
+            } else if (kind == NK_TRI) {
+                double t, b1, b2;
+                if (tri_hit(A, A.tris[pl], o, d, t_min, h.t, t, b1, b2)) {
+                    h.t = t;
+                    h.node = (int)n;
+                    h.xf = cur_xf;
+                }
+            } else if (kind == NK_XFORM_BEGIN) {  // transform.rs:153-156
+                const double* Minv = A.xforms + 32 * pl;
+                o = xf_point(Minv, wo);
+                d = xf_dir(Minv, wd);
+                inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+                a = sqlen(d);
+                cur_xf = (int)pl;
+            } else {  // NK_XFORM_END
+                o = wo;
+                d = wd;
+                inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+                a = sqlen(d);
+                cur_xf = -1;
+            }
+            n++;
+        } else {
+            n++;
+        }
+    }
+    return h;
+}
+
+struct Rec {  // HitRecord, hit.rs:7-14
+    D3 p, normal;
+    bool front_face;
+    double u, v;
+    int mat;
+};
+
+DEV D3 tex_color(const Acc& A, int tex, const Rec& rec) {  // material.rs:52-84
+    const TexDev* t = &A.texs[tex];
+    int type = t->type;
+    if (type == 1) {  // CheckerTexture: .0 when sines < 0
+        D3 p = rec.p;
+        double sines = sin(10. * p.x) * sin(10. * p.y) * sin(10. * p.z);
+        t = &A.texs[(sines < 0.) ? t->t0 : t->t1];
+        type = 0;
+    }
+    if (type == 0) return mk(t->color[0], t->color[1], t->color[2]);
+    // ImageTexture: nearest texel, v flipped; x == w at u == 1 is clamped (Q11)
+    double u = fmin(fmax(rec.u, 0.), 1.), v = 1. - fmin(fmax(rec.v, 0.), 1.);
+    int x = (int)floor((double)t->w * u), y = (int)floor((double)t->h * v);
+    if (x > t->w - 1) x = t->w - 1;
+    if (y > t->h - 1) y = t->h - 1;
+    const uint8_t* px = A.texels + t->texel_off + ((size_t)y * t->w + x) * 3;
+    return mk(px[0] / 255., px[1] / 255., px[2] / 255.);
+}
+
+// Build the HitRecord of the winning leaf only (the reference builds one per candidate).
+template <bool GENERAL>
+DEV Rec materialize(const Acc& A, const Hit& h, D3 wo, D3 wd, int* err) {
+    Rec rec;
+    uint2 m = A.meta[h.node];
+    uint32_t kind = m.x & NK_MASK, pl = m.x >> NK_BITS;
+    D3 o = wo, d = wd;
+    if (GENERAL && h.xf >= 0) {
+        const double* Minv = A.xforms + 32 * h.xf;
+        o = xf_point(Minv, wo);
+        d = xf_dir(Minv, wd);
+    }
+    D3 outward;
+    rec.u = 0.;
+    rec.v = 0.;
+    bool want_uv = false;
+    if (kind == NK_SPHERE) {  // sphere.rs:45-53
+        double2 c0 = A.spheres[2 * pl], c1 = A.spheres[2 * pl + 1];
+        rec.mat = A.sphere_mat[pl];
+        D3 p = add(o, muls(d, h.t));
+        outward = divs(sub(p, mk(c0.x, c0.y, c1.x)), c1.y);
+        want_uv = A.texs[A.mats[rec.mat].tex].type == 2;
+        if (want_uv) {  // get_uv, sphere.rs:16-20 (only an ImageTexture reads it)
+            const double PI = 3.14159265358979323846264338327950288, FRAC_1_PI = 0.318309886183790671537767526745028724;
+            double theta = acos(-outward.y);
+            double phi = atan2(-outward.z, outward.x) + PI;
+            rec.u = phi * FRAC_1_PI * 0.5;
+            rec.v = theta * FRAC_1_PI;
+        }
+    } else if (GENERAL && kind != NK_TRI) {  // rectangles
+        int axis = (int)kind - (int)NK_RECT_YZ;
+        double2 r0 = A.rects[3 * pl], r1 = A.rects[3 * pl + 1];
+        rec.mat = A.rect_mat[pl];
+        outward = mk(axis == 0 ? 1. : 0., axis == 1 ? 1. : 0., axis == 2 ? 1. : 0.);
+        if (A.texs[A.mats[rec.mat].tex].type == 2) {
+            D3 p = add(o, muls(d, h.t));
+            double a, b;
+            if (axis == 2) { a = p.x; b = p.y; }
+            else if (axis == 1) { a = p.x; b = p.z; }
+            else { a = p.y; b = p.z; }
+            rec.u = (a - r0.x) / (r1.x - r0.x);
+            rec.v = (b - r0.y) / (r1.y - r0.y);
+        }
+    } else if (GENERAL) {  // triangle, mesh.rs:104-137 : recompute the barycentrics (same ops, same bits)
+        uint4 tr = A.tris[pl];
+        rec.mat = (int)tr.w;
+        double t, b1 = 0., b2 = 0.;
+        tri_hit(A, tr, o, d, -INFINITY, INFINITY, t, b1, b2);
+        double b0 = 1.0 - b1 - b2;
+        D3 na = ld3(A.vnrm, tr.x), nb = ld3(A.vnrm, tr.y), nc = ld3(A.vnrm, tr.z);
+        outward = unit(add(add(muls(na, b0), muls(nb, b1)), muls(nc, b2)), err);
+    } else {
+        outward = mk(0., 0., 0.);
+        rec.mat = 0;
+    }
+    // HitRecord::new, hit.rs:16-39
+    rec.p = add(o, muls(d, h.t));
+    rec.front_face = dot(d, outward) < 0.;
+    rec.normal = unit(rec.front_face ? outward : neg(outward), err);
+    if (GENERAL && h.xf >= 0) {  // Transform::hit, transform.rs:157-161 (Q7, Q8)
+        const double* M = A.xforms + 32 * h.xf + 16;
+        D3 on = xf_dir(M, rec.normal);
+        rec.p = xf_point(M, rec.p);
+        rec.front_face = dot(d, on) < 0.;  // d is still the object-space ray
+        D3 un = unit(on, err);
+        rec.normal = rec.front_face ? un : neg(un);
+    }
+    return rec;
+}
+
+// Material::emitted + Material::scatter, material.rs:88-212.  Returns false on Absorb.
+DEV bool shade(const Acc& A, const Rec& rec, D3 rdir, Rng& rng, D3& emitted, D3& att, D3& out_dir, int* err) {
+    const MatDev mt = A.mats[rec.mat];
+    emitted = mk(0., 0., 0.);
+    if (mt.type == 0 || mt.type == 3) {  // Lambertian / DiffuseLight: scattered_direction, material.rs:92-98
+        D3 dir = add(rec.normal, unit(random_in_unit_sphere(rng), err));
+        if (near_zero(dir)) dir = rec.normal;
+        out_dir = dir;
+        if (mt.type == 0) {
+            att = tex_color(A, mt.tex, rec);
+        } else {
+            const double FRAC_1_PI = 0.318309886183790671537767526745028724;
+            att = mk(1. * FRAC_1_PI, 1. * FRAC_1_PI, 1. * FRAC_1_PI);  // material.rs:201-203
+            emitted = tex_color(A, mt.tex, rec);                         // material.rs:209-211 (no face test)
+        }
+        return true;
+    }
+    if (mt.type == 1) {  // Metal, material.rs:126-139 ; fuzz sample drawn even when fuzz == 0 (Q4)
+        D3 reflected = reflect(unit(rdir, err), rec.normal);
+        D3 dir = add(reflected, muls(random_in_unit_sphere(rng), mt.param));
+        if (dot(dir, rec.normal) > 0.) {
+            out_dir = dir;
+            att = tex_color(A, mt.tex, rec);
+            return true;
+        }
+        return false;  // Absorb (Q15)
+    }
+    // Dielectric, material.rs:157-188
+    att = tex_color(A, mt.tex, rec);
+    double ratio = rec.front_face ? (1.0 / mt.param) : mt.param;
+    D3 ud = unit(rdir, err);
+    double cos_theta = fmin(dot(neg(ud), rec.normal), 1.0);
+    double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
+    bool cannot_refract = ratio * sin_theta > 1.0;
+    bool do_reflect = cannot_refract;
+    if (!do_reflect) {  // the random number is consumed only when refraction is possible (Q16)
+        double q = (1. - ratio) / (1. + ratio);  // reflectance, material.rs:150-154
+        double r0 = q * q;
+        double b = 1. - cos_theta;
+        double b2 = b * b;
+        double b4 = b2 * b2;
+        double refl = r0 + (1. - r0) * (b * b4);
+        do_reflect = refl > rng.gen_f64();
+    }
+    out_dir = do_reflect ? reflect(ud, rec.normal) : refract(ud, rec.normal, ratio);
+    return true;
+}
+
+// ------------------------------------------------------------ pt_kernel ---
+template <bool LDS, bool GENERAL>
+__global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, RenderK rk, double* __restrict__ samples,
+                                                      unsigned int* __restrict__ counter, int* __restrict__ err) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Acc A;
+    if (LDS) {
+        const uint4* src = (const uint4*)sv.base;
+        uint4* dst = (uint4*)smem;
+        for (uint32_t i = threadIdx.x; i < sv.stage_bytes / 16; i += blockDim.x) dst[i] = src[i];
+        __syncthreads();
+        A = make_acc(smem, sv.base, sv);
+    } else {
+        A = make_acc(sv.base, sv.base, sv);
+    }
+    const int lane = threadIdx.x & 63;
+    const uint64_t lanemask_lt = (1ull << lane) - 1ull;
+
+    for (;;) {
+        unsigned int unit = 0;
+        if (lane == 0) unit = atomicAdd(counter, 1u);
+        unit = __builtin_amdgcn_readfirstlane(unit);
+        if (unit >= (unsigned)rk.n_units) break;  // every wave reaches this: the counter only grows
+        const int lt = (int)(unit / (unsigned)rk.subs_per_tile);
+        const int sub_i = (int)(unit - (unsigned)lt * (unsigned)rk.subs_per_tile);
+        const int tile = lt * rk.world + rk.rank;
+        const int tx = tile % rk.tiles_x, ty = tile / rk.tiles_x;
+        const int s0 = rk.s_begin + sub_i * rk.sub_spp;
+        const int s1 = min(s0 + rk.sub_spp, rk.s_end);
+        const int pool = (s1 - s0) * TILE_PIX;
+        int next = 0;  // wave-uniform
+
+        bool alive = false;
+        D3 o = mk(0, 0, 0), d = mk(0, 0, 1), beta = mk(1, 1, 1), L = mk(0, 0, 0);
+        int depth = 0;
+        size_t out_idx = 0;
+        Rng rng;
+        rng.s = 0;
+
+        for (;;) {
+            // ---- regeneration: dead lanes pull the next (pixel, sample) of the pool ----
+            uint64_t dead = __ballot(!alive);
+            if (dead != 0ull && next < pool) {
+                int k = next + __popcll(dead & lanemask_lt);
+                next = min(next + (int)__popcll(dead), pool);
+                if (!alive && k < pool) {
+                    int pix = k & (TILE_PIX - 1), s = s0 + (k >> 6);
+                    int x = tx * TILE_W + (pix & (TILE_W - 1)), y = ty * TILE_H + (pix >> 3);
+                    if (x < rk.width && y < rk.height) {
+                        // camera.rs:97-99 + Camera::get_ray camera.rs:57-64
+                        rng.seed_stream(rk.seed, (uint64_t)y * (uint64_t)rk.width + (uint64_t)x, (uint64_t)s);
+                        double u = ((double)x + rng.gen_f64()) / (double)(rk.width - 1);
+                        double v = ((double)y + rng.gen_f64()) / (double)(rk.height - 1);
+                        double st = 1.0 - v;
+                        D3 rd = muls(random_in_unit_disk(rng), cam.lens_radius);  // drawn even for aperture 0 (Q4)
+                        D3 offset = add(muls(cam.u, rd.x), muls(cam.v, rd.y));
+                        o = add(cam.origin, offset);
+                        d = sub(sub(add(add(cam.llc, muls(cam.horizontal, u)), muls(cam.vertical, st)), cam.origin), offset);
+                        beta = mk(1., 1., 1.);
+                        L = mk(0., 0., 0.);
+                        depth = rk.max_depth;
+                        out_idx = ((size_t)((size_t)lt * rk.chunk_spp + (s - rk.s_begin)) * TILE_PIX + pix) * 3;
+                        alive = true;
+                    }
+                }
+            }
+            if (__ballot(alive) == 0ull) {
+                if (next >= pool) break;
+                continue;
+            }
+            // ---- one path segment: sample_ray's loop body, photon_mapper.rs:335-362 ----
+            if (alive) {
+                Hit h = traverse<GENERAL>(A, o, d, rk.t_min, INFINITY);
+                bool done = true;
+                if (h.node >= 0 && depth > 0) {  // Q12: depth test after the hit, before emission
+                    depth -= 1;
+                    Rec rec = materialize<GENERAL>(A, h, o, d, err);
+                    D3 emitted, att, ndir;
+                    bool scattered = shade(A, rec, d, rng, emitted, att, ndir, err);
+                    L = add(L, elemul(beta, emitted));  // radiance += throughput * Le
+                    if (scattered) {  // Diffuse continues like Specular/Reflect/Refract (photon_mapper.rs:346-347)
+                        beta = elemul(beta, att);
+                        o = rec.p;
+                        d = ndir;
+                        done = false;
+                    }
+                }
+                if (done) {
+                    samples[out_idx] = L.x;
+                    samples[out_idx + 1] = L.y;
+                    samples[out_idx + 2] = L.z;
+                    alive = false;
+                }
+            }
+        }
+    }
+}
+
+// per pixel: accum += samples in sample order (camera.rs:96-101). One thread per (tile, pixel).
+__global__ void reduce_kernel(const double* __restrict__ samples, double* __restrict__ accum, int64_t n_pix, int chunk_spp,
+                              int n_s, int first) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pix) return;
+    int64_t lt = i >> 6;
+    int pix = (int)(i & 63);
+    double ax = 0., ay = 0., az = 0.;
+    if (!first) {
+        ax = accum[3 * i];
+        ay = accum[3 * i + 1];
+        az = accum[3 * i + 2];
+    }
+    const double* p = samples + ((size_t)lt * chunk_spp * TILE_PIX + pix) * 3;
+    for (int s = 0; s < n_s; s++) {
+        ax = ax + p[0];
+        ay = ay + p[1];
+        az = az + p[2];
+        p += TILE_PIX * 3;
+    }
+    accum[3 * i] = ax;
+    accum[3 * i + 1] = ay;
+    accum[3 * i + 2] = az;
+}
+// pixel_color /= spp (camera.rs:102); pixels of edge tiles that fall outside the image are zeroed
+__global__ void finalize_kernel(const double* __restrict__ accum, double* __restrict__ tiles, int64_t n_pix, int spp, int width,
+                                int height, int tiles_x, int rank, int world) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pix) return;
+    int64_t lt = i >> 6;
+    int pix = (int)(i & 63);
+    int64_t tile = lt * world + rank;
+    int x = (int)(tile % tiles_x) * TILE_W + (pix & 7), y = (int)(tile / tiles_x) * TILE_H + (pix >> 3);
+    bool inside = x < width && y < height;
+    double n = (double)spp;
+    tiles[3 * i] = inside ? accum[3 * i] / n : 0.;
+    tiles[3 * i + 1] = inside ? accum[3 * i + 1] / n : 0.;
+    tiles[3 * i + 2] = inside ? accum[3 * i + 2] / n : 0.;
+}
+// the stitch, camera.rs:115-123: gathered[rank][local tile][pix][3] -> frame[y][x][3]
+__global__ void assemble_kernel(const double* __restrict__ gathered, int64_t stride_tiles, double* __restrict__ frame, int width,
+                                int height, int tiles_x, int world) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t n = (int64_t)width * height;
+    if (i >= n) return;
+    int x = (int)(i % width), y = (int)(i / width);
+    int64_t tile = (int64_t)(y >> 3) * tiles_x + (x >> 3);
+    int r = (int)(tile % world);
+    int64_t lt = tile / world;
+    int pix = ((y & 7) << 3) | (x & 7);
+    const double* src = gathered + (((int64_t)r * stride_tiles + lt) * TILE_PIX + pix) * 3;
+    frame[3 * i] = src[0];
+    frame[3 * i + 1] = src[1];
+    frame[3 * i + 2] = src[2];
+}
+
+// ------------------------------------------------------- debug kernels ----
+__global__ void rng_kernel(uint64_t seed, uint64_t pixel, uint64_t sample, int n, uint64_t* out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    Rng r;
+    r.seed_stream(seed, pixel, sample);
+    for (int i = 0; i < n; i++) out[i] = r.next_u64();
+}
+__global__ void math_kernel(int op, size_t n, const double* a, const double* b, double* out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = (op == 0) ? sqrt(a[i]) : a[i] / b[i];
+}
+__global__ void hit_kernel(FlatView sv, size_t n, const double* rays, double t_min, double t_max, double* out, int* err) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Acc A = make_acc(sv.base, sv.base, sv);
+    D3 o = mk(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]), d = mk(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
+    Hit h = traverse<true>(A, o, d, t_min, t_max);
+    double* q = out + 12 * i;
+    for (int k = 0; k < 12; k++) q[k] = 0.;
+    if (h.node < 0) return;
+    Rec rec = materialize<true>(A, h, o, d, err);
+    // uv is materialised lazily (only for image textures); recompute it here for the diagnostic
+    q[0] = 1.;
+    q[1] = h.t;
+    q[2] = rec.p.x; q[3] = rec.p.y; q[4] = rec.p.z;
+    q[5] = rec.normal.x; q[6] = rec.normal.y; q[7] = rec.normal.z;
+    q[8] = rec.front_face ? 1. : 0.;
+    q[9] = rec.u; q[10] = rec.v;
+    q[11] = (double)h.node;
+}
+
+// ------------------------------------------------------------ host side ---
+int device_count() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void* dev_alloc(size_t n) {
+    void* p = nullptr;
+    HIP_CHECK(hipMalloc(&p, n ? n : 16));
+    return p;
+}
+void dev_free(void* p) { (void)hipFree(p); }
+void dev_copy_to_host(void* dst, const void* src, size_t n) { HIP_CHECK(hipMemcpy(dst, src, n, hipMemcpyDeviceToHost)); }
+void dev_set_device(int d) { HIP_CHECK(hipSetDevice(d)); }
+
+static const char* device_blob(const rt_scene& s, int dev) {
+    std::lock_guard<std::mutex> g(s.dev_mu);
+    for (auto& c : s.dev)
+        if (c.device == dev) return (const char*)c.d_blob;
+    DeviceCopy c;
+    c.device = dev;
+    HIP_CHECK(hipMalloc(&c.d_blob, s.flat.blob.size()));
+    HIP_CHECK(hipMemcpy(c.d_blob, s.flat.blob.data(), s.flat.blob.size(), hipMemcpyHostToDevice));
+    s.dev.push_back(c);
+    return (const char*)c.d_blob;
+}
+void free_device_copies(rt_scene& s) {
+    std::lock_guard<std::mutex> g(s.dev_mu);
+    for (auto& c : s.dev) {
+        int cur = 0;
+        if (hipGetDevice(&cur) == hipSuccess) {
+            (void)hipSetDevice(c.device);
+            (void)hipFree(c.d_blob);
+            (void)hipSetDevice(cur);
+        }
+    }
+    s.dev.clear();
+}
+
+static CamK to_camk(const CameraDev& c) {
+    CamK k;
+    k.origin = D3{c.origin[0], c.origin[1], c.origin[2]};
+    k.llc = D3{c.llc[0], c.llc[1], c.llc[2]};
+    k.horizontal = D3{c.horizontal[0], c.horizontal[1], c.horizontal[2]};
+    k.vertical = D3{c.vertical[0], c.vertical[1], c.vertical[2]};
+    k.u = D3{c.u[0], c.u[1], c.u[2]};
+    k.v = D3{c.v[0], c.v[1], c.v[2]};
+    k.lens_radius = c.lens_radius;
+    return k;
+}
+
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    void alloc(size_t n) { HIP_CHECK(hipMalloc(&p, n ? n : 16)); }
+};
+struct Events {
+    std::vector<hipEvent_t> ev;
+    ~Events() {
+        for (auto e : ev) (void)hipEventDestroy(e);
+    }
+    hipEvent_t make() {
+        hipEvent_t e;
+        HIP_CHECK(hipEventCreate(&e));
+        ev.push_back(e);
+        return e;
+    }
+};
+
+typedef void (*pt_fn)(FlatView, CamK, RenderK, double*, unsigned int*, int*);
+
+void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& plan, double* d_tiles, void* stream_, rt_stats* st) {
+    if (!s.committed) throw RtError(RT_ERR_NOT_COMMITTED, "scene not committed");
+    hipStream_t stream = (hipStream_t)stream_;
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+
+    FlatView view = s.flat.view;
+    view.base = device_blob(s, dev);
+    const bool general = (view.kinds_mask & ~((1u << NK_BOX) | (1u << NK_SPHERE))) != 0;
+    const size_t lds_budget = (size_t)prop.sharedMemPerBlock > 160 * 1024 ? 160 * 1024 : (size_t)prop.sharedMemPerBlock;
+    size_t lds_max = 0;
+    {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess && v > 0) lds_max = (size_t)v;
+        if (lds_max < lds_budget) lds_max = lds_budget;
+    }
+    const bool lds = view.stage_bytes > 0 && view.stage_bytes <= lds_max;
+    pt_fn fn = lds ? (general ? pt_kernel<true, true> : pt_kernel<true, false>) : (general ? pt_kernel<false, true> : pt_kernel<false, false>);
+    const size_t smem = lds ? view.stage_bytes : 0;
+    if (smem > 48 * 1024) HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    int blocks_per_cu = 0;
+    HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, (const void*)fn, PT_BLOCK, smem));
+    if (blocks_per_cu < 1) blocks_per_cu = 1;
+    const int grid = prop.multiProcessorCount * blocks_per_cu;
+
+    const int64_t n_pix = plan.tiles_owned * TILE_PIX;
+    DevBuf samples, accum, counter, err;
+    samples.alloc((size_t)n_pix * plan.spp_chunk * 3 * sizeof(double));
+    accum.alloc((size_t)n_pix * 3 * sizeof(double));
+    counter.alloc(sizeof(unsigned int));
+    err.alloc(sizeof(int));
+    HIP_CHECK(hipMemsetAsync(err.p, 0, sizeof(int), stream));
+
+    Events events;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pt_ev, red_ev;
+    CamK ck = to_camk(cam);
+    int launches = 0;
+    for (int s0 = 0; s0 < plan.spp; s0 += plan.spp_chunk) {
+        const int s1 = std::min(s0 + plan.spp_chunk, plan.spp);
+        RenderK rk;
+        rk.width = plan.width; rk.height = plan.height; rk.max_depth = plan.max_depth;
+        rk.t_min = plan.t_min; rk.seed = plan.seed;
+        rk.s_begin = s0; rk.s_end = s1;
+        rk.sub_spp = plan.sub_spp;
+        rk.subs_per_tile = (s1 - s0 + plan.sub_spp - 1) / plan.sub_spp;
+        int64_t units = plan.tiles_owned * rk.subs_per_tile;
+        if (units > 0x7FFFFFFF) throw RtError(RT_ERR_UNSUPPORTED, "too many work units per launch");
+        rk.n_units = (int)units;
+        rk.tiles_x = plan.tiles_x; rk.rank = plan.rank; rk.world = plan.world;
+        rk.chunk_spp = plan.spp_chunk;
+        HIP_CHECK(hipMemsetAsync(counter.p, 0, sizeof(unsigned int), stream));
+        hipEvent_t e0 = events.make(), e1 = events.make(), e2 = events.make();
+        HIP_CHECK(hipEventRecord(e0, stream));
+        if (rk.n_units > 0) {
+            hipLaunchKernelGGL(fn, dim3(grid), dim3(PT_BLOCK), smem, stream, view, ck, rk, (double*)samples.p, (unsigned int*)counter.p,
+                               (int*)err.p);
+            HIP_CHECK(hipGetLastError());
+        }
+        HIP_CHECK(hipEventRecord(e1, stream));
+        if (n_pix > 0) {
+            hipLaunchKernelGGL(reduce_kernel, dim3((unsigned)((n_pix + 255) / 256)), dim3(256), 0, stream, (const double*)samples.p,
+                               (double*)accum.p, n_pix, plan.spp_chunk, s1 - s0, s0 == 0 ? 1 : 0);
+            HIP_CHECK(hipGetLastError());
+        }
+        HIP_CHECK(hipEventRecord(e2, stream));
+        pt_ev.emplace_back(e0, e1);
+        red_ev.emplace_back(e1, e2);
+        launches++;
+    }
+    if (n_pix > 0) {
+        hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((n_pix + 255) / 256)), dim3(256), 0, stream, (const double*)accum.p, d_tiles,
+                           n_pix, plan.spp, plan.width, plan.height, plan.tiles_x, plan.rank, plan.world);
+        HIP_CHECK(hipGetLastError());
+    }
+    int h_err = 0;
+    HIP_CHECK(hipMemcpyAsync(&h_err, err.p, sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    if (st) {
+        double kms = 0, rms = 0;
+        for (auto& p : pt_ev) {
+            float ms = 0;
+            HIP_CHECK(hipEventElapsedTime(&ms, p.first, p.second));
+            kms += ms;
+        }
+        for (auto& p : red_ev) {
+            float ms = 0;
+            HIP_CHECK(hipEventElapsedTime(&ms, p.first, p.second));
+            rms += ms;
+        }
+        st->kernel_ms = kms;
+        st->reduce_ms = rms;
+        st->launches = launches;
+        st->kernel_used = 1;
+        st->scene_in_lds = lds ? 1 : 0;
+        st->block_threads = PT_BLOCK;
+        st->grid_blocks = grid;
+        st->spp_chunk = plan.spp_chunk;
+        st->scene_bytes = s.flat.blob.size();
+    }
+    if (h_err) throw RtError(RT_ERR_UNIT_ZERO, "unitizing zero vector (device)");
+}
+
+void assemble_frame(const RenderPlan& plan, const double* d_gathered, int64_t stride, double* d_frame, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    int64_t n = (int64_t)plan.width * plan.height;
+    hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_gathered, stride, d_frame, plan.width,
+                       plan.height, plan.tiles_x, plan.world);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(stream));
+}
+
+void debug_rng_device(uint64_t seed, uint64_t pixel, uint64_t sample, int n, uint64_t* out_host) {
+    DevBuf b;
+    b.alloc((size_t)n * 8);
+    hipLaunchKernelGGL(rng_kernel, dim3(1), dim3(64), 0, 0, seed, pixel, sample, n, (uint64_t*)b.p);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpy(out_host, b.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+}
+void debug_math_device(int op, size_t n, const double* a, const double* bb, double* out) {
+    DevBuf da, db, dc;
+    da.alloc(n * 8);
+    db.alloc(n * 8);
+    dc.alloc(n * 8);
+    HIP_CHECK(hipMemcpy(da.p, a, n * 8, hipMemcpyHostToDevice));
+    if (bb) HIP_CHECK(hipMemcpy(db.p, bb, n * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, op, n, (const double*)da.p, (const double*)db.p,
+                       (double*)dc.p);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpy(out, dc.p, n * 8, hipMemcpyDeviceToHost));
+}
+void debug_hit_device(const rt_scene& s, size_t n, const double* rays, double t_min, double t_max, double* out) {
+    if (!s.committed) throw RtError(RT_ERR_NOT_COMMITTED, "scene not committed");
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    FlatView view = s.flat.view;
+    view.base = device_blob(s, dev);
+    DevBuf dr, dout, err;
+    dr.alloc(n * 48);
+    dout.alloc(n * 96);
+    err.alloc(4);
+    HIP_CHECK(hipMemset(err.p, 0, 4));
+    HIP_CHECK(hipMemcpy(dr.p, rays, n * 48, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(hit_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, view, n, (const double*)dr.p, t_min, t_max,
+                       (double*)dout.p, (int*)err.p);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpy(out, dout.p, n * 96, hipMemcpyDeviceToHost));
+}
+
+}  // namespace rtamd

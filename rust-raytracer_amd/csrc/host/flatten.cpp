@@ -1,0 +1,199 @@
+// Flattener: object graph -> linear DFS pre-order program + SoA tables in one blob
+// (layout: common/flat.h).  The emission order IS the reference's visit order:
+//   BVHNode::hit   box, then left subtree, then right subtree   (bvh.rs:86-102)
+//   Vec<..>::hit   items in insertion order                     (hit.rs:57-67)
+//   Cube::hit      its 6 sides as a list                        (cube.rs:64-66)
+//   Mesh::hit      its inner BVHNode                            (mesh.rs:201-203)
+//   Transform::hit enter object space, inner object, leave      (transform.rs:152-165)
+// so the kernel's closest-hit update ("accept when t <= best", later wins ties)
+// reproduces the reference's result including its tie rule.
+#include <cstring>
+#include <map>
+
+#include "scene.h"
+
+namespace rtamd {
+
+namespace {
+
+struct Builder {
+    rt_scene& s;
+    std::vector<uint32_t> meta;
+    std::vector<double> boxes, spheres, rects, xforms, vpos, vnrm;
+    std::vector<int32_t> sphere_mat, rect_mat;
+    std::vector<uint32_t> tris;
+    std::map<int, uint32_t> sphere_of, rect_of, tri_of, xform_of;
+    std::vector<uint32_t> mesh_base;
+    uint32_t kinds = 0;
+    int xf_depth = 0, depth = 0, max_depth = 0;
+
+    explicit Builder(rt_scene& sc) : s(sc) {}
+
+    uint32_t node(uint32_t kind, uint32_t payload, uint32_t skip = 0) {
+        if (payload >= (1u << (32 - NK_BITS))) throw RtError(RT_ERR_UNSUPPORTED, "scene too large for 28-bit payload index");
+        meta.push_back(kind | (payload << NK_BITS));
+        meta.push_back(skip);
+        kinds |= 1u << kind;
+        return (uint32_t)(meta.size() / 2 - 1);
+    }
+
+    void emit(int id) {
+        const ObjectRec& o = s.objects[id];
+        depth++;
+        if (depth > max_depth) max_depth = depth;
+        switch (o.type) {
+            case OBJ_SPHERE: {
+                auto it = sphere_of.find(id);
+                if (it == sphere_of.end()) {
+                    it = sphere_of.emplace(id, (uint32_t)sphere_mat.size()).first;
+                    spheres.insert(spheres.end(), {o.c[0], o.c[1], o.c[2], o.r});
+                    sphere_mat.push_back(o.material);
+                }
+                node(NK_SPHERE, it->second);
+                break;
+            }
+            case OBJ_RECT: {
+                auto it = rect_of.find(id);
+                if (it == rect_of.end()) {
+                    it = rect_of.emplace(id, (uint32_t)rect_mat.size()).first;
+                    rects.insert(rects.end(), {o.a0, o.b0, o.a1, o.b1, o.k, 0.0});
+                    rect_mat.push_back(o.material);
+                }
+                node(o.axis == 0 ? NK_RECT_YZ : (o.axis == 1 ? NK_RECT_XZ : NK_RECT_XY), it->second);
+                break;
+            }
+            case OBJ_TRIANGLE: {
+                auto it = tri_of.find(id);
+                if (it == tri_of.end()) {
+                    it = tri_of.emplace(id, (uint32_t)(tris.size() / 4)).first;
+                    uint32_t base = mesh_base[o.mesh];
+                    tris.insert(tris.end(), {base + o.ia, base + o.ib, base + o.ic, (uint32_t)o.material});
+                }
+                node(NK_TRI, it->second);
+                break;
+            }
+            case OBJ_CUBE:
+            case OBJ_LIST:
+            case OBJ_MESH:
+                for (int c : o.children) emit(c);
+                break;
+            case OBJ_BVH: {
+                uint32_t bi = (uint32_t)(boxes.size() / 6);
+                boxes.insert(boxes.end(), {o.box.mn[0], o.box.mn[1], o.box.mn[2], o.box.mx[0], o.box.mx[1], o.box.mx[2]});
+                uint32_t n = node(NK_BOX, bi);
+                emit(o.children[0]);
+                emit(o.children[1]);
+                meta[2 * n + 1] = (uint32_t)(meta.size() / 2);
+                break;
+            }
+            case OBJ_TRANSFORM: {
+                if (xf_depth >= 1) throw RtError(RT_ERR_UNSUPPORTED, "nested Transform (depth > 1) is not supported by the device traversal yet");
+                auto it = xform_of.find(id);
+                if (it == xform_of.end()) {
+                    it = xform_of.emplace(id, (uint32_t)(xforms.size() / 32)).first;
+                    xforms.insert(xforms.end(), o.Minv, o.Minv + 16);
+                    xforms.insert(xforms.end(), o.M, o.M + 16);
+                }
+                uint32_t n = node(NK_XFORM_BEGIN, it->second);
+                xf_depth++;
+                emit(o.children[0]);
+                xf_depth--;
+                node(NK_XFORM_END, it->second);
+                meta[2 * n + 1] = (uint32_t)(meta.size() / 2);
+                break;
+            }
+            default:
+                throw RtError(RT_ERR_ARG, "unknown object type in flatten");
+        }
+        depth--;
+    }
+};
+
+template <class T>
+uint32_t append(std::vector<char>& blob, const std::vector<T>& v) {
+    size_t off = (blob.size() + 15) & ~size_t(15);
+    blob.resize(off);
+    if (!v.empty()) {
+        blob.resize(off + v.size() * sizeof(T));
+        std::memcpy(blob.data() + off, v.data(), v.size() * sizeof(T));
+    }
+    if (blob.size() > 0xFFFFFFF0u) throw RtError(RT_ERR_UNSUPPORTED, "flattened scene exceeds 4 GiB");
+    return (uint32_t)off;
+}
+
+}  // namespace
+
+void flatten(rt_scene& s) {
+    if (s.root < 0) throw RtError(RT_ERR_ARG, "scene has no root (rt_world_new / rt_scene_set_root)");
+    Builder b(s);
+    // global vertex table: meshes concatenated
+    uint32_t nv = 0;
+    for (auto& m : s.meshes) {
+        b.mesh_base.push_back(nv);
+        nv += (uint32_t)(m->pos.size() / 3);
+        b.vpos.insert(b.vpos.end(), m->pos.begin(), m->pos.end());
+        b.vnrm.insert(b.vnrm.end(), m->nrm.begin(), m->nrm.end());
+    }
+    b.emit(s.root);
+
+    std::vector<MatDev> mats;
+    for (auto& m : s.materials) mats.push_back(MatDev{m.type, m.tex, m.param});
+    std::vector<TexDev> texs;
+    std::vector<uint8_t> texels;
+    for (auto& t : s.textures) {
+        TexDev d{};
+        d.type = t.type;
+        d.t0 = t.t0;
+        d.t1 = t.t1;
+        d.w = t.w;
+        d.h = t.h;
+        d.texel_off = (uint32_t)texels.size();
+        for (int i = 0; i < 3; i++) d.color[i] = t.color[i];
+        texels.insert(texels.end(), t.rgb.begin(), t.rgb.end());
+        texs.push_back(d);
+    }
+
+    FlatScene& f = s.flat;
+    f.blob.clear();
+    FlatView v{};
+    // hot part (read once per visited node): candidate for LDS residency
+    v.off_meta = append(f.blob, b.meta);
+    v.off_boxes = append(f.blob, b.boxes);
+    v.off_spheres = append(f.blob, b.spheres);
+    v.off_rects = append(f.blob, b.rects);
+    v.off_tris = append(f.blob, b.tris);
+    v.off_xforms = append(f.blob, b.xforms);
+    v.off_vpos = append(f.blob, b.vpos);
+    f.blob.resize((f.blob.size() + 15) & ~size_t(15));
+    v.stage_bytes = (uint32_t)f.blob.size();
+    // cold part (read once per path segment, by the winning leaf only): always global
+    v.off_sphere_mat = append(f.blob, b.sphere_mat);
+    v.off_rect_mat = append(f.blob, b.rect_mat);
+    v.off_mats = append(f.blob, mats);
+    v.off_texs = append(f.blob, texs);
+    v.off_vnrm = append(f.blob, b.vnrm);
+    v.off_texels = append(f.blob, texels);
+    f.blob.resize((f.blob.size() + 15) & ~size_t(15));
+    v.total_bytes = (uint32_t)f.blob.size();
+    v.n_nodes = (uint32_t)(b.meta.size() / 2);
+    v.kinds_mask = b.kinds;
+    v.base = nullptr;
+    f.view = v;
+
+    rt_scene_info& in = f.info;
+    in.n_nodes = (int32_t)v.n_nodes;
+    in.n_boxes = (int32_t)(b.boxes.size() / 6);
+    in.n_spheres = (int32_t)b.sphere_mat.size();
+    in.n_rects = (int32_t)b.rect_mat.size();
+    in.n_tris = (int32_t)(b.tris.size() / 4);
+    in.n_xforms = (int32_t)(b.xforms.size() / 32);
+    in.n_materials = (int32_t)mats.size();
+    in.n_textures = (int32_t)texs.size();
+    in.n_verts = (int32_t)nv;
+    in.max_depth = b.max_depth;
+    in.committed = 1;
+    in.bytes = f.blob.size();
+    s.committed = true;
+}
+
+}  // namespace rtamd

@@ -1,0 +1,382 @@
+"""rtamd -- Python host binding of librtamd.so (the C ABI in include/rtamd.h).
+
+Mirrors the reference's host-side interface for the radiance path (names follow
+/root/reference/raytracer/src): World / Hitable constructors (Sphere, XYRectangle,
+..., BVHNode, Transform, Mesh, Cube), Material / Texture constructors, Camera and
+Camera.capture_image.  Everything here is plumbing over ctypes; all intersection
+and shading happens in the HIP kernels.  There is no CPU fallback: rendering
+without the built library or without a HIP device raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(_ROOT, "librtamd.so")
+
+RT_OK = 0
+ERR_NAMES = {
+    -1: "RT_ERR_ARG", -2: "RT_ERR_UNIT_ZERO", -3: "RT_ERR_NO_BBOX", -4: "RT_ERR_SINGULAR", -5: "RT_ERR_IO",
+    -6: "RT_ERR_SCHEMA", -7: "RT_ERR_NO_NORMALS", -8: "RT_ERR_NOT_COMMITTED", -9: "RT_ERR_NO_DEVICE",
+    -10: "RT_ERR_UNSUPPORTED", -11: "RT_ERR_HIP",
+}
+
+
+class RtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s (%d): %s" % (ERR_NAMES.get(code, "RT_ERR"), code, msg))
+        self.code = code
+
+
+class rt_camera(C.Structure):
+    _fields_ = [("look_from", C.c_double * 3), ("look_at", C.c_double * 3), ("vup", C.c_double * 3), ("vfov", C.c_double),
+                ("aspect", C.c_double), ("aperture", C.c_double), ("focus_dist", C.c_double)]
+
+
+class rt_params(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("spp", C.c_int32), ("max_depth", C.c_int32), ("t_min", C.c_double),
+                ("seed", C.c_uint64), ("rank", C.c_int32), ("world", C.c_int32), ("spp_chunk", C.c_int32), ("kernel", C.c_int32),
+                ("device", C.c_int32), ("reserved", C.c_int32)]
+
+
+class rt_stats(C.Structure):
+    _fields_ = [("seconds", C.c_double), ("kernel_ms", C.c_double), ("reduce_ms", C.c_double), ("samples", C.c_uint64),
+                ("launches", C.c_int32), ("kernel_used", C.c_int32), ("scene_in_lds", C.c_int32), ("block_threads", C.c_int32),
+                ("grid_blocks", C.c_int32), ("spp_chunk", C.c_int32), ("scene_bytes", C.c_uint64), ("reserved", C.c_uint64 * 4)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
+class rt_scene_info(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("n_nodes", "n_boxes", "n_spheres", "n_rects", "n_tris", "n_xforms", "n_materials",
+                                         "n_textures", "n_verts", "max_depth", "committed", "reserved")] + [("bytes", C.c_uint64)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
+_d3 = C.c_double * 3
+_dp = C.POINTER(C.c_double)
+_LIB = None
+
+# every symbol include/rtamd.h declares: (name, restype, argtypes)
+_SIGS = [
+    ("rt_abi_version", C.c_int, []),
+    ("rt_last_error", C.c_char_p, []),
+    ("rt_default_params", None, [C.POINTER(rt_params)]),
+    ("rt_device_count", C.c_int, []),
+    ("rt_scene_create", C.c_int, [C.POINTER(C.c_void_p)]),
+    ("rt_scene_destroy", None, [C.c_void_p]),
+    ("rt_texture_constant", C.c_int, [C.c_void_p, _d3]),
+    ("rt_texture_checker", C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    ("rt_texture_image", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_uint8)]),
+    ("rt_material_lambertian", C.c_int, [C.c_void_p, C.c_int]),
+    ("rt_material_metal", C.c_int, [C.c_void_p, C.c_int, C.c_double]),
+    ("rt_material_dielectric", C.c_int, [C.c_void_p, C.c_double, C.c_int]),
+    ("rt_material_diffuse_light", C.c_int, [C.c_void_p, C.c_int]),
+    ("rt_object_sphere", C.c_int, [C.c_void_p, _d3, C.c_double, C.c_int]),
+    ("rt_object_rect_xy", C.c_int, [C.c_void_p] + [C.c_double] * 5 + [C.c_int]),
+    ("rt_object_rect_xz", C.c_int, [C.c_void_p] + [C.c_double] * 5 + [C.c_int]),
+    ("rt_object_rect_yz", C.c_int, [C.c_void_p] + [C.c_double] * 5 + [C.c_int]),
+    ("rt_object_cube", C.c_int, [C.c_void_p, _d3, _d3, C.c_int]),
+    ("rt_object_sphere_light", C.c_int, [C.c_void_p, _d3, C.c_double, _d3]),
+    ("rt_object_xz_rect_light", C.c_int, [C.c_void_p] + [C.c_double] * 5 + [_d3]),
+    ("rt_object_mesh", C.c_int, [C.c_void_p, C.c_int, _dp, _dp, C.c_int, C.POINTER(C.c_uint32), C.c_int, C.c_int, C.c_uint64]),
+    ("rt_object_mesh_obj", C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_uint64]),
+    ("rt_object_transform", C.c_int, [C.c_void_p, _d3, _d3, _d3, C.c_int]),
+    ("rt_object_list", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
+    ("rt_object_bvh_node", C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    ("rt_object_bvh_build", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_uint64]),
+    ("rt_object_bounding_box", C.c_int, [C.c_void_p, C.c_int, C.c_double * 6]),
+    ("rt_world_new", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_uint64]),
+    ("rt_scene_set_root", C.c_int, [C.c_void_p, C.c_int]),
+    ("rt_scene_cornell_box", C.c_int, [C.c_void_p, C.c_char_p, C.c_double, C.c_uint64, C.POINTER(rt_camera)]),
+    ("rt_scene_load_file", C.c_int, [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(rt_camera)]),
+    ("rt_scene_commit", C.c_int, [C.c_void_p]),
+    ("rt_scene_info_get", C.c_int, [C.c_void_p, C.POINTER(rt_scene_info)]),
+    ("rt_render", C.c_int, [C.c_void_p, C.POINTER(rt_camera), C.POINTER(rt_params), _dp, C.POINTER(rt_stats)]),
+    ("rt_render_tiles_device", C.c_int, [C.c_void_p, C.POINTER(rt_camera), C.POINTER(rt_params), C.c_void_p, C.c_void_p,
+                                         C.POINTER(rt_stats)]),
+    ("rt_tiles_total", C.c_int64, [C.POINTER(rt_params)]),
+    ("rt_tiles_owned", C.c_int64, [C.POINTER(rt_params)]),
+    ("rt_assemble_frame_device", C.c_int, [C.POINTER(rt_params), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    ("rt_tonemap_u8", C.c_int, [_dp, C.c_size_t, C.POINTER(C.c_uint8)]),
+    ("rt_write_png", C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_uint8)]),
+    ("rt_debug_rng_device", C.c_int, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_uint64)]),
+    ("rt_debug_rng_host", C.c_int, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_uint64)]),
+    ("rt_debug_math_device", C.c_int, [C.c_int, C.c_size_t, _dp, _dp, _dp]),
+    ("rt_debug_hit_device", C.c_int, [C.c_void_p, C.c_size_t, _dp, C.c_double, C.c_double, _dp]),
+]
+ABI_SYMBOLS = [s[0] for s in _SIGS]
+
+
+def lib():
+    """Load librtamd.so.  Raises (never falls back) when the HIP extension has not been built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("librtamd.so is missing at %s -- run `make -C rust-raytracer_amd` (or __graft_entry__.build()); "
+                          "there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    for name, res, args in _SIGS:
+        fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = L
+    return L
+
+
+def _chk(rc):
+    if rc < 0:
+        raise RtError(rc, lib().rt_last_error().decode("utf-8", "replace"))
+    return rc
+
+
+def device_count():
+    return lib().rt_device_count()
+
+
+def default_params(**kw):
+    p = rt_params()
+    lib().rt_default_params(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def _arr3(v):
+    return _d3(*[float(x) for x in v])
+
+
+class Camera:
+    """Camera::new (camera.rs:24-55) arguments; capture_image renders through a World."""
+
+    def __init__(self, look_from_to, vup, vfov, aspect_ratio, aperture, focus_dist):
+        look_from, look_at = look_from_to
+        self.c = rt_camera(_arr3(look_from), _arr3(look_at), _arr3(vup), float(vfov), float(aspect_ratio), float(aperture),
+                           float(focus_dist))
+
+    @classmethod
+    def from_struct(cls, c):
+        self = cls.__new__(cls)
+        self.c = c
+        return self
+
+    def with_aspect(self, aspect):
+        c = rt_camera.from_buffer_copy(self.c)
+        c.aspect = float(aspect)
+        return Camera.from_struct(c)
+
+    def capture_image(self, world, width=800, height=800, sample_per_pixel=256, **kw):
+        """Camera::capture_image (camera.rs:66-128): returns an RgbImage as uint8 [H,W,3]."""
+        rad, _ = world.render(self, width=width, height=height, spp=sample_per_pixel, **kw)
+        return tonemap_u8(rad)
+
+
+class World:
+    """World (world.rs:8-30) + the Hitable/Material/Texture constructors that populate it."""
+
+    def __init__(self, handle=None):
+        self.L = lib()
+        if handle is None:
+            h = C.c_void_p()
+            _chk(self.L.rt_scene_create(C.byref(h)))
+            handle = h
+        self.h = handle
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.rt_scene_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # --- textures (material.rs:48-50) ---
+    def ConstantTexture(self, color):
+        return _chk(self.L.rt_texture_constant(self.h, _arr3(color)))
+
+    def CheckerTexture(self, t0, t1):
+        return _chk(self.L.rt_texture_checker(self.h, t0, t1))
+
+    def ImageTexture(self, rgb_u8):
+        a = np.ascontiguousarray(rgb_u8, dtype=np.uint8)
+        return _chk(self.L.rt_texture_image(self.h, a.shape[1], a.shape[0], a.ctypes.data_as(C.POINTER(C.c_uint8))))
+
+    # --- materials (material.rs:88-212) ---
+    def Lambertian(self, albedo):
+        return _chk(self.L.rt_material_lambertian(self.h, albedo))
+
+    def Metal(self, albedo, fuzz):
+        return _chk(self.L.rt_material_metal(self.h, albedo, float(fuzz)))
+
+    def Dielectric(self, ir, albedo):
+        return _chk(self.L.rt_material_dielectric(self.h, float(ir), albedo))
+
+    def DiffuseLight(self, emit):
+        return _chk(self.L.rt_material_diffuse_light(self.h, emit))
+
+    # --- hitables (objects/*.rs, light.rs) ---
+    def Sphere(self, center, radius, material):
+        return _chk(self.L.rt_object_sphere(self.h, _arr3(center), float(radius), material))
+
+    def XYRectangle(self, xy0, xy1, z, material):
+        return _chk(self.L.rt_object_rect_xy(self.h, float(xy0[0]), float(xy0[1]), float(xy1[0]), float(xy1[1]), float(z), material))
+
+    def XZRectangle(self, xz0, xz1, y, material):
+        return _chk(self.L.rt_object_rect_xz(self.h, float(xz0[0]), float(xz0[1]), float(xz1[0]), float(xz1[1]), float(y), material))
+
+    def YZRectangle(self, yz0, yz1, x, material):
+        return _chk(self.L.rt_object_rect_yz(self.h, float(yz0[0]), float(yz0[1]), float(yz1[0]), float(yz1[1]), float(x), material))
+
+    def Cube(self, box_min, box_max, material):
+        return _chk(self.L.rt_object_cube(self.h, _arr3(box_min), _arr3(box_max), material))
+
+    def SphereDiffuseLight(self, center, radius, flux, scale=1.0):
+        return _chk(self.L.rt_object_sphere_light(self.h, _arr3(center), float(radius), _arr3(flux)))
+
+    def XZRectLight(self, xz0, xz1, y, flux, scale=1.0):
+        return _chk(self.L.rt_object_xz_rect_light(self.h, float(xz0[0]), float(xz0[1]), float(xz1[0]), float(xz1[1]), float(y),
+                                                   _arr3(flux)))
+
+    def Mesh(self, positions, normals, indices, material, synthesize_normals=False, bvh_seed=1):
+        p = np.ascontiguousarray(positions, dtype=np.float64).reshape(-1, 3)
+        i = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1, 3)
+        n_ptr = None
+        if normals is not None:
+            n = np.ascontiguousarray(normals, dtype=np.float64).reshape(-1, 3)
+            assert n.shape == p.shape
+            n_ptr = n.ctypes.data_as(_dp)
+        return _chk(self.L.rt_object_mesh(self.h, p.shape[0], p.ctypes.data_as(_dp), n_ptr, i.shape[0],
+                                          i.ctypes.data_as(C.POINTER(C.c_uint32)), material, int(synthesize_normals), int(bvh_seed)))
+
+    def Mesh_load_obj(self, obj_file, material, synthesize_normals=False, bvh_seed=1):
+        return _chk(self.L.rt_object_mesh_obj(self.h, os.fsencode(obj_file), material, int(synthesize_normals), int(bvh_seed)))
+
+    def Transform(self, rotate_in_degree, scale, translate, obj):
+        return _chk(self.L.rt_object_transform(self.h, _arr3(rotate_in_degree), _arr3(scale), _arr3(translate), obj))
+
+    def HitableList(self, objects):
+        arr = (C.c_int * len(objects))(*objects)
+        return _chk(self.L.rt_object_list(self.h, len(objects), arr))
+
+    def BVHNode_construct(self, left, right):
+        return _chk(self.L.rt_object_bvh_node(self.h, left, right))
+
+    def BVHNode_new(self, objects, bvh_seed=1):
+        arr = (C.c_int * len(objects))(*objects)
+        return _chk(self.L.rt_object_bvh_build(self.h, len(objects), arr, int(bvh_seed)))
+
+    def bounding_box(self, obj):
+        out = (C.c_double * 6)()
+        _chk(self.L.rt_object_bounding_box(self.h, obj, out))
+        return np.array(out[:])
+
+    # --- World::new / commit ---
+    def new(self, hitable_list, bvh_seed=1):
+        """World::new (world.rs:15-25): root = BVHNode::new(hitable_list); then commit."""
+        arr = (C.c_int * len(hitable_list))(*hitable_list)
+        _chk(self.L.rt_world_new(self.h, len(hitable_list), arr, int(bvh_seed)))
+        return self.commit()
+
+    def set_root(self, obj):
+        _chk(self.L.rt_scene_set_root(self.h, obj))
+        return self.commit()
+
+    def commit(self):
+        _chk(self.L.rt_scene_commit(self.h))
+        return self
+
+    def info(self):
+        out = rt_scene_info()
+        _chk(self.L.rt_scene_info_get(self.h, C.byref(out)))
+        return out.as_dict()
+
+    # --- the hot path ---
+    def render(self, camera, width=800, height=800, spp=256, max_depth=50, t_min=1e-3, seed=1, rank=0, world=1, spp_chunk=0,
+               kernel=0, device=-1):
+        """rt_render: linear radiance f64 [H,W,3] on the host + stats dict."""
+        p = default_params(width=width, height=height, spp=spp, max_depth=max_depth, t_min=t_min, seed=seed, rank=rank, world=world,
+                           spp_chunk=spp_chunk, kernel=kernel, device=device)
+        out = np.zeros((height, width, 3), dtype=np.float64)
+        st = rt_stats()
+        _chk(self.L.rt_render(self.h, C.byref(camera.c), C.byref(p), out.ctypes.data_as(_dp), C.byref(st)))
+        return out, st.as_dict()
+
+    def render_tiles_device(self, camera, params, d_tiles_ptr, stream_ptr=None):
+        """rt_render_tiles_device: d_tiles_ptr is a raw device pointer (e.g. torch tensor .data_ptr())."""
+        st = rt_stats()
+        _chk(self.L.rt_render_tiles_device(self.h, C.byref(camera.c), C.byref(params), C.c_void_p(d_tiles_ptr),
+                                           C.c_void_p(stream_ptr or 0), C.byref(st)))
+        return st.as_dict()
+
+    def debug_hit(self, rays, t_min=1e-3, t_max=float("inf")):
+        r = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)
+        out = np.zeros((r.shape[0], 12), dtype=np.float64)
+        _chk(self.L.rt_debug_hit_device(self.h, r.shape[0], r.ctypes.data_as(_dp), float(t_min), float(t_max), out.ctypes.data_as(_dp)))
+        return out
+
+
+def load_scene_file(path):
+    """rt_scene_load_file: returns (World, Camera) for data/<name>.json|.yaml."""
+    L = lib()
+    h = C.c_void_p()
+    cam = rt_camera()
+    _chk(L.rt_scene_load_file(os.fsencode(path), C.byref(h), C.byref(cam)))
+    return World(h), Camera.from_struct(cam)
+
+
+def select_scene(cube_obj_path, aspect_ratio=1.0, bvh_seed=1):
+    """scene.rs:114-116 select_scene(_index) == cornell_box_scene(): returns (World, Camera)."""
+    w = World()
+    cam = rt_camera()
+    _chk(w.L.rt_scene_cornell_box(w.h, os.fsencode(cube_obj_path), float(aspect_ratio), int(bvh_seed), C.byref(cam)))
+    w.commit()
+    return w, Camera.from_struct(cam)
+
+
+def tiles_owned(params):
+    return int(lib().rt_tiles_owned(C.byref(params)))
+
+
+def tiles_total(params):
+    return int(lib().rt_tiles_total(C.byref(params)))
+
+
+def assemble_frame_device(params, d_gathered_ptr, tiles_per_rank_stride, d_frame_ptr, stream_ptr=None):
+    _chk(lib().rt_assemble_frame_device(C.byref(params), C.c_void_p(d_gathered_ptr), int(tiles_per_rank_stride),
+                                        C.c_void_p(d_frame_ptr), C.c_void_p(stream_ptr or 0)))
+
+
+def tonemap_u8(rgb):
+    a = np.ascontiguousarray(rgb, dtype=np.float64)
+    out = np.zeros(a.shape, dtype=np.uint8)
+    _chk(lib().rt_tonemap_u8(a.ctypes.data_as(_dp), a.size, out.ctypes.data_as(C.POINTER(C.c_uint8))))
+    return out
+
+
+def write_png(path, rgb_u8):
+    a = np.ascontiguousarray(rgb_u8, dtype=np.uint8)
+    _chk(lib().rt_write_png(os.fsencode(path), a.shape[1], a.shape[0], a.ctypes.data_as(C.POINTER(C.c_uint8))))
+
+
+def debug_rng(seed, pixel, sample, n, device=True):
+    out = (C.c_uint64 * n)()
+    fn = lib().rt_debug_rng_device if device else lib().rt_debug_rng_host
+    _chk(fn(int(seed), int(pixel), int(sample), n, out))
+    return [int(x) for x in out]
+
+
+def debug_math(op, a, b=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    out = np.zeros_like(a)
+    bp = None
+    if b is not None:
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        bp = b.ctypes.data_as(_dp)
+    _chk(lib().rt_debug_math_device(op, a.size, a.ctypes.data_as(_dp), bp, out.ctypes.data_as(_dp)))
+    return out
