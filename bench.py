@@ -33,13 +33,16 @@ SCENE = os.path.join(ROOT, "tests", "golden", "scenes", "scene_500.json")
 ALG_BYTES = os.path.join(ROOT, "tests", "golden", "alg_bytes_scene_500.json")
 TRAFFIC = os.path.join(ROOT, "profiles", "hbm_traffic.json")
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+CPU_BASELINE_THREADS = 16
 
 
 def cpu_baseline(width, height, spp_cpu, seed):
     """Oracle timed on the host cores (test infrastructure used as the reported CPU baseline)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle
-    cores = os.cpu_count() or 1
+    # the GPU box gives one GPU's share of the host (16 threads, see the task's process guard); never more
+    # threads than that even though the host shows 256
+    cores = min(len(os.sched_getaffinity(0)), CPU_BASELINE_THREADS)
     sc = oracle.load_scene_file(SCENE)
     t0 = time.perf_counter()
     _, cnt = sc.render(width, height, spp_cpu, seed=seed, n_jobs=64, n_workers=cores)
@@ -60,7 +63,7 @@ def main():
     ap.add_argument("--height", type=int, default=1200)
     ap.add_argument("--spp", type=int, default=1000)
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--cpu-spp", type=int, default=4, help="spp of the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-spp", type=int, default=12, help="spp of the bounded CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -82,10 +85,12 @@ def main():
     world, cam = rtamd.load_scene_file(SCENE)
     params = rtamd.default_params(width=args.width, height=args.height, spp=args.spp, max_depth=50, t_min=1e-3, seed=args.seed,
                                   rank=rank, world=world_size)
+    from rtamd.distributed import TileLayout, gather_tiles
+    layout = TileLayout(args.width, args.height, world_size)
     p0 = rtamd.default_params(width=args.width, height=args.height, spp=args.spp, rank=0, world=world_size)
-    stride = rtamd.tiles_owned(p0)  # rank 0 owns the most tiles; every rank pads to it for the gather
+    stride = layout.stride  # rank 0 owns the most tiles; every rank pads to it for the gather
+    assert stride == rtamd.tiles_owned(p0)
     d_tiles = torch.zeros(stride * 64 * 3, dtype=torch.float64, device=dev)
-    gathered = torch.zeros(world_size * stride * 64 * 3, dtype=torch.float64, device=dev) if rank == 0 else None
     frame = torch.zeros(args.height * args.width * 3, dtype=torch.float64, device=dev) if rank == 0 else None
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -94,13 +99,8 @@ def main():
 
     def step(timed):
         st = world.render_tiles_device(cam, params, d_tiles.data_ptr(), stream)
-        if world_size > 1:
-            # the stitch of camera.rs:115-123 across GPUs: framebuffer gather to rank 0 over RCCL/xGMI
-            glist = list(gathered.chunk(world_size)) if rank == 0 else None
-            dist.gather(d_tiles, glist, dst=0)
-            src = gathered
-        else:
-            src = d_tiles
+        # the stitch of camera.rs:115-123 across GPUs: ONE framebuffer gather to rank 0 over RCCL/xGMI
+        src = gather_tiles(d_tiles, layout, rank, dist, dst=0)
         if rank == 0:
             rtamd.assemble_frame_device(p0, src.data_ptr(), stride, frame.data_ptr(), stream)
         if timed:
@@ -142,7 +142,9 @@ def main():
         traffic = None
         if os.path.exists(TRAFFIC):
             with open(TRAFFIC) as f:
-                traffic = json.load(f).get("hbm_bytes_per_launch")
+                per_sample = json.load(f).get("hbm_bytes_per_sample")
+                if per_sample is not None:  # PMC-measured (profiles/), scaled to this run's launch size
+                    traffic = per_sample * samples_per_launch
         out = {
             "metric": "Msamples/sec (px*spp), scene_500 %dx%d %dspp" % (args.width, args.height, args.spp),
             "value": value, "unit": "Msamples/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,

@@ -273,12 +273,29 @@ struct Yaml {
             return scalar(token(",}]"));
         }
     };
-    Value inline_value(const std::string& s, int ln) {
-        if (!s.empty() && (s[0] == '{' || s[0] == '[')) {
+    static int flow_balance(const std::string& s) {
+        int depth = 0;
+        bool sq = false, dq = false;
+        for (char c : s) {
+            if (c == '\'' && !dq) sq = !sq;
+            else if (c == '"' && !sq) dq = !dq;
+            else if (!sq && !dq && (c == '{' || c == '[')) depth++;
+            else if (!sq && !dq && (c == '}' || c == ']')) depth--;
+        }
+        return depth;
+    }
+    // `i` must already point past the line `s` came from: a flow collection may continue on following lines
+    Value inline_value(const std::string& s0, int ln) {
+        if (!s0.empty() && (s0[0] == '{' || s0[0] == '[')) {
+            std::string s = s0;
+            while (flow_balance(s) > 0 && i < lines.size()) {
+                s += " " + lines[i].text;
+                i++;
+            }
             Flow f{s, 0, ln, this};
             return f.value();
         }
-        return scalar(s);
+        return scalar(s0);
     }
     // split "key: rest" ; returns false if the text is not a mapping entry
     static bool split_key(const std::string& t, std::string& key, std::string& rest) {
@@ -307,9 +324,10 @@ struct Yaml {
         if (first.text[0] == '-' && (first.text.size() == 1 || first.text[1] == ' ')) return sequence(indent, depth);
         std::string k, r;
         if (split_key(first.text, k, r)) return mapping(indent, depth);
-        Value v = inline_value(first.text, first.lineno);
+        const std::string text = first.text;
+        const int lineno = first.lineno;
         i++;
-        return v;
+        return inline_value(text, lineno);
     }
     Value mapping(int indent, int depth) {
         Value v;

@@ -1,0 +1,91 @@
+"""The C-ABI library loads on a GPU-less box and exports every symbol include/rtamd.h declares;
+host-only entry points work without a device and the render entry points fail loudly."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, scene_path
+
+HEADER = os.path.join(ROOT, "include", "rtamd.h")
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    import rtamd
+    assert sorted(rtamd.ABI_SYMBOLS) == declared_symbols()
+
+
+def test_library_exports_every_declared_symbol():
+    import rtamd
+    L = ctypes.CDLL(rtamd.LIB_PATH)
+    for name in declared_symbols():
+        assert hasattr(L, name), "librtamd.so does not export %s" % name
+    assert rtamd.lib().rt_abi_version() == 1
+
+
+def test_struct_layouts_match_header_sizes():
+    import rtamd
+    assert ctypes.sizeof(rtamd.rt_camera) == 13 * 8
+    assert ctypes.sizeof(rtamd.rt_params) == 4 * 4 + 8 + 8 + 6 * 4
+    assert ctypes.sizeof(rtamd.rt_stats) == 3 * 8 + 8 + 6 * 4 + 8 + 4 * 8
+    p = rtamd.default_params()
+    assert (p.width, p.height, p.spp, p.max_depth, p.t_min, p.world) == (800, 800, 256, 50, 0.001, 1)   # main.rs:34-45, camera.rs:73
+
+
+def test_no_cpu_fallback_without_a_device():
+    import rtamd
+    if rtamd.device_count() > 0:
+        pytest.skip("a HIP device is present")
+    world, cam = rtamd.load_scene_file(scene_path("scene_10.json"))
+    with pytest.raises(rtamd.RtError) as e:
+        world.render(cam, width=8, height=8, spp=1)
+    assert e.value.code == -9   # RT_ERR_NO_DEVICE
+    with pytest.raises(rtamd.RtError):
+        rtamd.debug_rng(1, 0, 0, 4, device=True)
+
+
+def test_product_never_touches_the_oracle():
+    """the product tree must not import, link or open anything under oracle/ (checker != product)."""
+    pkg = os.path.join(ROOT, "rust-raytracer_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".cpp", ".h", ".hip", ".hpp", ".rs", "Makefile")):
+                text = open(os.path.join(dirpath, fn), errors="replace").read()
+                assert "librt_oracle" not in text and "import oracle" not in text and "oracle/" not in text.replace("test oracle", ""), \
+                    "%s references the oracle" % os.path.join(dirpath, fn)
+
+
+def test_host_rng_matches_oracle_spec():
+    import oracle
+    import rtamd
+    for key in [(1, 0, 0), (42, 1439999, 999), (2**63 + 5, 2**40, 3)]:
+        assert rtamd.debug_rng(*key, 32, device=False) == oracle.rng_u64(*key, 32)
+
+
+def test_rng_golden_vector():
+    """tests/golden/rng_kat.json pins spec rtamd-rng-1 for both restatements."""
+    import json
+    import oracle
+    import rtamd
+    kat = json.load(open(os.path.join(ROOT, "tests", "golden", "rng_kat.json")))
+    for case in kat["cases"]:
+        key = (case["seed"], case["pixel"], case["sample"])
+        exp = [int(x, 16) for x in case["u64_hex"]]
+        assert oracle.rng_u64(*key, len(exp)) == exp
+        assert rtamd.debug_rng(*key, len(exp), device=False) == exp
+        assert oracle.rng_f64(*key, 2) == case["f64_first2"]
+
+
+def test_tonemap_host_matches_oracle():
+    import oracle
+    import rtamd
+    x = np.concatenate([np.linspace(-0.5, 1.5, 4001), [np.nan, np.inf, -np.inf, 0.0, 1.0, (254.9999 / 255) ** 2]])
+    assert np.array_equal(rtamd.tonemap_u8(x), oracle.tonemap_u8(x))

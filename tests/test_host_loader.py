@@ -1,0 +1,157 @@
+"""Host-side scene front end (no GPU): file loaders (JSON, YAML), OBJ reader, builders, bounding
+boxes and the flattener, cross-checked against the oracle's independent Python loaders."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import scene_path
+
+
+def test_scene_file_counts():
+    import rtamd
+    exp = {"scene_10.json": (25, 19), "scene_10.yaml": (25, 19), "scene_200_no_bvh.json": (405, 0), "scene_500.json": (1005, 999)}
+    for name, (ns, nb) in exp.items():
+        w, cam = rtamd.load_scene_file(scene_path(name))
+        info = w.info()
+        assert (info["n_spheres"], info["n_boxes"]) == (ns, nb), name
+        assert info["n_nodes"] == ns + nb and info["committed"] == 1
+        assert tuple(cam.c.look_from) == (-6.0, 2.0, -6.0) and cam.c.vfov == 45.0 and cam.c.focus_dist == 8.062258
+
+
+def test_yaml_and_json_flatten_identically(tmp_path):
+    import rtamd
+    a, _ = rtamd.load_scene_file(scene_path("scene_10.json"))
+    b, _ = rtamd.load_scene_file(scene_path("scene_10.yaml"))
+    assert a.info() == b.info()
+    # pretty-printed JSON (the reference's own formatting) and flow-style YAML parse to the same scene
+    doc = json.load(open(scene_path("scene_10.json")))
+    p = tmp_path / "pretty.json"
+    p.write_text(json.dumps(doc, indent=4))
+    c, _ = rtamd.load_scene_file(str(p))
+    assert c.info() == a.info()
+    import yaml
+    q = tmp_path / "flow.yaml"
+    q.write_text(yaml.safe_dump(doc, default_flow_style=True))
+    d, _ = rtamd.load_scene_file(str(q))
+    assert d.info() == a.info()
+
+
+def test_loader_errors():
+    import rtamd
+    with pytest.raises(rtamd.RtError) as e:
+        rtamd.load_scene_file(scene_path("test.json"))      # older schema: Sphere without material
+    assert e.value.code == -6
+    with pytest.raises(rtamd.RtError) as e:
+        rtamd.load_scene_file(scene_path("does_not_exist.json"))
+    assert e.value.code == -5
+
+
+@pytest.mark.parametrize("bad", ['{"objects": {"type": "Blob"}, "camera": {}}', '{"objects": {"type": "Sphere"}}', "[1,2", '{"camera": {}}'])
+def test_malformed_scene_files(tmp_path, bad):
+    import rtamd
+    p = tmp_path / "bad.json"
+    p.write_text(bad)
+    with pytest.raises(rtamd.RtError) as e:
+        rtamd.load_scene_file(str(p))
+    assert e.value.code == -6
+
+
+def test_builders_and_bounding_boxes_match_oracle():
+    import oracle
+    import rtamd
+    w, o = rtamd.World(), oracle.Scene()
+    mw = w.Lambertian(w.ConstantTexture((0.5, 0.5, 0.5)))
+    mo = o.Lambertian(o.ConstantTexture((0.5, 0.5, 0.5)))
+    pairs = [
+        (w.Sphere((1, 2, 3), 0.5, mw), o.Sphere((1, 2, 3), 0.5, mo)),
+        (w.XYRectangle((0, 1), (2, 3), 4, mw), o.XYRectangle((0, 1), (2, 3), 4, mo)),
+        (w.XZRectangle((0, 1), (2, 3), 4, mw), o.XZRectangle((0, 1), (2, 3), 4, mo)),
+        (w.YZRectangle((0, 1), (2, 3), 4, mw), o.YZRectangle((0, 1), (2, 3), 4, mo)),
+        (w.Cube((0, 0, 0), (1, 2, 3), mw), o.Cube((0, 0, 0), (1, 2, 3), mo)),
+    ]
+    P, N, I = oracle.load_obj(scene_path("cube.obj"))
+    mesh_w, mesh_o = w.Mesh(P, N, I, mw, bvh_seed=7), o.Mesh(P, N, I, mo, 7)
+    pairs.append((mesh_w, mesh_o))
+    pairs.append((w.Transform((10, 20, 30), (2, 3, 4), (5, 6, 7), mesh_w), o.Transform((10, 20, 30), (2, 3, 4), (5, 6, 7), mesh_o)))
+    pairs.append((w.HitableList([p[0] for p in pairs[:3]]), o.HitableList([p[1] for p in pairs[:3]])))
+    pairs.append((w.BVHNode_construct(pairs[0][0], pairs[4][0]), o.BVHNode_construct(pairs[0][1], pairs[4][1])))
+    pairs.append((w.BVHNode_new([p[0] for p in pairs[:5]], bvh_seed=3), o.BVHNode_new([p[1] for p in pairs[:5]], 3)))
+    for a, b in pairs:
+        assert np.array_equal(w.bounding_box(a), o.bounding_box(b))
+
+
+def test_obj_reader_matches_tobj_semantics():
+    import oracle
+    import rtamd
+    w = rtamd.World()
+    m = w.Lambertian(w.ConstantTexture((1, 1, 1)))
+    mesh = w.Mesh_load_obj(scene_path("cube.obj"), m)
+    w.set_root(mesh)
+    info = w.info()
+    P, N, I = oracle.load_obj(scene_path("cube.obj"))
+    assert info["n_tris"] == 12 == len(I) and info["n_verts"] == len(P) == 24   # single_index: one vertex per (v,vt,vn) triple
+    assert np.allclose(np.linalg.norm(N, axis=1), 1.0)
+    # f32 coordinates widened to f64 (mesh.rs:160-172)
+    assert float(np.float32(-0.999999)) in P[:, 2]
+
+
+def test_mesh_without_normals_is_an_error_unless_synthesized():
+    import oracle
+    import rtamd
+    w = rtamd.World()
+    m = w.Lambertian(w.ConstantTexture((1, 1, 1)))
+    with pytest.raises(rtamd.RtError) as e:
+        w.Mesh_load_obj(scene_path("bun315.obj"), m)          # the reference would panic at mesh.rs:62
+    assert e.value.code == -7
+    mesh = w.Mesh_load_obj(scene_path("bun315.obj"), m, synthesize_normals=True)
+    w.set_root(mesh)
+    assert w.info()["n_tris"] == 4968
+    P, N, I = oracle.load_obj(scene_path("bun315.obj"))
+    assert N is None and len(I) == 4968 and len(P) == 2503
+
+
+def test_error_codes_of_builders():
+    import rtamd
+    w = rtamd.World()
+    m = w.Lambertian(w.ConstantTexture((1, 1, 1)))
+    s = w.Sphere((0, 0, 0), 1, m)
+    with pytest.raises(rtamd.RtError) as e:
+        w.Sphere((0, 0, 0), 1, 99)
+    assert e.value.code == -1
+    with pytest.raises(rtamd.RtError) as e:
+        w.Transform((0, 0, 0), (0, 1, 1), (0, 0, 0), s)       # singular: "Invalid transform matrix" (transform.rs:146)
+    assert e.value.code == -4
+    empty = w.HitableList([])
+    with pytest.raises(rtamd.RtError) as e:
+        w.BVHNode_construct(s, empty)                          # "No bounding box in bvh_node constructor." (bvh.rs:57)
+    assert e.value.code == -3
+    with pytest.raises(rtamd.RtError) as e:
+        w.CheckerTexture(w.ConstantTexture((1, 1, 1)), w.CheckerTexture(w.ConstantTexture((0, 0, 0)), w.ConstantTexture((1, 1, 1))))
+    assert e.value.code == -1
+    w.set_root(s)
+    with pytest.raises(rtamd.RtError):
+        w.Sphere((0, 0, 0), 1, m)                              # immutable after commit
+    with pytest.raises(rtamd.RtError) as e:
+        rtamd.Camera(((0, 0, 0), (0, 0, 0)), (0, 1, 0), 40, 1, 0, 1).capture_image(w, 8, 8, 1)
+    assert e.value.code in (-2, -9)                            # zero-length view vector, or no device on a CPU box
+
+
+def test_cornell_box_scene_structure():
+    import rtamd
+    w, cam = rtamd.select_scene(scene_path("cube.obj"))
+    info = w.info()
+    # scene.rs:16-112: 5 walls + light + 6 cube sides = 12 rects, 2 spheres, 12 mesh triangles in one Transform
+    assert (info["n_rects"], info["n_spheres"], info["n_tris"], info["n_xforms"]) == (12, 2, 12, 1)
+    assert tuple(cam.c.look_from) == (278.0, 278.0, -800.0) and cam.c.vfov == 50.0 and cam.c.aperture == 0.0
+
+
+def test_png_writer(tmp_path):
+    import rtamd
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, size=(37, 301, 3), dtype=np.uint8)     # > 64 KiB raw: several stored deflate blocks
+    p = str(tmp_path / "x.png")
+    rtamd.write_png(p, img)
+    assert np.array_equal(np.asarray(Image.open(p)), img)
