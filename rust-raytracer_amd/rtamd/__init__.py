@@ -113,11 +113,35 @@ _SIGS = [
 ABI_SYMBOLS = [s[0] for s in _SIGS]
 
 
+def _share_hip_runtime_with_torch():
+    """One process must hold ONE HIP/HSA runtime.  PyTorch-ROCm bundles its own libamdhip64.so.7 (same SONAME
+    as /opt/rocm's): whichever is loaded first serves both.  If torch is installed but not imported yet, load
+    ITS runtime first so that a later `import torch` in the same process (bench.py, the tests) does not bring
+    up a second HSA runtime and report "No HIP GPUs are available".  RTAMD_HIP_RUNTIME=system skips this."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("RTAMD_HIP_RUNTIME", "") == "system":
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     """Load librtamd.so.  Raises (never falls back) when the HIP extension has not been built."""
     global _LIB
     if _LIB is not None:
         return _LIB
+    _share_hip_runtime_with_torch()
     if not os.path.exists(LIB_PATH):
         raise ImportError("librtamd.so is missing at %s -- run `make -C rust-raytracer_amd` (or __graft_entry__.build()); "
                           "there is no CPU fallback" % LIB_PATH)
