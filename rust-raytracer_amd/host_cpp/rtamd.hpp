@@ -1,0 +1,377 @@
+// rtamd.hpp -- C++ host side ABOVE the C ABI (include/rtamd.h), mirroring the reference's Rust
+// interface for the radiance path: same type names, constructor arguments and error behaviour
+// (a Rust panic becomes a C++ exception carrying the rt_status).
+//
+// The host owns an object graph exactly like the reference's (Arc<dyn Hitable> -> shared_ptr<Hitable>,
+// Arc<dyn Material>, Texture); World::World walks it ONCE and emits it through the rt_* builders --
+// the same walk a Rust `impl` over the reference's traits performs.
+// Nothing here intersects rays: Camera::capture_image is rt_render.
+//   raytracer/src/vec3.rs        -> Vec3, RgbImage conversion
+//   raytracer/src/material.rs    -> Texture / Material types
+//   raytracer/src/objects/*.rs   -> Hitable types
+//   raytracer/src/world.rs       -> World
+//   raytracer/src/camera.rs      -> Camera
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "rtamd.h"
+
+namespace rtamd_host {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+inline int check(int rc) {
+    if (rc < 0) throw Error(rc, rt_last_error());
+    return rc;
+}
+
+// vec3.rs:14-19 (operators: `*` between two Vec3 is the DOT product, vec3.rs:335-341)
+struct Vec3 {
+    double x = 0, y = 0, z = 0;
+    Vec3() {}
+    Vec3(double a, double b, double c) : x(a), y(b), z(c) {}
+    static Vec3 ones() { return Vec3(1, 1, 1); }
+    static Vec3 zero() { return Vec3(0, 0, 0); }
+    static Vec3 all(double v) { return Vec3(v, v, v); }
+    double squared_length() const { return x * x + y * y + z * z; }
+    double length() const { return std::sqrt(squared_length()); }
+    Vec3 unit() const {
+        double l = length();
+        if (l == 0.) throw Error(RT_ERR_UNIT_ZERO, "unitizing zero vector");
+        return Vec3(x / l, y / l, z / l);
+    }
+    static Vec3 elemul(Vec3 a, Vec3 b) { return Vec3(a.x * b.x, a.y * b.y, a.z * b.z); }
+    static Vec3 cross(Vec3 a, Vec3 b) { return Vec3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+    const double* data() const { return &x; }
+};
+inline Vec3 operator+(Vec3 a, Vec3 b) { return Vec3(a.x + b.x, a.y + b.y, a.z + b.z); }
+inline Vec3 operator+(Vec3 a, double s) { return Vec3(a.x + s, a.y + s, a.z + s); }
+inline Vec3 operator-(Vec3 a, Vec3 b) { return Vec3(a.x - b.x, a.y - b.y, a.z - b.z); }
+inline Vec3 operator-(Vec3 a, double s) { return Vec3(a.x - s, a.y - s, a.z - s); }
+inline Vec3 operator-(Vec3 a) { return Vec3(-a.x, -a.y, -a.z); }
+inline double operator*(Vec3 a, Vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline Vec3 operator*(Vec3 a, double s) { return Vec3(a.x * s, a.y * s, a.z * s); }
+inline Vec3 operator*(double s, Vec3 a) { return Vec3(a.x * s, a.y * s, a.z * s); }
+inline Vec3 operator/(Vec3 a, double s) { return Vec3(a.x / s, a.y / s, a.z / s); }
+inline bool operator==(Vec3 a, Vec3 b) { return a.x == b.x && a.y == b.y && a.z == b.z; }
+
+class Emitter;  // the walk that lowers the graph onto the C ABI
+
+// material.rs:18-20, 48-84
+struct Texture {
+    virtual ~Texture() {}
+    virtual int emit(Emitter& e) const = 0;
+};
+struct ConstantTexture : Texture {
+    Vec3 color;
+    explicit ConstantTexture(Vec3 c) : color(c) {}
+    int emit(Emitter& e) const override;
+};
+struct CheckerTexture : Texture {
+    ConstantTexture t0, t1;
+    CheckerTexture(ConstantTexture a, ConstantTexture b) : t0(a), t1(b) {}
+    int emit(Emitter& e) const override;
+};
+struct ImageTexture : Texture {
+    int width, height;
+    std::vector<uint8_t> rgb;
+    ImageTexture(int w, int h, std::vector<uint8_t> px) : width(w), height(h), rgb(std::move(px)) {}
+    int emit(Emitter& e) const override;
+};
+// material.rs:21-46, 88-212
+struct Material {
+    virtual ~Material() {}
+    virtual int emit(Emitter& e) const = 0;
+};
+using TexturePtr = std::shared_ptr<const Texture>;
+using MaterialPtr = std::shared_ptr<const Material>;
+struct Lambertian : Material {
+    TexturePtr albedo;
+    explicit Lambertian(TexturePtr a) : albedo(std::move(a)) {}
+    int emit(Emitter& e) const override;
+};
+struct Metal : Material {
+    TexturePtr albedo;
+    double fuzz;
+    Metal(TexturePtr a, double f) : albedo(std::move(a)), fuzz(f) {}
+    int emit(Emitter& e) const override;
+};
+struct Dielectric : Material {
+    double ir;
+    TexturePtr albedo;
+    Dielectric(double i, TexturePtr a) : ir(i), albedo(std::move(a)) {}
+    int emit(Emitter& e) const override;
+};
+struct DiffuseLight : Material {
+    TexturePtr emit_tex;
+    explicit DiffuseLight(TexturePtr t) : emit_tex(std::move(t)) {}
+    int emit(Emitter& e) const override;
+};
+
+// objects/hit.rs:51-54
+struct Hitable {
+    virtual ~Hitable() {}
+    virtual int emit(Emitter& e) const = 0;
+};
+using HitablePtr = std::shared_ptr<const Hitable>;
+using HitableList = std::vector<HitablePtr>;  // impl Hitable for Vec<Arc<dyn Hitable>>, hit.rs:56
+
+struct Sphere : Hitable {  // sphere.rs:9-13
+    Vec3 center;
+    double radius;
+    MaterialPtr material;
+    Sphere(Vec3 c, double r, MaterialPtr m) : center(c), radius(r), material(std::move(m)) {}
+    int emit(Emitter& e) const override;
+};
+struct XYRectangle : Hitable {  // rectangle.rs:7-12
+    std::pair<double, double> xy0, xy1;
+    double z;
+    MaterialPtr material;
+    XYRectangle(std::pair<double, double> a, std::pair<double, double> b, double k, MaterialPtr m) : xy0(a), xy1(b), z(k), material(std::move(m)) {}
+    int emit(Emitter& e) const override;
+};
+struct XZRectangle : Hitable {  // rectangle.rs:44-49
+    std::pair<double, double> xz0, xz1;
+    double y;
+    MaterialPtr material;
+    XZRectangle(std::pair<double, double> a, std::pair<double, double> b, double k, MaterialPtr m) : xz0(a), xz1(b), y(k), material(std::move(m)) {}
+    int emit(Emitter& e) const override;
+};
+struct YZRectangle : Hitable {  // rectangle.rs:82-87
+    std::pair<double, double> yz0, yz1;
+    double x;
+    MaterialPtr material;
+    YZRectangle(std::pair<double, double> a, std::pair<double, double> b, double k, MaterialPtr m) : yz0(a), yz1(b), x(k), material(std::move(m)) {}
+    int emit(Emitter& e) const override;
+};
+struct Cube : Hitable {  // cube.rs:9-62
+    Vec3 box_min, box_max;
+    MaterialPtr material;
+    Cube(Vec3 mn, Vec3 mx, MaterialPtr m) : box_min(mn), box_max(mx), material(std::move(m)) {}
+    int emit(Emitter& e) const override;
+};
+struct List : Hitable {  // a Vec<Arc<dyn Hitable>> used as a Hitable
+    HitableList items;
+    explicit List(HitableList l) : items(std::move(l)) {}
+    int emit(Emitter& e) const override;
+};
+struct BVHNode : Hitable {  // bvh.rs:29-83
+    HitablePtr left, right;   // BVHNode::construct
+    HitableList src_objects;  // BVHNode::new (when left/right are null)
+    static std::shared_ptr<BVHNode> construct(HitablePtr l, HitablePtr r) {
+        auto n = std::make_shared<BVHNode>();
+        n->left = std::move(l);
+        n->right = std::move(r);
+        return n;
+    }
+    static std::shared_ptr<BVHNode> new_(HitableList objs) {
+        auto n = std::make_shared<BVHNode>();
+        n->src_objects = std::move(objs);
+        return n;
+    }
+    int emit(Emitter& e) const override;
+};
+struct Mesh : Hitable {  // mesh.rs:144-198
+    std::string obj_file;
+    MaterialPtr material;
+    bool synthesize_normals = false;
+    static std::shared_ptr<Mesh> load_obj(std::string file, MaterialPtr m, bool synth = false) {
+        auto me = std::make_shared<Mesh>();
+        me->obj_file = std::move(file);
+        me->material = std::move(m);
+        me->synthesize_normals = synth;
+        return me;
+    }
+    int emit(Emitter& e) const override;
+};
+struct Transform : Hitable {  // transform.rs:17-22
+    Vec3 rotate_in_degree, scale, translate;
+    HitablePtr obj;
+    Transform(Vec3 r, Vec3 s, Vec3 t, HitablePtr o) : rotate_in_degree(r), scale(s), translate(t), obj(std::move(o)) {}
+    int emit(Emitter& e) const override;
+};
+struct XZRectLight : Hitable {  // light.rs:127-146 (as a Hitable; `scale` only feeds SPPM photon power)
+    std::pair<double, double> xz0, xz1;
+    double y;
+    Vec3 flux;
+    double scale;
+    XZRectLight(std::pair<double, double> a, std::pair<double, double> b, double k, Vec3 f, double s) : xz0(a), xz1(b), y(k), flux(f), scale(s) {}
+    int emit(Emitter& e) const override;
+};
+struct SphereDiffuseLight : Hitable {  // light.rs:67-86
+    Vec3 center;
+    double radius;
+    Vec3 flux;
+    double scale;
+    SphereDiffuseLight(Vec3 c, double r, Vec3 f, double s) : center(c), radius(r), flux(f), scale(s) {}
+    int emit(Emitter& e) const override;
+};
+
+class Emitter {
+   public:
+    rt_scene* s;
+    uint64_t bvh_seed;
+    std::map<const void*, int> seen;  // shared nodes (Arc clones) are emitted once
+    Emitter(rt_scene* sc, uint64_t seed) : s(sc), bvh_seed(seed) {}
+    template <class T>
+    int once(const T* node) {
+        auto it = seen.find(node);
+        if (it != seen.end()) return it->second;
+        int id = node->emit(*this);
+        seen[node] = id;
+        return id;
+    }
+};
+inline int ConstantTexture::emit(Emitter& e) const { return check(rt_texture_constant(e.s, color.data())); }
+inline int CheckerTexture::emit(Emitter& e) const { return check(rt_texture_checker(e.s, t0.emit(e), t1.emit(e))); }
+inline int ImageTexture::emit(Emitter& e) const { return check(rt_texture_image(e.s, width, height, rgb.data())); }
+inline int Lambertian::emit(Emitter& e) const { return check(rt_material_lambertian(e.s, e.once(albedo.get()))); }
+inline int Metal::emit(Emitter& e) const { return check(rt_material_metal(e.s, e.once(albedo.get()), fuzz)); }
+inline int Dielectric::emit(Emitter& e) const { return check(rt_material_dielectric(e.s, ir, e.once(albedo.get()))); }
+inline int DiffuseLight::emit(Emitter& e) const { return check(rt_material_diffuse_light(e.s, e.once(emit_tex.get()))); }
+inline int Sphere::emit(Emitter& e) const { return check(rt_object_sphere(e.s, center.data(), radius, e.once(material.get()))); }
+inline int XYRectangle::emit(Emitter& e) const {
+    return check(rt_object_rect_xy(e.s, xy0.first, xy0.second, xy1.first, xy1.second, z, e.once(material.get())));
+}
+inline int XZRectangle::emit(Emitter& e) const {
+    return check(rt_object_rect_xz(e.s, xz0.first, xz0.second, xz1.first, xz1.second, y, e.once(material.get())));
+}
+inline int YZRectangle::emit(Emitter& e) const {
+    return check(rt_object_rect_yz(e.s, yz0.first, yz0.second, yz1.first, yz1.second, x, e.once(material.get())));
+}
+inline int Cube::emit(Emitter& e) const { return check(rt_object_cube(e.s, box_min.data(), box_max.data(), e.once(material.get()))); }
+inline int List::emit(Emitter& e) const {
+    std::vector<int> ids;
+    for (auto& h : items) ids.push_back(e.once(h.get()));
+    return check(rt_object_list(e.s, (int)ids.size(), ids.data()));
+}
+inline int BVHNode::emit(Emitter& e) const {
+    if (left && right) return check(rt_object_bvh_node(e.s, e.once(left.get()), e.once(right.get())));
+    std::vector<int> ids;
+    for (auto& h : src_objects) ids.push_back(e.once(h.get()));
+    return check(rt_object_bvh_build(e.s, (int)ids.size(), ids.data(), e.bvh_seed));
+}
+inline int Mesh::emit(Emitter& e) const {
+    return check(rt_object_mesh_obj(e.s, obj_file.c_str(), e.once(material.get()), synthesize_normals ? 1 : 0, e.bvh_seed));
+}
+inline int Transform::emit(Emitter& e) const {
+    return check(rt_object_transform(e.s, rotate_in_degree.data(), scale.data(), translate.data(), e.once(obj.get())));
+}
+inline int XZRectLight::emit(Emitter& e) const {
+    return check(rt_object_xz_rect_light(e.s, xz0.first, xz0.second, xz1.first, xz1.second, y, flux.data()));
+}
+inline int SphereDiffuseLight::emit(Emitter& e) const { return check(rt_object_sphere_light(e.s, center.data(), radius, flux.data())); }
+
+// image::RgbImage stand-in (camera.rs:88,114)
+struct RgbImage {
+    int width = 0, height = 0;
+    std::vector<uint8_t> data;  // row-major RGB8
+    void save(const std::string& path) const { check(rt_write_png(path.c_str(), width, height, data.data())); }
+};
+
+// camera.rs:11-64
+struct Camera {
+    rt_camera c{};
+    Camera() {}
+    Camera(std::pair<Vec3, Vec3> look_from_to, Vec3 vup, double vfov, double aspect_ratio, double aperture, double focus_dist) {
+        for (int i = 0; i < 3; i++) {
+            c.look_from[i] = look_from_to.first.data()[i];
+            c.look_at[i] = look_from_to.second.data()[i];
+            c.vup[i] = vup.data()[i];
+        }
+        c.vfov = vfov;
+        c.aspect = aspect_ratio;
+        c.aperture = aperture;
+        c.focus_dist = focus_dist;
+    }
+};
+
+// main.rs:26-47 GlobalConfig + the constants capture_image / sample_ray hard-code
+struct Config {
+    int width = 800, height = 800;  // main.rs:34-45
+    int sample_per_pixel = 256;     // camera.rs:73
+    int max_depth = 50;             // photon_mapper.rs:334
+    double t_min = 0.001;           // photon_mapper.rs:335
+    uint64_t seed = 1;
+};
+
+// world.rs:8-30.  World::new(hitable_list, cam, lights): root = BVHNode::new(hitable_list).
+class World {
+   public:
+    Camera cam;
+    World(const HitableList& hitable_list, Camera camera, uint64_t bvh_seed = 1) : cam(camera) {
+        check(rt_scene_create(&s_));
+        try {
+            Emitter e(s_, bvh_seed);
+            std::vector<int> ids;
+            for (auto& h : hitable_list) ids.push_back(e.once(h.get()));
+            check(rt_world_new(s_, (int)ids.size(), ids.data(), bvh_seed));
+            check(rt_scene_commit(s_));
+        } catch (...) {
+            rt_scene_destroy(s_);
+            throw;
+        }
+    }
+    // a scene file of the reference's data/ directory (README.md Track 5)
+    explicit World(const std::string& scene_file) {
+        check(rt_scene_load_file(scene_file.c_str(), &s_, &cam.c));
+    }
+    ~World() { rt_scene_destroy(s_); }
+    World(const World&) = delete;
+    World& operator=(const World&) = delete;
+    const rt_scene* handle() const { return s_; }
+
+    // Camera::capture_image (camera.rs:66-128): radiance via the HIP path, then From<Vec3> for Rgb<u8>
+    RgbImage capture_image(const Config& cfg = Config(), rt_stats* stats = nullptr, std::vector<double>* radiance = nullptr) const {
+        rt_params p;
+        rt_default_params(&p);
+        p.width = cfg.width; p.height = cfg.height; p.spp = cfg.sample_per_pixel; p.max_depth = cfg.max_depth;
+        p.t_min = cfg.t_min; p.seed = cfg.seed;
+        std::vector<double> rad((size_t)cfg.width * cfg.height * 3);
+        check(rt_render(s_, &cam.c, &p, rad.data(), stats));
+        RgbImage img;
+        img.width = cfg.width;
+        img.height = cfg.height;
+        img.data.resize(rad.size());
+        check(rt_tonemap_u8(rad.data(), rad.size(), img.data.data()));
+        if (radiance) *radiance = std::move(rad);
+        return img;
+    }
+
+   private:
+    rt_scene* s_ = nullptr;
+};
+
+// scene.rs:16-112 cornell_box_scene(), written against the mirrored types exactly as the reference writes it
+inline std::unique_ptr<World> cornell_box_scene(const std::string& cube_obj, double aspect_ratio = 1.0, uint64_t bvh_seed = 1) {
+    auto tex = [](double r, double g, double b) { return std::make_shared<ConstantTexture>(Vec3(r, g, b)); };
+    MaterialPtr red = std::make_shared<Lambertian>(tex(0.75, 0.25, 0.25));
+    MaterialPtr white = std::make_shared<Lambertian>(tex(0.75, 0.75, 0.75));
+    MaterialPtr blue = std::make_shared<Lambertian>(tex(0.25, 0.25, 0.75));
+    auto light = std::make_shared<XZRectLight>(std::make_pair(213., 227.), std::make_pair(343., 332.), 554., Vec3(1., 1., 1.), 1000000.);
+    HitableList hitable_list = {
+        std::make_shared<YZRectangle>(std::make_pair(0.0, 0.0), std::make_pair(555.0, 555.0), 555., red),
+        std::make_shared<YZRectangle>(std::make_pair(0., 0.), std::make_pair(555., 555.), 0., blue),
+        std::make_shared<XZRectangle>(std::make_pair(0., 0.), std::make_pair(555., 555.), 0., white),
+        std::make_shared<XZRectangle>(std::make_pair(0., 0.), std::make_pair(555., 555.), 555., white),
+        std::make_shared<XYRectangle>(std::make_pair(0., 0.), std::make_pair(555., 555.), 555., white),
+        std::make_shared<Sphere>(Vec3(140., 100., 240.), 100., std::make_shared<Dielectric>(1.5, tex(0.999, 0.999, 0.999))),
+        std::make_shared<Sphere>(Vec3(400., 100., 360.), 100., std::make_shared<Metal>(tex(0.999, 0.999, 0.999), 0.)),
+        light,
+        std::make_shared<Transform>(Vec3::zero(), Vec3::ones() * 50., Vec3(100., 50., 100.), Mesh::load_obj(cube_obj, white)),
+        std::make_shared<Cube>(Vec3(300., 0., 100.), Vec3(380., 100., 180.), white),
+    };
+    Camera cam({Vec3(278., 278., -800.), Vec3(278., 278., 278.)}, Vec3(0., 1., 0.), 50., aspect_ratio, 0.0, 10.0);
+    return std::make_unique<World>(hitable_list, cam, bvh_seed);
+}
+
+}  // namespace rtamd_host

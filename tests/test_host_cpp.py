@@ -1,0 +1,44 @@
+"""The C++ host side above the C ABI (rust-raytracer_amd/host_cpp/rtamd.hpp + main.cpp = the
+reference's main.rs on librtamd): builds, replays the reference's Vec3 tests against the mirrored
+Vec3, walks the Cornell object graph through the builders, and (GPU) renders the same image as the
+oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, scene_path
+
+EXE = os.path.join(ROOT, "rust-raytracer_amd", "rtamd_render")
+
+
+def run(*args):
+    return subprocess.run([EXE, *args], capture_output=True, text=True, timeout=300)
+
+
+def test_vec3_selftest_of_the_cpp_mirror():
+    r = run("--vec3-selftest")
+    assert r.returncode == 0 and "vec3 selftest: ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_cornell_graph_walk_and_scene_files():
+    r = run("--describe", "--cube", scene_path("cube.obj"))
+    assert r.returncode == 0 and "60 nodes (26 boxes, 2 spheres, 12 rects, 12 tris, 1 xforms)" in r.stdout, r.stdout + r.stderr
+    r = run("--describe", "--scene", scene_path("scene_500.json"))
+    assert r.returncode == 0 and "999 boxes, 1005 spheres" in r.stdout
+    r = run("--describe", "--scene", scene_path("test.json"))
+    assert r.returncode == 1 and "error -6" in r.stderr          # RT_ERR_SCHEMA, no abort
+    r = run("--describe", "--cube", "/nonexistent/cube.obj")
+    assert r.returncode == 1 and "error -5" in r.stderr          # "Failed to load OBJ file." -> RT_ERR_IO
+
+
+@pytest.mark.gpu
+def test_cpp_main_renders_the_oracles_image(tmp_path):
+    import oracle
+    from PIL import Image
+    out = str(tmp_path / "test.png")
+    r = run("--cube", scene_path("cube.obj"), "-w", "48", "-h", "48", "--spp", "8", "--seed", "1", "-o", out)
+    assert r.returncode == 0 and "Msamples/s" in r.stdout, r.stdout + r.stderr
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "cornell_48x48_8spp_seed1.npy"))
+    assert np.array_equal(np.asarray(Image.open(out)), oracle.tonemap_u8(gold))
