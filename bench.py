@@ -153,7 +153,8 @@ def main():
             "config": {"workload": "tests/golden/scenes/scene_500.json (data/scene_500.json of the reference, minified): 1005 spheres, "
                                    "999-node file BVH, %dx%d, %d spp, depth 50, seed %d" % (args.width, args.height, args.spp, args.seed),
                        "parallelism": "image tiles 8x8 dealt round-robin to %d GPU(s), RCCL framebuffer gather" % world_size,
-                       "kernel": "pt_kernel(ref-order f64, scene %s)" % ("in LDS" if last.get("scene_in_lds") else "in L2/HBM"),
+                       "kernel": "pt_kernel<%s>(f64 primitives, scene %s)" % ({1: "reference-order stackless", 2: "SAH-BVH2 accel, f32 conservative boxes"}.get(last.get("kernel_used"), "?"),
+                                                                              "in LDS" if last.get("scene_in_lds") else "in L2/HBM"),
                        "block_threads": last.get("block_threads"), "grid_blocks": last.get("grid_blocks"),
                        "spp_chunk": last.get("spp_chunk")},
             "wall_s": dt,

@@ -75,7 +75,8 @@ typedef struct rt_params {
     int32_t rank;        /* image-tile partition: this call renders tiles t with t % world == rank */
     int32_t world;       /* 1 = whole image */
     int32_t spp_chunk;   /* samples per pixel per kernel launch; 0 = auto */
-    int32_t kernel;      /* 0 = auto; 1 = reference-order f64 kernel */
+    int32_t kernel;      /* 0 = auto; 1 = reference-order stackless traversal; 2 = SAH-BVH2 accel traversal.
+                            Both give bit-identical images (same f64 primitive tests, same tie rule). */
     int32_t device;      /* HIP device ordinal; -1 = current */
     int32_t reserved;
 } rt_params;
@@ -161,6 +162,7 @@ typedef struct rt_scene_info {
     int32_t n_nodes, n_boxes, n_spheres, n_rects, n_tris, n_xforms, n_materials, n_textures;
     int32_t n_verts, max_depth, committed, reserved;
     uint64_t bytes;
+    int32_t accel_ok, accel_nodes, accel_items, accel_instances, accel_stack, reserved2;
 } rt_scene_info;
 int rt_scene_info_get(const rt_scene* s, rt_scene_info* out);
 
@@ -194,9 +196,9 @@ int rt_debug_rng_device(uint64_t seed, uint64_t pixel, uint64_t sample, int n, u
 int rt_debug_rng_host(uint64_t seed, uint64_t pixel, uint64_t sample, int n, uint64_t* out_host);
 /* device f64 sqrt / divide, element-wise, for the correctly-rounded check: op 0 = sqrt(a), 1 = a/b */
 int rt_debug_math_device(int op, size_t n, const double* a_host, const double* b_host, double* out_host);
-/* closest hit of explicit world-space rays through the device traversal: rays n*6 (orig,dir);
- * out n*12 = {hit, t, p[3], normal[3], front_face, u, v, leaf_node} */
-int rt_debug_hit_device(const rt_scene* s, size_t n, const double* rays_host, double t_min, double t_max, double* out_host);
+/* closest hit of explicit world-space rays through device traversal `kernel` (1 or 2): rays n*6 (orig,dir);
+ * out n*12 = {hit, t, p[3], normal[3], front_face, u, v, leaf index in the reference-order program} */
+int rt_debug_hit_device(const rt_scene* s, int kernel, size_t n, const double* rays_host, double t_min, double t_max, double* out_host);
 
 #ifdef __cplusplus
 }

@@ -307,7 +307,7 @@ static RenderPlan make_plan(const rt_params* p) {
     REQUIRE(p->spp > 0, "spp must be positive");
     REQUIRE(p->max_depth >= 0, "max_depth must be >= 0");
     REQUIRE(p->world >= 1 && p->rank >= 0 && p->rank < p->world, "bad rank/world");
-    REQUIRE(p->kernel == 0 || p->kernel == 1, "unknown kernel id");
+    REQUIRE(p->kernel >= 0 && p->kernel <= 2, "unknown kernel id");
     RenderPlan pl;
     pl.width = p->width; pl.height = p->height; pl.spp = p->spp; pl.max_depth = p->max_depth;
     pl.t_min = p->t_min; pl.seed = p->seed; pl.rank = p->rank; pl.world = p->world;
@@ -316,7 +316,7 @@ static RenderPlan make_plan(const rt_params* p) {
     pl.tiles_total = (int64_t)pl.tiles_x * pl.tiles_y;
     pl.tiles_owned = (pl.tiles_total - p->rank + p->world - 1) / p->world;
     if (pl.tiles_owned < 0) pl.tiles_owned = 0;
-    pl.kernel = 1;
+    pl.kernel = p->kernel;
     // sample-buffer budget: <= ~1.5 GiB per launch
     int chunk = p->spp_chunk;
     if (chunk <= 0) {
@@ -473,11 +473,11 @@ int rt_debug_math_device(int op, size_t n, const double* a_host, const double* b
         return (int)RT_OK;
     });
 }
-int rt_debug_hit_device(const rt_scene* s, size_t n, const double* rays_host, double t_min, double t_max, double* out_host) {
+int rt_debug_hit_device(const rt_scene* s, int kernel, size_t n, const double* rays_host, double t_min, double t_max, double* out_host) {
     return guard([&] {
-        REQUIRE(s && n > 0 && rays_host && out_host, "bad argument");
+        REQUIRE(s && n > 0 && rays_host && out_host && (kernel == 1 || kernel == 2), "bad argument");
         if (device_count() < 1) throw RtError(RT_ERR_NO_DEVICE, "no HIP device");
-        debug_hit_device(*s, n, rays_host, t_min, t_max, out_host);
+        debug_hit_device(*s, kernel, n, rays_host, t_min, t_max, out_host);
         return (int)RT_OK;
     });
 }

@@ -7,7 +7,8 @@
 // next node and a failed box test jumps to `skip`.  No stack, no pointers.
 //
 // Everything lives in one blob so it can be staged into LDS with one copy:
-//   hot  [meta | boxes | spheres | rects | tris | xforms | vpos]      <- staged into LDS when it fits
+//   hot  [meta | boxes | spheres | rects | tris | xforms | vpos | n2 | items2 | inst2]
+//        kernel 1 stages [meta..vpos], kernel 2 stages [spheres..inst2] into LDS when it fits
 //   cold [sphere_mat | rect_mat | mats | texs | vnrm | texels]        <- read once per segment, stays global
 // each section 16-byte aligned.  f64 payloads are the reference's own values.
 #pragma once
@@ -42,15 +43,52 @@ struct TexDev {   // material.rs:48-84
     double color[3];       // Constant
 };
 
+// ---------------------------------------------------------------------------
+// Accel ("kernel 2"): a BVH2 built on the host over the SAME primitives, used only to
+// decide WHICH primitives to test.  Box tests merely cull, so any conservative hierarchy
+// yields the reference's closest hit as long as (a) primitives are tested with the
+// reference's f64 arithmetic and (b) exact ties are resolved as the reference's visit order
+// resolves them: every item carries `order` = its index in the DFS program above, and a
+// candidate replaces the current best when t < best or (t == best and order > best.order).
+//   Node2 (64 B): both children's boxes in f32, rounded OUTWARD and padded (flatten2.cpp
+//   derives the pad from the f32 rounding of ray origins), so the f32 slab test never culls
+//   a box the exact test would keep.
+//   ref (32 bit): tag = ref >> 30 : 0 inner (Node2 index) | 1 leaf ((count-1) << 26 | first item)
+//                 | 2 restore-world marker | 3 done (0xFFFFFFFF)
+//   item (8 B): {kind | payload << 4, order}; kind = NodeKind of a primitive, or NK_INSTANCE
+//   instance (8 B): {xform index, root ref of its object-space BVH}
+// ---------------------------------------------------------------------------
+static const uint32_t NK_INSTANCE = 8;
+struct Node2 {
+    float lo_x[2], lo_y[2], lo_z[2], hi_x[2], hi_y[2], hi_z[2];  // [child]
+    uint32_t child[2];
+    uint32_t pad[2];
+};
+static const uint32_t REF_TAG_SHIFT = 30;
+static const uint32_t REF_LEAF = 1u << 30;
+static const uint32_t REF_RESTORE = 2u << 30;
+static const uint32_t REF_DONE = 0xFFFFFFFFu;
+static const uint32_t REF_LEAF_COUNT_SHIFT = 26;
+static const uint32_t REF_LEAF_FIRST_MASK = (1u << 26) - 1;
+static const int ACCEL_MAX_LEAF = 4;
+static const int ACCEL_MAX_STACK = 64;
+
 struct FlatView {  // by-value kernel argument
     const char* base;
     uint32_t off_meta, off_boxes, off_spheres, off_sphere_mat, off_rects, off_rect_mat, off_tris, off_xforms;
     uint32_t off_mats, off_texs, off_vpos, off_vnrm, off_texels;
     uint32_t n_nodes;
-    uint32_t stage_bytes;  // hot part: bytes [0, stage_bytes) are staged into LDS by the LDS kernel variant
+    uint32_t stage_bytes;  // kernel 1 stages bytes [0, stage_bytes) into LDS: [meta|boxes|spheres|rects|tris|xforms|vpos]
     uint32_t kinds_mask;   // bit k set if some node has kind k
     uint32_t total_bytes;
-    uint32_t pad;
+    // accel (kernel 2)
+    uint32_t accel_ok;        // 0: no accel was built (unbounded item, depth overflow, ...): kernel 1 only
+    uint32_t off_n2, off_items2, off_inst2;
+    uint32_t root2;           // root ref
+    uint32_t stage2_begin, stage2_end;  // kernel 2 stages [stage2_begin, stage2_end): [spheres|rects|tris|xforms|vpos|n2|items2|inst2]
+    uint32_t stack2;          // stack entries a lane can need
+    uint32_t pad0;
+    double origin_limit2;     // accel boxes are padded for ray origins with max-abs coordinate <= this (camera checked per render)
 };
 
 }  // namespace rtamd

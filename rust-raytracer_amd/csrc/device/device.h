@@ -27,7 +27,7 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
 void assemble_frame(const RenderPlan& plan, const double* d_gathered, int64_t tiles_per_rank_stride, double* d_frame, void* stream);
 void debug_rng_device(uint64_t seed, uint64_t pixel, uint64_t sample, int n, uint64_t* out_host);
 void debug_math_device(int op, size_t n, const double* a, const double* b, double* out);
-void debug_hit_device(const rt_scene& s, size_t n, const double* rays, double t_min, double t_max, double* out);
+void debug_hit_device(const rt_scene& s, int kernel, size_t n, const double* rays, double t_min, double t_max, double* out);
 int device_count();
 // thin HIP wrappers so abi.cpp stays free of HIP headers
 void* dev_alloc(size_t n);

@@ -117,6 +117,11 @@ struct Acc {  // typed views into the blob (LDS or global; the address space is 
     const double* vnrm;
     const uint8_t* texels;   // always global
     uint32_t n_nodes;
+    // accel (kernel 2)
+    const float4* n2;        // 4 x float4 per Node2
+    const uint2* items2;     // {kind | payload << 4, order}
+    const uint2* inst2;      // {xform, root ref}
+    uint32_t root2;
 };
 template <class P>
 DEV Acc make_acc(P hot, const char* gbase, const FlatView& v) {  // hot: LDS copy or the global blob; cold part always global
@@ -135,6 +140,10 @@ DEV Acc make_acc(P hot, const char* gbase, const FlatView& v) {  // hot: LDS cop
     a.vnrm = (const double*)(gbase + v.off_vnrm);
     a.texels = (const uint8_t*)(gbase + v.off_texels);
     a.n_nodes = v.n_nodes;
+    a.n2 = (const float4*)(hot + v.off_n2);
+    a.items2 = (const uint2*)(hot + v.off_items2);
+    a.inst2 = (const uint2*)(hot + v.off_inst2);
+    a.root2 = v.root2;
     return a;
 }
 
@@ -235,8 +244,9 @@ DEV bool tri_hit(const Acc& A, uint4 tr, D3 o, D3 dir, double t_min, double t_ma
 
 struct Hit {
     double t;
-    int node;  // DFS index of the winning leaf, -1 = miss
-    int xf;    // enclosing Transform (xform index) or -1
+    int node;     // DFS index of the winning leaf in the reference-order program, -1 = miss
+    int xf;       // enclosing Transform (xform index) or -1
+    uint32_t kp;  // kind | payload << 4 of the winning leaf
 };
 
 // World::hit -> BVHNode::hit / Vec::hit / Transform::hit, flattened (common/flat.h).
@@ -251,6 +261,7 @@ DEV Hit traverse(const Acc& A, D3 wo, D3 wd, double t_min, double t_max) {
     h.t = t_max;
     h.node = -1;
     h.xf = -1;
+    h.kp = 0;
     int cur_xf = -1;
     uint32_t n = 0;
     const uint32_t N = A.n_nodes;
@@ -265,6 +276,7 @@ DEV Hit traverse(const Acc& A, D3 wo, D3 wd, double t_min, double t_max) {
                 h.t = t;
                 h.node = (int)n;
                 h.xf = cur_xf;
+                h.kp = m.x;
             }
             n++;
         } else if (GENERAL) {
@@ -274,6 +286,7 @@ DEV Hit traverse(const Acc& A, D3 wo, D3 wd, double t_min, double t_max) {
                     h.t = t;
                     h.node = (int)n;
                     h.xf = cur_xf;
+                    h.kp = m.x;
                 }
             } else if (kind == NK_TRI) {
                 double t, b1, b2;
@@ -281,6 +294,7 @@ DEV Hit traverse(const Acc& A, D3 wo, D3 wd, double t_min, double t_max) {
                     h.t = t;
                     h.node = (int)n;
                     h.xf = cur_xf;
+                    h.kp = m.x;
                 }
             } else if (kind == NK_XFORM_BEGIN) {  // transform.rs:153-156
                 const double* Minv = A.xforms + 32 * pl;
@@ -299,6 +313,157 @@ DEV Hit traverse(const Acc& A, D3 wo, D3 wd, double t_min, double t_max) {
             n++;
         } else {
             n++;
+        }
+    }
+    return h;
+}
+
+
+// ---------------------------------------------------------------- kernel 2 traversal ----
+// Conservative f32 slab test of BOTH children of a Node2.
+//
+// Claim: if some real t in [t_min, best] puts o + t*d inside the exact f64 box B, the test passes.
+//   stored bounds:  lo <= B.min - pad,  hi >= B.max + pad  (host, rounded outward), with
+//   pad >= 2 * 2^-24 * |o|max, so with of = fl32(o) (|of - o| <= 2^-24 |o|):  lo - of <= (B.min - o) - pad/2.
+//   a = fl(lo - of), p = fl(a * inv32): three roundings (sub, inv64->f32, mul) => p = Y*inv*(1+th), |th| < 3.1 * 2^-24,
+//   where Y*inv is BELOW the true slab entry.  Widening  tn - 4*2^-24*|tn|  (resp. tf + ...) absorbs th; the
+//   widening is monotone, so it is applied once after max3/min3.  NaNs (0*inf, inf-inf) only arise when a
+//   constraint is vacuous and are dropped by max/min, which loosens the test.  t_min / best are rounded outward.
+struct Ray32 {
+    float ox, oy, oz, ix, iy, iz;
+    float tmin, best;  // rounded outward
+};
+DEV float f32_down(double x) { float f = (float)x; return __builtin_fmaf(-fabsf(f), 1.1920929e-7f, f); }
+DEV float f32_up(double x) { float f = (float)x; return __builtin_fmaf(fabsf(f), 1.1920929e-7f, f); }
+DEV Ray32 make_ray32(D3 o, D3 inv, double t_min, double best) {
+    Ray32 r;
+    r.ox = (float)o.x; r.oy = (float)o.y; r.oz = (float)o.z;
+    r.ix = (float)inv.x; r.iy = (float)inv.y; r.iz = (float)inv.z;
+    r.tmin = f32_down(t_min);
+    r.best = f32_up(best);
+    return r;
+}
+DEV void slab32(float lo, float hi, float o, float inv, float& tn, float& tf) {
+    float p = (lo - o) * inv, q = (hi - o) * inv;
+    bool neg = inv < 0.0f;
+    tn = neg ? q : p;
+    tf = neg ? p : q;
+}
+DEV bool box32(float lox, float loy, float loz, float hix, float hiy, float hiz, const Ray32& r, float& entry) {
+    float nx, fx, ny, fy, nz, fz;
+    slab32(lox, hix, r.ox, r.ix, nx, fx);
+    slab32(loy, hiy, r.oy, r.iy, ny, fy);
+    slab32(loz, hiz, r.oz, r.iz, nz, fz);
+    float tn = fmaxf(fmaxf(nx, ny), nz), tf = fminf(fminf(fx, fy), fz);
+    const float K = 2.3841858e-7f;  // 4 * 2^-24
+    tn = __builtin_fmaf(-fabsf(tn), K, tn);
+    tf = __builtin_fmaf(fabsf(tf), K, tf);
+    tn = fmaxf(tn, r.tmin);
+    tf = fminf(tf, r.best);
+    entry = tn;
+    return tn <= tf;
+}
+
+// Closest hit through the accel (common/flat.h): near-child-first BVH2 descent with a per-lane stack in LDS,
+// "while-while" form (all lanes descend inner nodes until each holds a leaf, then all test leaves).
+// Primitive tests, ranges and the tie rule are the reference's (see traverse<> above); only the order in which
+// primitives are met differs, which cannot change the result.
+template <bool GENERAL>
+DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, double t_min, double t_max) {
+    D3 o = wo, d = wd;
+    D3 inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+    double a = sqlen(d);
+    Hit h;
+    h.t = t_max;
+    h.node = -1;
+    h.xf = -1;
+    h.kp = 0;
+    int cur_xf = -1;
+    Ray32 r = make_ray32(o, inv, t_min, t_max);
+    int sp = 0;
+    uint32_t cur = A.root2;
+    for (;;) {
+        while ((cur >> REF_TAG_SHIFT) == 0u) {  // inner node: test both children
+            const float4* p = A.n2 + 4 * cur;
+            float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];  // (lox0,lox1,loy0,loy1) (loz0,loz1,hix0,hix1) (hiy0,hiy1,hiz0,hiz1) (c0,c1,-,-)
+            float e0, e1;
+            bool h0 = box32(q0.x, q0.z, q1.x, q1.z, q2.x, q2.z, r, e0);
+            bool h1 = box32(q0.y, q0.w, q1.y, q1.w, q2.y, q2.w, r, e1);
+            uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
+            if (h0 && h1) {
+                bool swap = e1 < e0;
+                uint32_t nearc = swap ? c1 : c0, farc = swap ? c0 : c1;
+                stk[sp * stride] = farc;
+                sp++;
+                cur = nearc;
+            } else if (h0) {
+                cur = c0;
+            } else if (h1) {
+                cur = c1;
+            } else if (sp > 0) {
+                sp--;
+                cur = stk[sp * stride];
+            } else {
+                cur = REF_DONE;
+            }
+        }
+        if (cur == REF_DONE) break;
+        if ((cur >> REF_TAG_SHIFT) == 1u) {  // leaf: test its items with the reference's f64 routines
+            uint32_t first = cur & REF_LEAF_FIRST_MASK, cnt = ((cur >> REF_LEAF_COUNT_SHIFT) & 7u) + 1u;
+            uint32_t enter = REF_DONE;
+            for (uint32_t i = 0; i < cnt; i++) {
+                uint2 it = A.items2[first + i];
+                uint32_t kind = it.x & NK_MASK, pl = it.x >> NK_BITS;
+                double t = 0.;
+                bool got = false;
+                if (kind == NK_SPHERE) {
+                    got = sphere_hit(A.spheres + 2 * pl, o, d, a, t_min, h.t, t);
+                } else if (GENERAL) {
+                    if (kind == NK_RECT_YZ || kind == NK_RECT_XZ || kind == NK_RECT_XY) {
+                        got = rect_hit(A.rects + 3 * pl, (int)kind - (int)NK_RECT_YZ, o, d, t_min, h.t, t);
+                    } else if (kind == NK_TRI) {
+                        double b1, b2;
+                        got = tri_hit(A, A.tris[pl], o, d, t_min, h.t, t, b1, b2);
+                    } else {  // NK_INSTANCE: descend into its object-space BVH after the remaining items
+                        enter = pl;
+                    }
+                }
+                // accepted candidates satisfy t <= h.t; an exact tie goes to the later one in reference order
+                if (got && (t < h.t || (int)it.y > h.node || !(t == t))) {
+                    h.t = t;
+                    h.node = (int)it.y;
+                    h.xf = cur_xf;
+                    h.kp = it.x;
+                    r.best = f32_up(t);
+                }
+            }
+            if (GENERAL && enter != REF_DONE) {  // Transform::hit, transform.rs:153-156
+                uint2 in = A.inst2[enter];
+                const double* Minv = A.xforms + 32 * in.x;
+                o = xf_point(Minv, wo);
+                d = xf_dir(Minv, wd);
+                inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+                a = sqlen(d);
+                cur_xf = (int)in.x;
+                r = make_ray32(o, inv, t_min, h.t);
+                stk[sp * stride] = REF_RESTORE;
+                sp++;
+                cur = in.y;
+                continue;
+            }
+        } else {  // REF_RESTORE: leave the Transform
+            o = wo;
+            d = wd;
+            inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+            a = sqlen(d);
+            cur_xf = -1;
+            r = make_ray32(o, inv, t_min, h.t);
+        }
+        if (sp > 0) {
+            sp--;
+            cur = stk[sp * stride];
+        } else {
+            cur = REF_DONE;
         }
     }
     return h;
@@ -334,8 +499,7 @@ DEV D3 tex_color(const Acc& A, int tex, const Rec& rec) {  // material.rs:52-84
 template <bool GENERAL>
 DEV Rec materialize(const Acc& A, const Hit& h, D3 wo, D3 wd, int* err) {
     Rec rec;
-    uint2 m = A.meta[h.node];
-    uint32_t kind = m.x & NK_MASK, pl = m.x >> NK_BITS;
+    uint32_t kind = h.kp & NK_MASK, pl = h.kp >> NK_BITS;
     D3 o = wo, d = wd;
     if (GENERAL && h.xf >= 0) {
         const double* Minv = A.xforms + 32 * h.xf;
@@ -449,20 +613,25 @@ DEV bool shade(const Acc& A, const Rec& rec, D3 rdir, Rng& rng, D3& emitted, D3&
 }
 
 // ------------------------------------------------------------ pt_kernel ---
-template <bool LDS, bool GENERAL>
+template <bool LDS, bool GENERAL, int ACCEL>
 __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, RenderK rk, double* __restrict__ samples,
                                                       unsigned int* __restrict__ counter, int* __restrict__ err) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // LDS map: [staged scene tables (LDS variants)] [kernel 2: per-lane traversal stacks, stack2 x blockDim words]
+    const uint32_t st_begin = (ACCEL == 2) ? sv.stage2_begin : 0u;
+    const uint32_t st_end = (ACCEL == 2) ? sv.stage2_end : sv.stage_bytes;
     Acc A;
     if (LDS) {
-        const uint4* src = (const uint4*)sv.base;
+        const uint4* src = (const uint4*)(sv.base + st_begin);
         uint4* dst = (uint4*)smem;
-        for (uint32_t i = threadIdx.x; i < sv.stage_bytes / 16; i += blockDim.x) dst[i] = src[i];
+        for (uint32_t i = threadIdx.x; i < (st_end - st_begin) / 16; i += blockDim.x) dst[i] = src[i];
         __syncthreads();
-        A = make_acc(smem, sv.base, sv);
+        A = make_acc(smem - st_begin, sv.base, sv);
     } else {
         A = make_acc(sv.base, sv.base, sv);
     }
+    uint32_t* stk = (uint32_t*)(smem + (LDS ? (st_end - st_begin) : 0u)) + threadIdx.x;
+    const int stk_stride = (int)blockDim.x;
     const int lane = threadIdx.x & 63;
     const uint64_t lanemask_lt = (1ull << lane) - 1ull;
 
@@ -520,7 +689,8 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
             }
             // ---- one path segment: sample_ray's loop body, photon_mapper.rs:335-362 ----
             if (alive) {
-                Hit h = traverse<GENERAL>(A, o, d, rk.t_min, INFINITY);
+                Hit h = (ACCEL == 2) ? traverse2<GENERAL>(A, stk, stk_stride, o, d, rk.t_min, INFINITY)
+                                     : traverse<GENERAL>(A, o, d, rk.t_min, INFINITY);
                 bool done = true;
                 if (h.node >= 0 && depth > 0) {  // Q12: depth test after the hit, before emission
                     depth -= 1;
@@ -614,12 +784,14 @@ __global__ void math_kernel(int op, size_t n, const double* a, const double* b, 
     if (i >= n) return;
     out[i] = (op == 0) ? sqrt(a[i]) : a[i] / b[i];
 }
-__global__ void hit_kernel(FlatView sv, size_t n, const double* rays, double t_min, double t_max, double* out, int* err) {
+__global__ void hit_kernel(FlatView sv, int accel, size_t n, const double* rays, double t_min, double t_max, double* out, int* err) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Acc A = make_acc(sv.base, sv.base, sv);
     D3 o = mk(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]), d = mk(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
-    Hit h = traverse<true>(A, o, d, t_min, t_max);
+    Hit h = (accel == 2) ? traverse2<true>(A, (uint32_t*)smem + threadIdx.x, (int)blockDim.x, o, d, t_min, t_max)
+                         : traverse<true>(A, o, d, t_min, t_max);
     double* q = out + 12 * i;
     for (int k = 0; k < 12; k++) q[k] = 0.;
     if (h.node < 0) return;
@@ -719,16 +891,31 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
     FlatView view = s.flat.view;
     view.base = device_blob(s, dev);
     const bool general = (view.kinds_mask & ~((1u << NK_BOX) | (1u << NK_SPHERE))) != 0;
-    const size_t lds_budget = (size_t)prop.sharedMemPerBlock > 160 * 1024 ? 160 * 1024 : (size_t)prop.sharedMemPerBlock;
-    size_t lds_max = 0;
+    size_t lds_max = 64 * 1024;
     {
         int v = 0;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess && v > 0) lds_max = (size_t)v;
-        if (lds_max < lds_budget) lds_max = lds_budget;
+        if (lds_max > 160 * 1024) lds_max = 160 * 1024;
     }
-    const bool lds = view.stage_bytes > 0 && view.stage_bytes <= lds_max;
-    pt_fn fn = lds ? (general ? pt_kernel<true, true> : pt_kernel<true, false>) : (general ? pt_kernel<false, true> : pt_kernel<false, false>);
-    const size_t smem = lds ? view.stage_bytes : 0;
+    // kernel 2 (accel) is the default when an accel exists and its padding covers this camera's origin
+    // (flatten.cpp: boxes are padded for ray origins up to origin_limit2); otherwise kernel 1 (reference order).
+    double cam_abs = std::fmax(std::fmax(std::fabs(cam.origin[0]), std::fabs(cam.origin[1])), std::fabs(cam.origin[2])) + std::fabs(cam.lens_radius);
+    const bool accel_usable = view.accel_ok && cam_abs <= view.origin_limit2 && std::isfinite(cam_abs);
+    int kernel = plan.kernel;
+    if (kernel == 0) kernel = accel_usable ? 2 : 1;
+    if (kernel == 2 && !accel_usable)
+        throw RtError(RT_ERR_UNSUPPORTED, "kernel 2 requested but no usable accel for this scene/camera (unbounded item, depth overflow, or camera "
+                                          "farther than 64x the scene extent); use kernel 0/1");
+    const size_t stack_bytes = (kernel == 2) ? (size_t)view.stack2 * PT_BLOCK * sizeof(uint32_t) : 0;
+    const size_t hot_bytes = (kernel == 2) ? (size_t)(view.stage2_end - view.stage2_begin) : (size_t)view.stage_bytes;
+    if (stack_bytes > lds_max) throw RtError(RT_ERR_UNSUPPORTED, "accel stack does not fit LDS");
+    const bool lds = hot_bytes > 0 && hot_bytes + stack_bytes <= lds_max;
+    pt_fn fn;
+    if (kernel == 2)
+        fn = lds ? (general ? pt_kernel<true, true, 2> : pt_kernel<true, false, 2>) : (general ? pt_kernel<false, true, 2> : pt_kernel<false, false, 2>);
+    else
+        fn = lds ? (general ? pt_kernel<true, true, 1> : pt_kernel<true, false, 1>) : (general ? pt_kernel<false, true, 1> : pt_kernel<false, false, 1>);
+    const size_t smem = (lds ? hot_bytes : 0) + stack_bytes;
     if (smem > 48 * 1024) HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     int blocks_per_cu = 0;
     HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, (const void*)fn, PT_BLOCK, smem));
@@ -802,7 +989,7 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
         st->kernel_ms = kms;
         st->reduce_ms = rms;
         st->launches = launches;
-        st->kernel_used = 1;
+        st->kernel_used = kernel;
         st->scene_in_lds = lds ? 1 : 0;
         st->block_threads = PT_BLOCK;
         st->grid_blocks = grid;
@@ -840,7 +1027,7 @@ void debug_math_device(int op, size_t n, const double* a, const double* bb, doub
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemcpy(out, dc.p, n * 8, hipMemcpyDeviceToHost));
 }
-void debug_hit_device(const rt_scene& s, size_t n, const double* rays, double t_min, double t_max, double* out) {
+void debug_hit_device(const rt_scene& s, int kernel, size_t n, const double* rays, double t_min, double t_max, double* out) {
     if (!s.committed) throw RtError(RT_ERR_NOT_COMMITTED, "scene not committed");
     int dev = 0;
     HIP_CHECK(hipGetDevice(&dev));
@@ -852,8 +1039,9 @@ void debug_hit_device(const rt_scene& s, size_t n, const double* rays, double t_
     err.alloc(4);
     HIP_CHECK(hipMemset(err.p, 0, 4));
     HIP_CHECK(hipMemcpy(dr.p, rays, n * 48, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(hit_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, view, n, (const double*)dr.p, t_min, t_max,
-                       (double*)dout.p, (int*)err.p);
+    if (kernel == 2 && !view.accel_ok) throw RtError(RT_ERR_UNSUPPORTED, "no accel for this scene");
+    hipLaunchKernelGGL(hit_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), (kernel == 2) ? view.stack2 * 64 * sizeof(uint32_t) : 0, 0, view,
+                       kernel, n, (const double*)dr.p, t_min, t_max, (double*)dout.p, (int*)err.p);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemcpy(out, dout.p, n * 96, hipMemcpyDeviceToHost));
 }

@@ -10,6 +10,9 @@
 #include <cstring>
 #include <map>
 
+#include <cmath>
+
+#include "accel.h"
 #include "scene.h"
 
 namespace rtamd {
@@ -26,6 +29,31 @@ struct Builder {
     std::vector<uint32_t> mesh_base;
     uint32_t kinds = 0;
     int xf_depth = 0, depth = 0, max_depth = 0;
+    // accel (kernel 2) item collection: context 0 = world space, context 1+i = object space of instance i
+    struct InstCtx {
+        std::vector<AccelItem> items;
+        std::map<int, size_t> of;  // object id -> item slot (a re-emitted object keeps one slot, latest order)
+        uint32_t xform = 0;
+        const double* Minv = nullptr;
+    };
+    std::vector<InstCtx> actx{1};
+    std::vector<size_t> ctx_stack{0};
+    bool accel_ok = true;
+
+    void accel_item(int obj_id, const ObjectRec& o, uint32_t kp, uint32_t node_index) {
+        InstCtx& c = actx[ctx_stack.back()];
+        if (!o.has_box) {
+            accel_ok = false;
+            return;
+        }
+        auto it = c.of.find(obj_id);
+        if (it == c.of.end()) {
+            c.of.emplace(obj_id, c.items.size());
+            c.items.push_back(AccelItem{o.box, kp, (int32_t)node_index});
+        } else {
+            c.items[it->second].order = (int32_t)node_index;  // the later visit wins ties (Q5/Q14)
+        }
+    }
 
     explicit Builder(rt_scene& sc) : s(sc) {}
 
@@ -49,7 +77,8 @@ struct Builder {
                     spheres.insert(spheres.end(), {o.c[0], o.c[1], o.c[2], o.r});
                     sphere_mat.push_back(o.material);
                 }
-                node(NK_SPHERE, it->second);
+                uint32_t n = node(NK_SPHERE, it->second);
+                accel_item(id, o, NK_SPHERE | (it->second << NK_BITS), n);
                 break;
             }
             case OBJ_RECT: {
@@ -59,7 +88,9 @@ struct Builder {
                     rects.insert(rects.end(), {o.a0, o.b0, o.a1, o.b1, o.k, 0.0});
                     rect_mat.push_back(o.material);
                 }
-                node(o.axis == 0 ? NK_RECT_YZ : (o.axis == 1 ? NK_RECT_XZ : NK_RECT_XY), it->second);
+                uint32_t kind = o.axis == 0 ? NK_RECT_YZ : (o.axis == 1 ? NK_RECT_XZ : NK_RECT_XY);
+                uint32_t n = node(kind, it->second);
+                accel_item(id, o, kind | (it->second << NK_BITS), n);
                 break;
             }
             case OBJ_TRIANGLE: {
@@ -69,7 +100,8 @@ struct Builder {
                     uint32_t base = mesh_base[o.mesh];
                     tris.insert(tris.end(), {base + o.ia, base + o.ib, base + o.ic, (uint32_t)o.material});
                 }
-                node(NK_TRI, it->second);
+                uint32_t n = node(NK_TRI, it->second);
+                accel_item(id, o, NK_TRI | (it->second << NK_BITS), n);
                 break;
             }
             case OBJ_CUBE:
@@ -95,9 +127,17 @@ struct Builder {
                     xforms.insert(xforms.end(), o.M, o.M + 16);
                 }
                 uint32_t n = node(NK_XFORM_BEGIN, it->second);
+                // accel: the Transform is one item of the enclosing space; its subtree gets its own object-space BVH
+                uint32_t inst_index = (uint32_t)(actx.size() - 1);
+                accel_item(id, o, NK_INSTANCE | (inst_index << NK_BITS), n);
+                actx.emplace_back();
+                actx.back().xform = it->second;
+                actx.back().Minv = o.Minv;
+                ctx_stack.push_back(actx.size() - 1);
                 xf_depth++;
                 emit(o.children[0]);
                 xf_depth--;
+                ctx_stack.pop_back();
                 node(NK_XFORM_END, it->second);
                 meta[2 * n + 1] = (uint32_t)(meta.size() / 2);
                 break;
@@ -156,16 +196,70 @@ void flatten(rt_scene& s) {
     FlatScene& f = s.flat;
     f.blob.clear();
     FlatView v{};
-    // hot part (read once per visited node): candidate for LDS residency
+    // ---- accel (kernel 2) ----
+    AccelBuild ab;
+    ab.ok = b.accel_ok;
+    uint32_t root2 = REF_DONE;
+    double origin_limit = 0.;
+    if (ab.ok && !b.actx[0].items.empty()) {
+        // E_w: largest |coordinate| of the world items; boxes are padded so that rounding a ray origin with
+        // max-abs coordinate <= 64*E_w to f32 (relative error 2^-24) can never make the f32 slab test cull a box
+        // the exact test keeps: pad >= 2 * 2^-24 * |o|max  (derivation in csrc/device/kernels.hip, aabb2_pair)
+        double ew = 0.;
+        for (auto& it : b.actx[0].items)
+            for (int a = 0; a < 3; a++) ew = std::fmax(ew, std::fmax(std::fabs(it.box.mn[a]), std::fabs(it.box.mx[a])));
+        if (!(ew > 0.) || !std::isfinite(ew)) {
+            ab.ok = false;
+        } else {
+            origin_limit = 64. * ew;
+            const double pad_w = std::ldexp(origin_limit, -22);  // 2 * (2 * 2^-24 * |o|max): factor-2 safety margin
+            root2 = accel_build_bvh(ab, b.actx[0].items, pad_w, 0);
+            const int depth_tlas = ab.max_depth;
+            ab.inst.assign(2 * (b.actx.size() - 1), 0u);
+            for (size_t i = 1; ab.ok && i < b.actx.size(); i++) {
+                auto& c = b.actx[i];
+                // object-space origin bound: |M^-1 o| <= sum_b |Minv[a][b]| * |o|max + |Minv[a][3]|
+                double oo = 0.;
+                for (int a = 0; a < 3; a++)
+                    oo = std::fmax(oo, (std::fabs(c.Minv[4 * a]) + std::fabs(c.Minv[4 * a + 1]) + std::fabs(c.Minv[4 * a + 2])) * origin_limit +
+                                           std::fabs(c.Minv[4 * a + 3]));
+                for (auto& it : c.items)  // hit points inside the instance also serve as origins of secondary rays (in world space only)
+                    for (int a = 0; a < 3; a++) oo = std::fmax(oo, std::fmax(std::fabs(it.box.mn[a]), std::fabs(it.box.mx[a])));
+                uint32_t r = accel_build_bvh(ab, c.items, std::ldexp(oo, -22), depth_tlas + 1);
+                ab.inst[2 * (i - 1)] = c.xform;
+                ab.inst[2 * (i - 1) + 1] = r;
+            }
+        }
+    } else {
+        ab.ok = false;
+    }
+    if (ab.max_depth + 2 > ACCEL_MAX_STACK) ab.ok = false;
+
+    // hot part (read once per visited node): candidates for LDS residency
     v.off_meta = append(f.blob, b.meta);
     v.off_boxes = append(f.blob, b.boxes);
     v.off_spheres = append(f.blob, b.spheres);
+    v.stage2_begin = v.off_spheres;
     v.off_rects = append(f.blob, b.rects);
     v.off_tris = append(f.blob, b.tris);
     v.off_xforms = append(f.blob, b.xforms);
     v.off_vpos = append(f.blob, b.vpos);
     f.blob.resize((f.blob.size() + 15) & ~size_t(15));
     v.stage_bytes = (uint32_t)f.blob.size();
+    if (!ab.ok) {
+        ab.nodes.clear();
+        ab.items.clear();
+        ab.inst.clear();
+    }
+    v.off_n2 = append(f.blob, ab.nodes);
+    v.off_items2 = append(f.blob, ab.items);
+    v.off_inst2 = append(f.blob, ab.inst);
+    f.blob.resize((f.blob.size() + 15) & ~size_t(15));
+    v.stage2_end = (uint32_t)f.blob.size();
+    v.accel_ok = ab.ok ? 1u : 0u;
+    v.root2 = root2;
+    v.stack2 = (uint32_t)(ab.max_depth + 2);
+    v.origin_limit2 = origin_limit;
     // cold part (read once per path segment, by the winning leaf only): always global
     v.off_sphere_mat = append(f.blob, b.sphere_mat);
     v.off_rect_mat = append(f.blob, b.rect_mat);
@@ -193,6 +287,11 @@ void flatten(rt_scene& s) {
     in.max_depth = b.max_depth;
     in.committed = 1;
     in.bytes = f.blob.size();
+    in.accel_ok = ab.ok ? 1 : 0;
+    in.accel_nodes = (int32_t)ab.nodes.size();
+    in.accel_items = (int32_t)(ab.items.size() / 2);
+    in.accel_instances = (int32_t)(ab.inst.size() / 2);
+    in.accel_stack = (int32_t)v.stack2;
     s.committed = true;
 }
 

@@ -52,10 +52,11 @@ class rt_stats(C.Structure):
 
 class rt_scene_info(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("n_nodes", "n_boxes", "n_spheres", "n_rects", "n_tris", "n_xforms", "n_materials",
-                                         "n_textures", "n_verts", "max_depth", "committed", "reserved")] + [("bytes", C.c_uint64)]
+                                         "n_textures", "n_verts", "max_depth", "committed", "reserved")] + [("bytes", C.c_uint64)] + \
+               [(n, C.c_int32) for n in ("accel_ok", "accel_nodes", "accel_items", "accel_instances", "accel_stack", "reserved2")]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        return {k: getattr(self, k) for k, _ in self._fields_ if not k.startswith("reserved")}
 
 
 _d3 = C.c_double * 3
@@ -108,7 +109,7 @@ _SIGS = [
     ("rt_debug_rng_device", C.c_int, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_uint64)]),
     ("rt_debug_rng_host", C.c_int, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_uint64)]),
     ("rt_debug_math_device", C.c_int, [C.c_int, C.c_size_t, _dp, _dp, _dp]),
-    ("rt_debug_hit_device", C.c_int, [C.c_void_p, C.c_size_t, _dp, C.c_double, C.c_double, _dp]),
+    ("rt_debug_hit_device", C.c_int, [C.c_void_p, C.c_int, C.c_size_t, _dp, C.c_double, C.c_double, _dp]),
 ]
 ABI_SYMBOLS = [s[0] for s in _SIGS]
 
@@ -338,10 +339,11 @@ class World:
                                            C.c_void_p(stream_ptr or 0), C.byref(st)))
         return st.as_dict()
 
-    def debug_hit(self, rays, t_min=1e-3, t_max=float("inf")):
+    def debug_hit(self, rays, t_min=1e-3, t_max=float("inf"), kernel=1):
         r = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)
         out = np.zeros((r.shape[0], 12), dtype=np.float64)
-        _chk(self.L.rt_debug_hit_device(self.h, r.shape[0], r.ctypes.data_as(_dp), float(t_min), float(t_max), out.ctypes.data_as(_dp)))
+        _chk(self.L.rt_debug_hit_device(self.h, int(kernel), r.shape[0], r.ctypes.data_as(_dp), float(t_min), float(t_max),
+                                        out.ctypes.data_as(_dp)))
         return out
 
 

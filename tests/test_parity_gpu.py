@@ -54,6 +54,7 @@ def test_device_sqrt_and_divide_are_correctly_rounded():
         assert np.array_equal(rtamd.debug_math(1, a, b), a / b)
 
 
+@pytest.mark.parametrize("kernel", [1, 2])
 @pytest.mark.parametrize("name,w,h,spp,aspect", [
     ("scene_10.json", 64, 36, 16, 16.0 / 9.0),      # C1 at reduced size
     ("scene_10.yaml", 40, 24, 4, None),
@@ -61,12 +62,19 @@ def test_device_sqrt_and_divide_are_correctly_rounded():
     ("scene_500.json", 96, 96, 8, None),            # C2 at reduced size
     ("scene_500.json", 37, 21, 3, None),            # ragged: not a multiple of the 8x8 tile
 ])
-def test_render_bit_exact_vs_oracle(name, w, h, spp, aspect):
+def test_render_bit_exact_vs_oracle(name, w, h, spp, aspect, kernel):
     world, cam, ref = _pair(name, aspect)
-    img, st = world.render(cam, width=w, height=h, spp=spp, seed=1)
+    img, st = world.render(cam, width=w, height=h, spp=spp, seed=1, kernel=kernel)
     exp, _ = ref.render(w, h, spp, seed=1)
-    _assert_same(img, exp, "%s %dx%dx%d" % (name, w, h, spp))
-    assert st["samples"] == w * h * spp
+    _assert_same(img, exp, "%s %dx%dx%d kernel %d" % (name, w, h, spp, kernel))
+    assert st["samples"] == w * h * spp and st["kernel_used"] == kernel
+
+
+def test_auto_kernel_is_the_accel_kernel():
+    world, cam, _ = _pair("scene_500.json")
+    assert world.info()["accel_ok"] == 1
+    _, st = world.render(cam, width=16, height=16, spp=1)
+    assert st["kernel_used"] == 2 and st["scene_in_lds"] == 1
 
 
 def test_seed_changes_image_and_is_reproducible():
@@ -100,27 +108,29 @@ def test_depth_limit_semantics():
     """Q12: depth is tested after the hit and before emission: max_depth hits contribute."""
     world, cam, ref = _pair("scene_500.json")
     for depth in (0, 1, 2, 5):
-        img, _ = world.render(cam, width=32, height=32, spp=4, seed=1, max_depth=depth)
+        img, _ = world.render(cam, width=32, height=32, spp=4, seed=1, max_depth=depth, kernel=1 + depth % 2)
         exp, _ = ref.render(32, 32, 4, max_depth=depth, seed=1)
         _assert_same(img, exp, "max_depth=%d" % depth)
     z, _ = world.render(cam, width=16, height=16, spp=2, seed=1, max_depth=0)
     assert not z.any()
 
 
-def test_cornell_box_bit_exact():
+@pytest.mark.parametrize("kernel", [1, 2])
+def test_cornell_box_bit_exact(kernel):
     """C3 geometry: rects, cube, transform(mesh), glass + mirror spheres, rect light (scene.rs:16-112)."""
     import oracle
     import rtamd
     cube = scene_path("cube.obj")
     world, cam = rtamd.select_scene(cube, aspect_ratio=1.0, bvh_seed=1)
     ref = oracle.cornell_box_scene(cube, 1.0, seed=1)
-    img, _ = world.render(cam, width=64, height=64, spp=8, seed=1)
+    img, _ = world.render(cam, width=64, height=64, spp=8, seed=1, kernel=kernel)
     exp, _ = ref.render(64, 64, 8, seed=1)
-    _assert_same(img, exp, "cornell 64x64x8")
+    _assert_same(img, exp, "cornell 64x64x8 kernel %d" % kernel)
     assert img.max() > 0
 
 
-def test_first_hit_records_match_oracle():
+@pytest.mark.parametrize("kernel", [1, 2])
+def test_first_hit_records_match_oracle(kernel):
     """World::hit on explicit rays: t, p, normal, front_face identical to the oracle's HitRecord."""
     import oracle
     import rtamd
@@ -134,7 +144,7 @@ def test_first_hit_records_match_oracle():
         rays[:, :3] = origin
         target = rng.random((n, 3)) * scale if scale > 100 else (rng.random((n, 3)) - 0.5) * scale
         rays[:, 3:] = target - rays[:, :3]
-        out = world.debug_hit(rays, t_min=1e-3)
+        out = world.debug_hit(rays, t_min=1e-3, kernel=kernel)
         nhit = 0
         for i in range(n):
             h = ref.hit(rays[i, :3], rays[i, 3:], t_min=1e-3)
@@ -147,6 +157,7 @@ def test_first_hit_records_match_oracle():
             assert np.array_equal(out[i, 5:8], h["normal"])
             assert bool(out[i, 8]) == h["front_face"]
         assert nhit > n // 4
+        assert np.array_equal(out, world.debug_hit(rays, t_min=1e-3, kernel=1))   # incl. the winning leaf's reference-order index
 
 
 def test_tonemap_and_png_roundtrip(tmp_path):
@@ -161,3 +172,35 @@ def test_tonemap_and_png_roundtrip(tmp_path):
     rtamd.write_png(p, u8)
     assert np.array_equal(np.asarray(Image.open(p).convert("RGB")), u8)
     assert np.array_equal(cam.capture_image(world, width=64, height=36, sample_per_pixel=4, seed=1), u8)
+
+
+def test_kernels_agree_on_random_sphere_soups_with_ties():
+    """kernel 1 (reference order) vs kernel 2 (accel) on scenes built to provoke the tie rule: duplicated and
+    touching spheres, shared centres, a 1-object BVHNode::new (Q14) and rays aimed exactly at sphere centres."""
+    import rtamd
+    rng = np.random.default_rng(5)
+    w = rtamd.World()
+    mats = [w.Lambertian(w.ConstantTexture(tuple(rng.random(3)))) for _ in range(4)]
+    ids = []
+    centres = rng.integers(-4, 5, size=(40, 3)).astype(float)
+    for i, c in enumerate(centres):
+        ids.append(w.Sphere(tuple(c), 0.5, mats[i % 4]))
+        if i % 3 == 0:
+            ids.append(w.Sphere(tuple(c), 0.5, mats[(i + 1) % 4]))        # exact duplicate: later one must win
+        if i % 5 == 0:
+            ids.append(w.Sphere(tuple(c + (1.0, 0, 0)), 0.5, mats[2]))     # touching neighbour: tangent-point ties
+    single = w.BVHNode_new([ids[0]], bvh_seed=1)
+    w.new(ids + [single], bvh_seed=9)
+    n = 4000
+    rays = np.zeros((n, 6))
+    rays[:, :3] = (0.0, 0.0, -20.0)
+    target = centres[rng.integers(0, len(centres), n)] + np.where(rng.random((n, 1)) < 0.5, 0.0, rng.normal(0, 0.4, (n, 3)))
+    rays[:, 3:] = target - rays[:, :3]
+    a = w.debug_hit(rays, kernel=1)
+    b = w.debug_hit(rays, kernel=2)
+    assert np.array_equal(a, b)
+    assert a[:, 0].sum() > n // 2
+    cam = rtamd.Camera(((0, 0, -20), (0, 0, 0)), (0, 1, 0), 40, 1.0, 0.0, 20.0)
+    i1, _ = w.render(cam, width=48, height=48, spp=4, kernel=1)
+    i2, _ = w.render(cam, width=48, height=48, spp=4, kernel=2)
+    assert np.array_equal(i1, i2)
