@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--height", type=int, default=1200)
     ap.add_argument("--spp", type=int, default=1000)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--kernel", type=int, default=0, help="0 = library default; 1/2/3 force a path-trace kernel (A/B runs only)")
     ap.add_argument("--cpu-spp", type=int, default=12, help="spp of the bounded CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
 
@@ -84,7 +85,7 @@ def main():
 
     world, cam = rtamd.load_scene_file(SCENE)
     params = rtamd.default_params(width=args.width, height=args.height, spp=args.spp, max_depth=50, t_min=1e-3, seed=args.seed,
-                                  rank=rank, world=world_size)
+                                  rank=rank, world=world_size, kernel=args.kernel)
     from rtamd.distributed import TileLayout, gather_tiles
     layout = TileLayout(args.width, args.height, world_size)
     p0 = rtamd.default_params(width=args.width, height=args.height, spp=args.spp, rank=0, world=world_size)
@@ -153,7 +154,7 @@ def main():
             "config": {"workload": "tests/golden/scenes/scene_500.json (data/scene_500.json of the reference, minified): 1005 spheres, "
                                    "999-node file BVH, %dx%d, %d spp, depth 50, seed %d" % (args.width, args.height, args.spp, args.seed),
                        "parallelism": "image tiles 8x8 dealt round-robin to %d GPU(s), RCCL framebuffer gather" % world_size,
-                       "kernel": "pt_kernel<%s>(f64 primitives, scene %s)" % ({1: "reference-order stackless", 2: "SAH-BVH2 accel, f32 conservative boxes"}.get(last.get("kernel_used"), "?"),
+                       "kernel": "pt_kernel<%s>(f64 primitives, scene %s)" % ({1: "reference-order stackless", 2: "SAH-BVH2 accel, f32 conservative boxes", 3: "SAH-BVH2 accel, early-restart schedule"}.get(last.get("kernel_used"), "?"),
                                                                               "in LDS" if last.get("scene_in_lds") else "in L2/HBM"),
                        "block_threads": last.get("block_threads"), "grid_blocks": last.get("grid_blocks"),
                        "spp_chunk": last.get("spp_chunk")},

@@ -75,8 +75,9 @@ typedef struct rt_params {
     int32_t rank;        /* image-tile partition: this call renders tiles t with t % world == rank */
     int32_t world;       /* 1 = whole image */
     int32_t spp_chunk;   /* samples per pixel per kernel launch; 0 = auto */
-    int32_t kernel;      /* 0 = auto; 1 = reference-order stackless traversal; 2 = SAH-BVH2 accel traversal.
-                            Both give bit-identical images (same f64 primitive tests, same tie rule). */
+    int32_t kernel;      /* 0 = auto; 1 = reference-order stackless traversal; 2 = SAH-BVH2 accel traversal;
+                            (default when an accel exists); 3 = kernel 2 with an early-restart schedule (diagnostic).
+                            All give bit-identical images (same f64 primitive tests, same tie rule). */
     int32_t device;      /* HIP device ordinal; -1 = current */
     int32_t reserved;
 } rt_params;

@@ -22,6 +22,9 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "../common/flat.h"
@@ -30,7 +33,9 @@
 
 namespace rtamd {
 
-#define PT_BLOCK 512
+#ifndef PT_BLOCK
+#define PT_BLOCK 1024
+#endif
 
 #define HIP_CHECK(expr)                                                                                  \
     do {                                                                                                 \
@@ -159,6 +164,7 @@ struct RenderK {
     int sub_spp, subs_per_tile, n_units;
     int tiles_x, rank, world;
     int chunk_spp;  // sample-buffer stride
+    int restart_th; // kernel 3: lanes that must have finished a segment before the wave shades
 };
 
 // ------------------------------------------------------ intersection ------
@@ -476,13 +482,31 @@ struct Rec {  // HitRecord, hit.rs:7-14
     int mat;
 };
 
+// Sign of sin(a) without evaluating it: with k = floor(a/pi), sin(a) < 0 iff k is odd.  r = a*(1/pi) carries an
+// absolute error < 2.3e-16*|r| < 6e-11 for |r| < 2^18, so k is the true floor whenever frac(r) is farther than
+// 1e-9 from 0 and 1; otherwise (and for huge |a|) the caller falls back to the real sin().  Returns 0 (+), 1 (-), 2 (?).
+DEV int sin_sign_fast(double a) {
+    const double INV_PI = 0.318309886183790671537767526745028724;
+    double r = a * INV_PI;
+    double kf = floor(r);
+    double f = r - kf;
+    if (!(fabs(r) < 262144.0) || f < 1e-9 || f > 1.0 - 1e-9) return 2;
+    return ((int)kf) & 1;
+}
 DEV D3 tex_color(const Acc& A, int tex, const Rec& rec) {  // material.rs:52-84
     const TexDev* t = &A.texs[tex];
     int type = t->type;
-    if (type == 1) {  // CheckerTexture: .0 when sines < 0
+    if (type == 1) {  // CheckerTexture: .0 when sines < 0 ; only the SIGN of sin(10x)sin(10y)sin(10z) is used
         D3 p = rec.p;
-        double sines = sin(10. * p.x) * sin(10. * p.y) * sin(10. * p.z);
-        t = &A.texs[(sines < 0.) ? t->t0 : t->t1];
+        int s0 = sin_sign_fast(10. * p.x), s1 = sin_sign_fast(10. * p.y), s2 = sin_sign_fast(10. * p.z);
+        bool negative;
+        if ((s0 | s1 | s2) & 2) {  // within 1e-9 of a zero of some factor (or huge argument): evaluate literally
+            double sines = sin(10. * p.x) * sin(10. * p.y) * sin(10. * p.z);
+            negative = sines < 0.;
+        } else {
+            negative = ((s0 ^ s1 ^ s2) & 1) != 0;  // |factors| > 3e-9, so the product cannot underflow to zero
+        }
+        t = &A.texs[negative ? t->t0 : t->t1];
         type = 0;
     }
     if (type == 0) return mk(t->color[0], t->color[1], t->color[2]);
@@ -716,6 +740,250 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
     }
 }
 
+
+// ------------------------------------------------------- pt_kernel_sm (kernel 3) ---
+// EXPERIMENTAL / DIAGNOSTIC (not the default): kernel 2's work with an EARLY-RESTART schedule and optional
+// per-phase schedule statistics (RTAMD_SM_STATS=1).  Measured on scene_500: restarting early does not pay
+// (threshold 24: -20 %, 56: +2 %), because shading then runs with few lanes; kept for its instrumentation.
+// Kernel 2 shades only when every lane of the wave has finished its traversal, so a lane whose ray left the
+// scene after 3 nodes idles while a neighbour visits 40 (measured: 33 % VALU lane utilisation).  Here the
+// traversal state (cur, stack pointer, ray, best hit) persists across rounds: the wave leaves the traversal
+// loop as soon as SM_RESTART lanes (or all live ones) are done, shades / regenerates just those, and they
+// re-enter traversal at the root while the others resume where they stopped.
+// Scheduling changes nothing a lane computes: results stay bit-identical to kernels 1 and 2.
+#define SM_RESTART 56
+
+template <bool LDS, bool GENERAL>
+__global__ void __launch_bounds__(PT_BLOCK) pt_kernel_sm(FlatView sv, const CamK* __restrict__ camp, RenderK rk, double* __restrict__ samples,
+                                                         unsigned int* __restrict__ counter, int* __restrict__ err,
+                                                         unsigned long long* __restrict__ stats) {
+    // optional schedule statistics (RTAMD_SM_STATS=1): per phase, {wave-level executions, lane participations}
+    unsigned long long st_w[4] = {0, 0, 0, 0}, st_l[4] = {0, 0, 0, 0};
+#define SM_STAT(ph, active)                                         \
+    if (stats) {                                                    \
+        st_w[ph] += 1;                                              \
+        st_l[ph] += (unsigned long long)__popcll(__ballot(active)); \
+    }
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint32_t st_begin = sv.stage2_begin, st_end = sv.stage2_end;
+    Acc A;
+    if (LDS) {
+        const uint4* src = (const uint4*)(sv.base + st_begin);
+        uint4* dst = (uint4*)smem;
+        for (uint32_t i = threadIdx.x; i < (st_end - st_begin) / 16; i += blockDim.x) dst[i] = src[i];
+        __syncthreads();
+        A = make_acc(smem - st_begin, sv.base, sv);
+    } else {
+        A = make_acc(sv.base, sv.base, sv);
+    }
+    uint32_t* stk = (uint32_t*)(smem + (LDS ? (st_end - st_begin) : 0u)) + threadIdx.x;
+    const int stride = (int)blockDim.x;
+    const int lane = threadIdx.x & 63;
+    const uint64_t lanemask_lt = (1ull << lane) - 1ull;
+    const double t_min = rk.t_min;
+
+    for (;;) {
+        unsigned int unit = 0;
+        if (lane == 0) unit = atomicAdd(counter, 1u);
+        unit = __builtin_amdgcn_readfirstlane(unit);
+        if (unit >= (unsigned)rk.n_units) break;
+        const int lt = (int)(unit / (unsigned)rk.subs_per_tile);
+        const int sub_i = (int)(unit - (unsigned)lt * (unsigned)rk.subs_per_tile);
+        const int tile = lt * rk.world + rk.rank;
+        const int tx = tile % rk.tiles_x, ty = tile / rk.tiles_x;
+        const int s0 = rk.s_begin + sub_i * rk.sub_spp;
+        const int s1 = min(s0 + rk.sub_spp, rk.s_end);
+        const int pool = (s1 - s0) * TILE_PIX;
+        int next = 0;
+
+        bool alive = false;
+        D3 wo = mk(0, 0, 0), wd = mk(0, 0, 1);  // world-space ray of the current segment
+        D3 o = wo, d = wd;                        // GENERAL: ray in the space being traversed (object space inside a Transform)
+        double a = 1.;
+        Ray32 r = make_ray32(wo, mk(1, 1, 1), t_min, INFINITY);
+        Hit h;
+        h.t = INFINITY; h.node = -1; h.xf = -1; h.kp = 0;
+        uint32_t cur = REF_DONE;
+        int sp = 0, cur_xf = -1;
+        D3 beta = mk(1, 1, 1), L = mk(0, 0, 0);
+        int depth = 0;
+        size_t out_idx = 0;
+        Rng rng;
+        rng.s = 0;
+
+        for (;;) {
+            // ---- regeneration: dead lanes pull the next (pixel, sample) of the pool (camera.rs:97-99, :57-64) ----
+            const uint64_t dead = __ballot(!alive);
+            if (dead != 0ull && next < pool) {
+                const int k = next + __popcll(dead & lanemask_lt);
+                next = min(next + (int)__popcll(dead), pool);
+                SM_STAT(0, !alive && k < pool);
+                if (!alive && k < pool) {
+                    const int pix = k & (TILE_PIX - 1), s = s0 + (k >> 6);
+                    const int x = tx * TILE_W + (pix & (TILE_W - 1)), y = ty * TILE_H + (pix >> 3);
+                    if (x < rk.width && y < rk.height) {
+                        const CamK cam = *camp;
+                        rng.seed_stream(rk.seed, (uint64_t)y * (uint64_t)rk.width + (uint64_t)x, (uint64_t)s);
+                        double u = ((double)x + rng.gen_f64()) / (double)(rk.width - 1);
+                        double v = ((double)y + rng.gen_f64()) / (double)(rk.height - 1);
+                        double st = 1.0 - v;
+                        D3 rd = muls(random_in_unit_disk(rng), cam.lens_radius);
+                        D3 offset = add(muls(cam.u, rd.x), muls(cam.v, rd.y));
+                        wo = add(cam.origin, offset);
+                        wd = sub(sub(add(add(cam.llc, muls(cam.horizontal, u)), muls(cam.vertical, st)), cam.origin), offset);
+                        beta = mk(1., 1., 1.);
+                        L = mk(0., 0., 0.);
+                        depth = rk.max_depth;
+                        out_idx = ((size_t)((size_t)lt * rk.chunk_spp + (s - rk.s_begin)) * TILE_PIX + pix) * 3;
+                        alive = true;
+                        // begin the first segment: World::hit(ray, t_min, +inf)
+                        if (GENERAL) { o = wo; d = wd; }
+                        a = sqlen(wd);
+                        r = make_ray32(wo, mk(1.0 / wd.x, 1.0 / wd.y, 1.0 / wd.z), t_min, INFINITY);
+                        h.t = INFINITY; h.node = -1; h.xf = -1; h.kp = 0;
+                        cur = A.root2;
+                        sp = 0;
+                        cur_xf = -1;
+                    }
+                }
+            }
+            const int n_alive = __popcll(__ballot(alive));
+            if (n_alive == 0) {
+                if (next >= pool) break;
+                continue;
+            }
+            const int want_done = min(rk.restart_th, n_alive);
+
+            // ---- traversal, resumable: runs until `want_done` live lanes have finished their segment ----
+            for (;;) {
+                while (alive && (cur >> REF_TAG_SHIFT) == 0u) {  // inner node: both children, f32 conservative
+                    SM_STAT(1, true);
+                    const float4* p = A.n2 + 4 * cur;
+                    float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+                    float e0, e1;
+                    bool h0 = box32(q0.x, q0.z, q1.x, q1.z, q2.x, q2.z, r, e0);
+                    bool h1 = box32(q0.y, q0.w, q1.y, q1.w, q2.y, q2.w, r, e1);
+                    uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
+                    if (h0 && h1) {
+                        bool swap = e1 < e0;
+                        stk[sp * stride] = swap ? c0 : c1;
+                        sp++;
+                        cur = swap ? c1 : c0;
+                    } else if (h0 || h1) {
+                        cur = h0 ? c0 : c1;
+                    } else if (sp > 0) {
+                        sp--;
+                        cur = stk[sp * stride];
+                    } else {
+                        cur = REF_DONE;
+                    }
+                }
+                if ((int)__popcll(__ballot(alive && cur == REF_DONE)) >= want_done) break;
+                SM_STAT(2, alive && cur != REF_DONE);
+                if (alive && cur != REF_DONE) {
+                    const D3 ro = GENERAL ? o : wo, rdir = GENERAL ? d : wd;
+                    bool entered = false;
+                    if ((cur >> REF_TAG_SHIFT) == 1u) {  // leaf: the reference's f64 primitive tests
+                        uint32_t first = cur & REF_LEAF_FIRST_MASK, cnt = ((cur >> REF_LEAF_COUNT_SHIFT) & 7u) + 1u;
+                        uint32_t enter = REF_DONE;
+                        for (uint32_t i = 0; i < cnt; i++) {
+                            uint2 it = A.items2[first + i];
+                            uint32_t kind = it.x & NK_MASK, pl = it.x >> NK_BITS;
+                            double t = 0.;
+                            bool got = false;
+                            if (kind == NK_SPHERE) {
+                                got = sphere_hit(A.spheres + 2 * pl, ro, rdir, a, t_min, h.t, t);
+                            } else if (GENERAL) {
+                                if (kind == NK_RECT_YZ || kind == NK_RECT_XZ || kind == NK_RECT_XY) {
+                                    got = rect_hit(A.rects + 3 * pl, (int)kind - (int)NK_RECT_YZ, ro, rdir, t_min, h.t, t);
+                                } else if (kind == NK_TRI) {
+                                    double b1, b2;
+                                    got = tri_hit(A, A.tris[pl], ro, rdir, t_min, h.t, t, b1, b2);
+                                } else {
+                                    enter = pl;
+                                }
+                            }
+                            if (got && (t < h.t || (int)it.y > h.node || !(t == t))) {
+                                h.t = t;
+                                h.node = (int)it.y;
+                                h.xf = cur_xf;
+                                h.kp = it.x;
+                                r.best = f32_up(t);
+                            }
+                        }
+                        if (GENERAL && enter != REF_DONE) {  // Transform::hit entry, transform.rs:153-156
+                            uint2 in = A.inst2[enter];
+                            const double* Minv = A.xforms + 32 * in.x;
+                            o = xf_point(Minv, wo);
+                            d = xf_dir(Minv, wd);
+                            a = sqlen(d);
+                            cur_xf = (int)in.x;
+                            r = make_ray32(o, mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z), t_min, h.t);
+                            stk[sp * stride] = REF_RESTORE;
+                            sp++;
+                            cur = in.y;
+                            entered = true;
+                        }
+                    } else if (GENERAL) {  // REF_RESTORE: back to world space
+                        o = wo;
+                        d = wd;
+                        a = sqlen(d);
+                        cur_xf = -1;
+                        r = make_ray32(o, mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z), t_min, h.t);
+                    }
+                    if (!entered) {
+                        if (sp > 0) {
+                            sp--;
+                            cur = stk[sp * stride];
+                        } else {
+                            cur = REF_DONE;
+                        }
+                    }
+                }
+            }
+
+            // ---- shade the finished lanes: sample_ray's loop body after World::hit, photon_mapper.rs:336-362 ----
+            SM_STAT(3, alive && cur == REF_DONE);
+            if (alive && cur == REF_DONE) {
+                bool done = true;
+                if (h.node >= 0 && depth > 0) {
+                    depth -= 1;
+                    Rec rec = materialize<GENERAL>(A, h, wo, wd, err);
+                    D3 emitted, att, ndir;
+                    bool scattered = shade(A, rec, wd, rng, emitted, att, ndir, err);
+                    L = add(L, elemul(beta, emitted));
+                    if (scattered) {
+                        beta = elemul(beta, att);
+                        wo = rec.p;
+                        wd = ndir;
+                        done = false;
+                    }
+                }
+                if (done) {
+                    samples[out_idx] = L.x;
+                    samples[out_idx + 1] = L.y;
+                    samples[out_idx + 2] = L.z;
+                    alive = false;
+                } else {  // next segment
+                    if (GENERAL) { o = wo; d = wd; }
+                    a = sqlen(wd);
+                    r = make_ray32(wo, mk(1.0 / wd.x, 1.0 / wd.y, 1.0 / wd.z), t_min, INFINITY);
+                    h.t = INFINITY; h.node = -1; h.xf = -1; h.kp = 0;
+                    cur = A.root2;
+                    sp = 0;
+                    cur_xf = -1;
+                }
+            }
+        }
+    }
+    if (stats && lane == 0) {
+        for (int i = 0; i < 4; i++) {
+            atomicAdd(&stats[2 * i], st_w[i]);
+            atomicAdd(&stats[2 * i + 1], st_l[i]);
+        }
+    }
+}
+
 // per pixel: accum += samples in sample order (camera.rs:96-101). One thread per (tile, pixel).
 __global__ void reduce_kernel(const double* __restrict__ samples, double* __restrict__ accum, int64_t n_pix, int chunk_spp,
                               int n_s, int first) {
@@ -878,61 +1146,138 @@ struct Events {
     }
 };
 
+// ---- per-device caches: properties and render workspaces (no hipMalloc/hipFree/property queries per call) ----
+struct DevInfo {
+    int cus = 0;
+    size_t lds_max = 64 * 1024;
+};
+static std::mutex g_mu;
+static std::map<int, DevInfo> g_devinfo;
+static const DevInfo& dev_info(int dev) {
+    std::lock_guard<std::mutex> g(g_mu);
+    auto it = g_devinfo.find(dev);
+    if (it != g_devinfo.end()) return it->second;
+    DevInfo di;
+    hipDeviceProp_t prop;
+    HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+    di.cus = prop.multiProcessorCount;
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess && v > 0) di.lds_max = (size_t)v;
+    if (di.lds_max > 160 * 1024) di.lds_max = 160 * 1024;
+    return g_devinfo.emplace(dev, di).first->second;
+}
+// A workspace = the sample buffer, the accumulator and a small block {work counter, error flag, camera, stats}.
+// Kept for the life of the process and reused by later calls on the same device (grown when a call needs more).
+struct Workspace {
+    int device = -1;
+    bool busy = false;
+    void *samples = nullptr, *accum = nullptr, *small = nullptr;
+    size_t samples_bytes = 0, accum_bytes = 0;
+};
+static std::vector<Workspace*> g_ws;
+static const size_t WS_SMALL = 1024;
+struct WorkspaceLease {
+    Workspace* w = nullptr;
+    WorkspaceLease(int dev, size_t need_samples, size_t need_accum) {
+        {
+            std::lock_guard<std::mutex> g(g_mu);
+            for (Workspace* c : g_ws)
+                if (c->device == dev && !c->busy) {
+                    w = c;
+                    break;
+                }
+            if (!w) {
+                w = new Workspace();
+                w->device = dev;
+                g_ws.push_back(w);
+            }
+            w->busy = true;
+        }
+        try {
+            if (!w->small) HIP_CHECK(hipMalloc(&w->small, WS_SMALL));
+            if (w->samples_bytes < need_samples) {
+                if (w->samples) (void)hipFree(w->samples);
+                w->samples = nullptr;
+                w->samples_bytes = 0;
+                HIP_CHECK(hipMalloc(&w->samples, need_samples));
+                w->samples_bytes = need_samples;
+            }
+            if (w->accum_bytes < need_accum) {
+                if (w->accum) (void)hipFree(w->accum);
+                w->accum = nullptr;
+                w->accum_bytes = 0;
+                HIP_CHECK(hipMalloc(&w->accum, need_accum));
+                w->accum_bytes = need_accum;
+            }
+        } catch (...) {
+            std::lock_guard<std::mutex> g(g_mu);
+            w->busy = false;
+            throw;
+        }
+    }
+    ~WorkspaceLease() {
+        std::lock_guard<std::mutex> g(g_mu);
+        w->busy = false;
+    }
+};
+
 typedef void (*pt_fn)(FlatView, CamK, RenderK, double*, unsigned int*, int*);
+typedef void (*pt_sm_fn)(FlatView, const CamK*, RenderK, double*, unsigned int*, int*, unsigned long long*);
 
 void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& plan, double* d_tiles, void* stream_, rt_stats* st) {
     if (!s.committed) throw RtError(RT_ERR_NOT_COMMITTED, "scene not committed");
     hipStream_t stream = (hipStream_t)stream_;
     int dev = 0;
     HIP_CHECK(hipGetDevice(&dev));
-    hipDeviceProp_t prop;
-    HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+    const DevInfo& di = dev_info(dev);
 
     FlatView view = s.flat.view;
     view.base = device_blob(s, dev);
     const bool general = (view.kinds_mask & ~((1u << NK_BOX) | (1u << NK_SPHERE))) != 0;
-    size_t lds_max = 64 * 1024;
-    {
-        int v = 0;
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess && v > 0) lds_max = (size_t)v;
-        if (lds_max > 160 * 1024) lds_max = 160 * 1024;
-    }
+    const size_t lds_max = di.lds_max;
     // kernel 2 (accel) is the default when an accel exists and its padding covers this camera's origin
     // (flatten.cpp: boxes are padded for ray origins up to origin_limit2); otherwise kernel 1 (reference order).
     double cam_abs = std::fmax(std::fmax(std::fabs(cam.origin[0]), std::fabs(cam.origin[1])), std::fabs(cam.origin[2])) + std::fabs(cam.lens_radius);
     const bool accel_usable = view.accel_ok && cam_abs <= view.origin_limit2 && std::isfinite(cam_abs);
     int kernel = plan.kernel;
     if (kernel == 0) kernel = accel_usable ? 2 : 1;
-    if (kernel == 2 && !accel_usable)
+    if (kernel >= 2 && !accel_usable)
         throw RtError(RT_ERR_UNSUPPORTED, "kernel 2 requested but no usable accel for this scene/camera (unbounded item, depth overflow, or camera "
                                           "farther than 64x the scene extent); use kernel 0/1");
-    const size_t stack_bytes = (kernel == 2) ? (size_t)view.stack2 * PT_BLOCK * sizeof(uint32_t) : 0;
-    const size_t hot_bytes = (kernel == 2) ? (size_t)(view.stage2_end - view.stage2_begin) : (size_t)view.stage_bytes;
+    const size_t stack_bytes = (kernel >= 2) ? (size_t)view.stack2 * PT_BLOCK * sizeof(uint32_t) : 0;
+    const size_t hot_bytes = (kernel >= 2) ? (size_t)(view.stage2_end - view.stage2_begin) : (size_t)view.stage_bytes;
     if (stack_bytes > lds_max) throw RtError(RT_ERR_UNSUPPORTED, "accel stack does not fit LDS");
     const bool lds = hot_bytes > 0 && hot_bytes + stack_bytes <= lds_max;
-    pt_fn fn;
-    if (kernel == 2)
+    pt_fn fn = nullptr;
+    pt_sm_fn fn_sm = nullptr;
+    if (kernel == 3)
+        fn_sm = lds ? (general ? pt_kernel_sm<true, true> : pt_kernel_sm<true, false>) : (general ? pt_kernel_sm<false, true> : pt_kernel_sm<false, false>);
+    else if (kernel == 2)
         fn = lds ? (general ? pt_kernel<true, true, 2> : pt_kernel<true, false, 2>) : (general ? pt_kernel<false, true, 2> : pt_kernel<false, false, 2>);
     else
         fn = lds ? (general ? pt_kernel<true, true, 1> : pt_kernel<true, false, 1>) : (general ? pt_kernel<false, true, 1> : pt_kernel<false, false, 1>);
     const size_t smem = (lds ? hot_bytes : 0) + stack_bytes;
-    if (smem > 48 * 1024) HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    const void* fptr = (kernel == 3) ? (const void*)fn_sm : (const void*)fn;
+    if (smem > 48 * 1024) HIP_CHECK(hipFuncSetAttribute(fptr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     int blocks_per_cu = 0;
-    HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, (const void*)fn, PT_BLOCK, smem));
+    HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, fptr, PT_BLOCK, smem));
     if (blocks_per_cu < 1) blocks_per_cu = 1;
-    const int grid = prop.multiProcessorCount * blocks_per_cu;
+    const int grid = di.cus * blocks_per_cu;
 
     const int64_t n_pix = plan.tiles_owned * TILE_PIX;
-    DevBuf samples, accum, counter, err;
-    samples.alloc((size_t)n_pix * plan.spp_chunk * 3 * sizeof(double));
-    accum.alloc((size_t)n_pix * 3 * sizeof(double));
-    counter.alloc(sizeof(unsigned int));
-    err.alloc(sizeof(int));
-    HIP_CHECK(hipMemsetAsync(err.p, 0, sizeof(int), stream));
-
+    WorkspaceLease lease(dev, std::max<size_t>(16, (size_t)n_pix * plan.spp_chunk * 3 * sizeof(double)),
+                         std::max<size_t>(16, (size_t)n_pix * 3 * sizeof(double)));
+    struct Ptr {
+        void* p;
+    };
+    char* small = (char*)lease.w->small;
+    Ptr samples{lease.w->samples}, accum{lease.w->accum}, counter{small}, err{small + 16}, camk{small + 64}, smstats{small + 512};
+    const bool want_stats = getenv("RTAMD_SM_STATS") != nullptr;
+    HIP_CHECK(hipMemsetAsync(small, 0, WS_SMALL, stream));
     Events events;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pt_ev, red_ev;
     CamK ck = to_camk(cam);
+    HIP_CHECK(hipMemcpyAsync(camk.p, &ck, sizeof(CamK), hipMemcpyHostToDevice, stream));
     int launches = 0;
     for (int s0 = 0; s0 < plan.spp; s0 += plan.spp_chunk) {
         const int s1 = std::min(s0 + plan.spp_chunk, plan.spp);
@@ -947,12 +1292,18 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
         rk.n_units = (int)units;
         rk.tiles_x = plan.tiles_x; rk.rank = plan.rank; rk.world = plan.world;
         rk.chunk_spp = plan.spp_chunk;
+        rk.restart_th = SM_RESTART;
+        if (const char* e = getenv("RTAMD_SM_RESTART")) rk.restart_th = std::max(1, atoi(e));  // tuning knob (A/B runs)
         HIP_CHECK(hipMemsetAsync(counter.p, 0, sizeof(unsigned int), stream));
         hipEvent_t e0 = events.make(), e1 = events.make(), e2 = events.make();
         HIP_CHECK(hipEventRecord(e0, stream));
         if (rk.n_units > 0) {
-            hipLaunchKernelGGL(fn, dim3(grid), dim3(PT_BLOCK), smem, stream, view, ck, rk, (double*)samples.p, (unsigned int*)counter.p,
-                               (int*)err.p);
+            if (kernel == 3)
+                hipLaunchKernelGGL(fn_sm, dim3(grid), dim3(PT_BLOCK), smem, stream, view, (const CamK*)camk.p, rk, (double*)samples.p,
+                                   (unsigned int*)counter.p, (int*)err.p, (unsigned long long*)(want_stats ? smstats.p : nullptr));
+            else
+                hipLaunchKernelGGL(fn, dim3(grid), dim3(PT_BLOCK), smem, stream, view, ck, rk, (double*)samples.p, (unsigned int*)counter.p,
+                                   (int*)err.p);
             HIP_CHECK(hipGetLastError());
         }
         HIP_CHECK(hipEventRecord(e1, stream));
@@ -995,6 +1346,14 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
         st->grid_blocks = grid;
         st->spp_chunk = plan.spp_chunk;
         st->scene_bytes = s.flat.blob.size();
+    }
+    if (want_stats && kernel == 3) {
+        unsigned long long hs[8];
+        HIP_CHECK(hipMemcpy(hs, smstats.p, sizeof(hs), hipMemcpyDeviceToHost));
+        const char* names[4] = {"regen", "inner", "leaf", "shade"};
+        for (int i = 0; i < 4; i++)
+            fprintf(stderr, "[rtamd sm-stats] %-5s wave-execs %llu lane-participations %llu utilisation %.1f%%\n", names[i], hs[2 * i], hs[2 * i + 1],
+                    hs[2 * i] ? 100.0 * hs[2 * i + 1] / (64.0 * hs[2 * i]) : 0.0);
     }
     if (h_err) throw RtError(RT_ERR_UNIT_ZERO, "unitizing zero vector (device)");
 }

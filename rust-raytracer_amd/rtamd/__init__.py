@@ -14,7 +14,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(_ROOT, "librtamd.so")
+LIB_PATH = os.environ.get("RTAMD_LIB") or os.path.join(_ROOT, "librtamd.so")  # RTAMD_LIB: A/B builds only
 
 RT_OK = 0
 ERR_NAMES = {

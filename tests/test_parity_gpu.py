@@ -54,7 +54,7 @@ def test_device_sqrt_and_divide_are_correctly_rounded():
         assert np.array_equal(rtamd.debug_math(1, a, b), a / b)
 
 
-@pytest.mark.parametrize("kernel", [1, 2])
+@pytest.mark.parametrize("kernel", [1, 2, 3])
 @pytest.mark.parametrize("name,w,h,spp,aspect", [
     ("scene_10.json", 64, 36, 16, 16.0 / 9.0),      # C1 at reduced size
     ("scene_10.yaml", 40, 24, 4, None),
@@ -108,14 +108,14 @@ def test_depth_limit_semantics():
     """Q12: depth is tested after the hit and before emission: max_depth hits contribute."""
     world, cam, ref = _pair("scene_500.json")
     for depth in (0, 1, 2, 5):
-        img, _ = world.render(cam, width=32, height=32, spp=4, seed=1, max_depth=depth, kernel=1 + depth % 2)
+        img, _ = world.render(cam, width=32, height=32, spp=4, seed=1, max_depth=depth, kernel=1 + depth % 3)
         exp, _ = ref.render(32, 32, 4, max_depth=depth, seed=1)
         _assert_same(img, exp, "max_depth=%d" % depth)
     z, _ = world.render(cam, width=16, height=16, spp=2, seed=1, max_depth=0)
     assert not z.any()
 
 
-@pytest.mark.parametrize("kernel", [1, 2])
+@pytest.mark.parametrize("kernel", [1, 2, 3])
 def test_cornell_box_bit_exact(kernel):
     """C3 geometry: rects, cube, transform(mesh), glass + mirror spheres, rect light (scene.rs:16-112)."""
     import oracle
@@ -129,7 +129,7 @@ def test_cornell_box_bit_exact(kernel):
     assert img.max() > 0
 
 
-@pytest.mark.parametrize("kernel", [1, 2])
+@pytest.mark.parametrize("kernel", [1, 2, 3])
 def test_first_hit_records_match_oracle(kernel):
     """World::hit on explicit rays: t, p, normal, front_face identical to the oracle's HitRecord."""
     import oracle
@@ -144,7 +144,7 @@ def test_first_hit_records_match_oracle(kernel):
         rays[:, :3] = origin
         target = rng.random((n, 3)) * scale if scale > 100 else (rng.random((n, 3)) - 0.5) * scale
         rays[:, 3:] = target - rays[:, :3]
-        out = world.debug_hit(rays, t_min=1e-3, kernel=kernel)
+        out = world.debug_hit(rays, t_min=1e-3, kernel=min(kernel, 2))   # kernel 3 = kernel 2's traversal, other scheduling
         nhit = 0
         for i in range(n):
             h = ref.hit(rays[i, :3], rays[i, 3:], t_min=1e-3)
@@ -203,4 +203,5 @@ def test_kernels_agree_on_random_sphere_soups_with_ties():
     cam = rtamd.Camera(((0, 0, -20), (0, 0, 0)), (0, 1, 0), 40, 1.0, 0.0, 20.0)
     i1, _ = w.render(cam, width=48, height=48, spp=4, kernel=1)
     i2, _ = w.render(cam, width=48, height=48, spp=4, kernel=2)
-    assert np.array_equal(i1, i2)
+    i3, _ = w.render(cam, width=48, height=48, spp=4, kernel=3)
+    assert np.array_equal(i1, i2) and np.array_equal(i1, i3)
