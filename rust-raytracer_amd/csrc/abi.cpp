@@ -317,17 +317,21 @@ static RenderPlan make_plan(const rt_params* p) {
     pl.tiles_owned = (pl.tiles_total - p->rank + p->world - 1) / p->world;
     if (pl.tiles_owned < 0) pl.tiles_owned = 0;
     pl.kernel = p->kernel;
-    // sample-buffer budget: <= ~1.5 GiB per launch
+    // sample-buffer budget: <= ~1.5 GiB per launch (24 B per pixel-sample), at most 256 spp per launch
     int chunk = p->spp_chunk;
     if (chunk <= 0) {
         int64_t per_spp = std::max<int64_t>(1, pl.tiles_owned) * TILE_PIX * 3 * 8;
         int64_t c = (int64_t(3) << 29) / per_spp;
-        chunk = (int)std::max<int64_t>(1, std::min<int64_t>(c, 64));
+        chunk = (int)std::max<int64_t>(1, std::min<int64_t>(c, 256));
     }
     if (chunk > p->spp) chunk = p->spp;
     pl.spp_chunk = chunk;
-    // one work unit = 64 pixels x sub_spp samples; keep >= ~8 units per resident wave when possible
-    pl.sub_spp = std::min(chunk, 16);
+    // one work unit = 64 pixels x sub_spp samples (a wave drains it with in-wave regeneration).  Large pools amortise
+    // the drain tail; many units balance the 4096 resident waves: aim at >= ~12 units per wave, 4 <= sub_spp <= 16.
+    int64_t want_units = 12 * 4096;
+    int64_t subs = std::max<int64_t>(1, want_units / std::max<int64_t>(1, pl.tiles_owned));
+    int sub = (int)((chunk + subs - 1) / subs);
+    pl.sub_spp = std::max(std::min(chunk, 4), std::min(sub, 16));
     return pl;
 }
 

@@ -7,9 +7,9 @@
 // next node and a failed box test jumps to `skip`.  No stack, no pointers.
 //
 // Everything lives in one blob so it can be staged into LDS with one copy:
-//   hot  [meta | boxes | spheres | rects | tris | xforms | vpos | n2 | items2 | inst2]
-//        kernel 1 stages [meta..vpos], kernel 2 stages [spheres..inst2] into LDS when it fits
-//   cold [sphere_mat | rect_mat | mats | texs | vnrm | texels]        <- read once per segment, stays global
+//   hot  [meta | boxes | spheres | rects | tris | tripre | xforms | n2 | items2 | inst2]
+//        kernel 1 stages [meta..xforms], kernel 2 stages [spheres..inst2] into LDS when it fits
+//   cold [sphere_mat | rect_mat | mats | texs | vpos | vnrm | texels] <- read once per segment, stays global
 // each section 16-byte aligned.  f64 payloads are the reference's own values.
 #pragma once
 #include <stdint.h>
@@ -87,7 +87,7 @@ struct FlatView {  // by-value kernel argument
     uint32_t root2;           // root ref
     uint32_t stage2_begin, stage2_end;  // kernel 2 stages [stage2_begin, stage2_end): [spheres|rects|tris|xforms|vpos|n2|items2|inst2]
     uint32_t stack2;          // stack entries a lane can need
-    uint32_t pad0;
+    uint32_t off_tripre;      // per triangle {pa, pb-pa, pc-pa, pad}: 10 f64 (hot part, after tris)
     double origin_limit2;     // accel boxes are padded for ray origins with max-abs coordinate <= this (camera checked per render)
 };
 

@@ -115,6 +115,7 @@ struct Acc {  // typed views into the blob (LDS or global; the address space is 
     const double2* rects;    // 3 x double2: (a0,b0) (a1,b1) (k,-)
     const int* rect_mat;
     const uint4* tris;       // a,b,c,mat
+    const double2* tripre;   // 5 x double2 per triangle: pa, e0 = pb-pa, e1 = pc-pa (mesh.rs:69, hoisted to commit time)
     const double* xforms;    // 32 per transform: M^-1 then M, row-major
     const MatDev* mats;
     const TexDev* texs;
@@ -136,8 +137,9 @@ DEV Acc make_acc(P hot, const char* gbase, const FlatView& v) {  // hot: LDS cop
     a.spheres = (const double2*)(hot + v.off_spheres);
     a.rects = (const double2*)(hot + v.off_rects);
     a.tris = (const uint4*)(hot + v.off_tris);
+    a.tripre = (const double2*)(hot + v.off_tripre);
     a.xforms = (const double*)(hot + v.off_xforms);
-    a.vpos = (const double*)(hot + v.off_vpos);
+    a.vpos = (const double*)(gbase + v.off_vpos);
     a.sphere_mat = (const int*)(gbase + v.off_sphere_mat);
     a.rect_mat = (const int*)(gbase + v.off_rect_mat);
     a.mats = (const MatDev*)(gbase + v.off_mats);
@@ -227,9 +229,10 @@ DEV bool rect_hit(const double2* r, int axis, D3 o, D3 d, double t_min, double t
 }
 DEV D3 ld3(const double* p, uint32_t i) { return mk(p[3 * i], p[3 * i + 1], p[3 * i + 2]); }
 // Triangle::hit, mesh.rs:57-102 ; returns t and the barycentrics b1,b2
-DEV bool tri_hit(const Acc& A, uint4 tr, D3 o, D3 dir, double t_min, double t_max, double& t_out, double& b1o, double& b2o) {
-    D3 pa = ld3(A.vpos, tr.x), pb = ld3(A.vpos, tr.y), pc = ld3(A.vpos, tr.z);
-    D3 e0 = sub(pb, pa), e1 = sub(pc, pa);
+DEV bool tri_hit(const Acc& A, uint32_t tri, D3 o, D3 dir, double t_min, double t_max, double& t_out, double& b1o, double& b2o) {
+    const double2* q = A.tripre + 5 * tri;
+    double2 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4];
+    D3 pa = mk(q0.x, q0.y, q1.x), e0 = mk(q1.y, q2.x, q2.y), e1 = mk(q3.x, q3.y, q4.x);
     D3 s0 = cross(dir, e1);
     double dd = dot(s0, e0);
     if (dd == 0.0) return false;
@@ -296,7 +299,7 @@ DEV Hit traverse(const Acc& A, D3 wo, D3 wd, double t_min, double t_max) {
                 }
             } else if (kind == NK_TRI) {
                 double t, b1, b2;
-                if (tri_hit(A, A.tris[pl], o, d, t_min, h.t, t, b1, b2)) {
+                if (tri_hit(A, pl, o, d, t_min, h.t, t, b1, b2)) {
                     h.t = t;
                     h.node = (int)n;
                     h.xf = cur_xf;
@@ -429,7 +432,7 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
                         got = rect_hit(A.rects + 3 * pl, (int)kind - (int)NK_RECT_YZ, o, d, t_min, h.t, t);
                     } else if (kind == NK_TRI) {
                         double b1, b2;
-                        got = tri_hit(A, A.tris[pl], o, d, t_min, h.t, t, b1, b2);
+                        got = tri_hit(A, pl, o, d, t_min, h.t, t, b1, b2);
                     } else {  // NK_INSTANCE: descend into its object-space BVH after the remaining items
                         enter = pl;
                     }
@@ -565,7 +568,7 @@ DEV Rec materialize(const Acc& A, const Hit& h, D3 wo, D3 wd, int* err) {
         uint4 tr = A.tris[pl];
         rec.mat = (int)tr.w;
         double t, b1 = 0., b2 = 0.;
-        tri_hit(A, tr, o, d, -INFINITY, INFINITY, t, b1, b2);
+        tri_hit(A, pl, o, d, -INFINITY, INFINITY, t, b1, b2);
         double b0 = 1.0 - b1 - b2;
         D3 na = ld3(A.vnrm, tr.x), nb = ld3(A.vnrm, tr.y), nc = ld3(A.vnrm, tr.z);
         outward = unit(add(add(muls(na, b0), muls(nb, b1)), muls(nc, b2)), err);
@@ -898,7 +901,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_sm(FlatView sv, const CamK
                                     got = rect_hit(A.rects + 3 * pl, (int)kind - (int)NK_RECT_YZ, ro, rdir, t_min, h.t, t);
                                 } else if (kind == NK_TRI) {
                                     double b1, b2;
-                                    got = tri_hit(A, A.tris[pl], ro, rdir, t_min, h.t, t, b1, b2);
+                                    got = tri_hit(A, pl, ro, rdir, t_min, h.t, t, b1, b2);
                                 } else {
                                     enter = pl;
                                 }

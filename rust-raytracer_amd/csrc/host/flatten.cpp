@@ -25,6 +25,7 @@ struct Builder {
     std::vector<double> boxes, spheres, rects, xforms, vpos, vnrm;
     std::vector<int32_t> sphere_mat, rect_mat;
     std::vector<uint32_t> tris;
+    std::vector<double> tripre;  // per triangle: pa, e0 = pb - pa, e1 = pc - pa, pad (10 doubles = 80 B)
     std::map<int, uint32_t> sphere_of, rect_of, tri_of, xform_of;
     std::vector<uint32_t> mesh_base;
     uint32_t kinds = 0;
@@ -40,7 +41,7 @@ struct Builder {
     std::vector<size_t> ctx_stack{0};
     bool accel_ok = true;
 
-    void accel_item(int obj_id, const ObjectRec& o, uint32_t kp, uint32_t node_index) {
+    void accel_item(int obj_id, const ObjectRec& o, uint32_t kp, uint32_t node_index, const Box* tight = nullptr) {
         InstCtx& c = actx[ctx_stack.back()];
         if (!o.has_box) {
             accel_ok = false;
@@ -49,7 +50,7 @@ struct Builder {
         auto it = c.of.find(obj_id);
         if (it == c.of.end()) {
             c.of.emplace(obj_id, c.items.size());
-            c.items.push_back(AccelItem{o.box, kp, (int32_t)node_index});
+            c.items.push_back(AccelItem{tight ? *tight : o.box, kp, (int32_t)node_index});
         } else {
             c.items[it->second].order = (int32_t)node_index;  // the later visit wins ties (Q5/Q14)
         }
@@ -99,9 +100,25 @@ struct Builder {
                     it = tri_of.emplace(id, (uint32_t)(tris.size() / 4)).first;
                     uint32_t base = mesh_base[o.mesh];
                     tris.insert(tris.end(), {base + o.ia, base + o.ib, base + o.ic, (uint32_t)o.material});
+                    // what Triangle::hit recomputes per call (mesh.rs:69): edge = [pb - pa, pc - pa]; same f64 subtractions
+                    const double* P = s.meshes[o.mesh]->pos.data();
+                    const double *pa = P + 3 * o.ia, *pb = P + 3 * o.ib, *pc = P + 3 * o.ic;
+                    tripre.insert(tripre.end(), {pa[0], pa[1], pa[2], pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2], pc[0] - pa[0], pc[1] - pa[1],
+                                                 pc[2] - pa[2], 0.0});
                 }
                 uint32_t n = node(NK_TRI, it->second);
-                accel_item(id, o, NK_TRI | (it->second << NK_BITS), n);
+                {
+                    // accel: the TIGHT vertex box (the reference's +-0.1 object-space padding, mesh.rs:33-42, only serves its
+                    // own BVH; any box containing the triangle prunes correctly)
+                    const double* P = s.meshes[o.mesh]->pos.data();
+                    const double *pa = P + 3 * o.ia, *pb = P + 3 * o.ib, *pc = P + 3 * o.ic;
+                    Box tb;
+                    for (int a = 0; a < 3; a++) {
+                        tb.mn[a] = std::fmin(std::fmin(pa[a], pb[a]), pc[a]);
+                        tb.mx[a] = std::fmax(std::fmax(pa[a], pb[a]), pc[a]);
+                    }
+                    accel_item(id, o, NK_TRI | (it->second << NK_BITS), n, &tb);
+                }
                 break;
             }
             case OBJ_CUBE:
@@ -242,8 +259,8 @@ void flatten(rt_scene& s) {
     v.stage2_begin = v.off_spheres;
     v.off_rects = append(f.blob, b.rects);
     v.off_tris = append(f.blob, b.tris);
+    v.off_tripre = append(f.blob, b.tripre);
     v.off_xforms = append(f.blob, b.xforms);
-    v.off_vpos = append(f.blob, b.vpos);
     f.blob.resize((f.blob.size() + 15) & ~size_t(15));
     v.stage_bytes = (uint32_t)f.blob.size();
     if (!ab.ok) {
@@ -265,6 +282,7 @@ void flatten(rt_scene& s) {
     v.off_rect_mat = append(f.blob, b.rect_mat);
     v.off_mats = append(f.blob, mats);
     v.off_texs = append(f.blob, texs);
+    v.off_vpos = append(f.blob, b.vpos);  // kept for introspection; the kernels read tripre instead
     v.off_vnrm = append(f.blob, b.vnrm);
     v.off_texels = append(f.blob, texels);
     f.blob.resize((f.blob.size() + 15) & ~size_t(15));
