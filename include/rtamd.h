@@ -79,7 +79,9 @@ typedef struct rt_params {
                             (default when an accel exists); 3 = kernel 2 with an early-restart schedule (diagnostic).
                             All give bit-identical images (same f64 primitive tests, same tie rule). */
     int32_t device;      /* HIP device ordinal; -1 = current */
-    int32_t reserved;
+    int32_t integrator;  /* 0 = sample_ray as the reference structures it (BSDF sampling only; default);
+                            1 = light importance sampling: on Diffuse hits the direction is drawn from the
+                                0.5*lights + 0.5*cosine mixture pdf (book-3 MixturePDF semantics; needs rt_scene_set_lights) */
 } rt_params;
 
 typedef struct rt_stats {
@@ -147,6 +149,10 @@ int rt_object_bounding_box(const rt_scene* s, int object, double out_min_max[6])
 
 /* World::new(hitable_list, cam, lights) (world.rs:15-25): root = BVHNode::new(list) */
 int rt_world_new(rt_scene* s, int n, const int* objects, uint64_t bvh_seed);
+/* World::new's `lights: Vec<Arc<dyn Light>>` (world.rs:18; scene.rs:110 passes the XZRectLight): the objects that the
+ * mixture-pdf integrator samples.  Each must be a sphere or an XZ rectangle in world space (the reference's two Light
+ * impls, light.rs:67-86,127-146); RT_ERR_UNSUPPORTED for lights under a Transform. */
+int rt_scene_set_lights(rt_scene* s, int n, const int* objects);
 /* root = an existing object (e.g. the HitableList of a scene file) */
 int rt_scene_set_root(rt_scene* s, int object);
 /* scene.rs:16-112 cornell_box_scene(): the reference's only built-in scene, numbers verbatim.

@@ -62,7 +62,8 @@ def lib():
     L.orc_set_root.argtypes = [C.c_void_p, C.c_int]
     L.orc_bounding_box.argtypes = [C.c_void_p, C.c_int, c_double_p]
     L.orc_render.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_uint64,
-                             C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_double_p, c_u64_p]
+                             C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_double_p, c_u64_p, C.c_int]
+    L.orc_set_lights.argtypes = [C.c_void_p, C.c_int, c_int_p]
     L.orc_hit.argtypes = [C.c_void_p, C.c_int, c_double_p, c_double_p, C.c_double, C.c_double, c_double_p]
     L.orc_aabb_hit.argtypes = [c_double_p, c_double_p, c_double_p, C.c_double, C.c_double]
     L.orc_scatter.argtypes = [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p, C.c_int, C.c_double, C.c_double,
@@ -209,8 +210,14 @@ class Scene:
         return np.array(out[:])
 
     # queries
-    def render(self, width, height, spp, max_depth=50, t_min=1e-3, seed=1, window=None, n_jobs=64, n_workers=None):
-        """Camera::capture_image: returns (radiance f64 [wh,ww,3], counters dict)."""
+    def set_lights(self, ids):
+        """World::new's `lights` (world.rs:18); used by the mixture-pdf integrator only."""
+        arr = (C.c_int * len(ids))(*ids)
+        self._chk(self.L.orc_set_lights(self.h, len(ids), arr), "set_lights")
+
+    def render(self, width, height, spp, max_depth=50, t_min=1e-3, seed=1, window=None, n_jobs=64, n_workers=None, integrator=0):
+        """Camera::capture_image: returns (radiance f64 [wh,ww,3], counters dict).
+        integrator 0 = sample_ray (BSDF sampling), 1 = light/cosine mixture pdf."""
         if window is None:
             window = (0, 0, width, height)
         x0, y0, x1, y1 = window
@@ -219,7 +226,7 @@ class Scene:
         out = np.zeros((y1 - y0, x1 - x0, 3), dtype=np.float64)
         cnt = (C.c_uint64 * 7)()
         rc = self.L.orc_render(self.h, width, height, spp, max_depth, float(t_min), int(seed), x0, y0, x1, y1,
-                               n_jobs, n_workers, out.ctypes.data_as(c_double_p), cnt)
+                               n_jobs, n_workers, out.ctypes.data_as(c_double_p), cnt, int(integrator))
         self._chk(rc, "render")
         return out, dict(zip(COUNTER_NAMES, [int(c) for c in cnt]))
 
@@ -417,6 +424,7 @@ def cornell_box_scene(cube_obj_path, aspect_ratio=1.0, seed=1):
     # XZRectLight::new (light.rs:134-146): XZRectangle + DiffuseLight(ConstantTexture(flux)); scale is photon-only
     light_mat = sc.DiffuseLight(sc.ConstantTexture((1.0, 1.0, 1.0)))
     P, N, I = load_obj(cube_obj_path)
+    light = sc.XZRectangle((213.0, 227.0), (343.0, 332.0), 554.0, light_mat)
     items = [
         sc.YZRectangle((0.0, 0.0), (555.0, 555.0), 555.0, red),
         sc.YZRectangle((0.0, 0.0), (555.0, 555.0), 0.0, blue),
@@ -425,10 +433,11 @@ def cornell_box_scene(cube_obj_path, aspect_ratio=1.0, seed=1):
         sc.XYRectangle((0.0, 0.0), (555.0, 555.0), 555.0, white),
         sc.Sphere((140.0, 100.0, 240.0), 100.0, sc.Dielectric(1.5, sc.ConstantTexture((0.999, 0.999, 0.999)))),
         sc.Sphere((400.0, 100.0, 360.0), 100.0, sc.Metal(sc.ConstantTexture((0.999, 0.999, 0.999)), 0.0)),
-        sc.XZRectangle((213.0, 227.0), (343.0, 332.0), 554.0, light_mat),
+        light,
         sc.Transform((0.0, 0.0, 0.0), (50.0, 50.0, 50.0), (100.0, 50.0, 100.0), sc.Mesh(P, N, I, white, seed)),
         sc.Cube((300.0, 0.0, 100.0), (380.0, 100.0, 180.0), white),
     ]
     sc.World(items, seed)
+    sc.set_lights([light])  # scene.rs:110 vec![Arc::new(light)]
     sc.Camera((278.0, 278.0, -800.0), (278.0, 278.0, 278.0), (0.0, 1.0, 0.0), 50.0, aspect_ratio, 0.0, 10.0)
     return sc

@@ -678,6 +678,7 @@ struct Scene {
     std::vector<std::unique_ptr<Material>> materials;
     std::vector<std::unique_ptr<Hitable>> objects;
     const Hitable* root = nullptr;
+    std::vector<const Hitable*> lights;  // World::new's `lights` (world.rs:18): Sphere / XZ Rect hitables
     Camera cam;
     bool cam_set = false;
     std::string err;
@@ -707,11 +708,111 @@ static Vec3 sample_ray(const Scene& sc, Ray ray, int max_depth, double t_min, Ct
     return radiance;
 }
 
+// ----------------------------------------------------------------------------
+// Light importance sampling (SURVEY.md s8f "next" #2; north_star's "importance-sampled PDF").
+// The reference has NO pdf code: its only sketch is the dead Light::sample_li shadow-ray loop
+// (light.rs:107-124,170-183) and XZRectLight::random_point_on_area (light.rs:148-154).  This
+// integrator mode follows book 3 ("The Rest of Your Life") MixturePDF semantics instead:
+// on a Diffuse interaction the next direction is drawn from  0.5 * p_lights + 0.5 * p_cosine
+// and the throughput is weighted by  attenuation * scattering_pdf / pdf_mix .
+// Everything is trig-free (Marsaglia / rejection sampling only), so CPU and GPU agree bit for bit.
+//   p_cosine(dir)   = max(0, n . unit(dir)) / pi     (the density of the reference's own
+//                     Lambertian sample n + random_unit_vector(), material.rs:92-98)
+//   p_lights(dir)   = mean over lights of pdf_value(light, p, dir)   (book 3 hittable_list)
+//   rect  light: pdf_value = t^2 |v|^2 / (|v.y|/|v| * area) if the ray (p, v) hits it, else 0;
+//                random(p)  = (x0 + (x1-x0) u1, y, z0 + (z1-z0) u2) - p      (light.rs:148-154)
+//   sphere light: pdf_value = 1 / (2 pi (1 - cos_max)), cos_max = sqrt(1 - r^2/|c-p|^2), if hit;
+//                random(p)  = uniform direction in the cone, built from a rejection-sampled disk point
+// RNG order per Diffuse interaction: scatter()'s own draws, coin, light index, light sample.
+// PARITY UNPINNED (no reference counterpart); validated by equality in expectation with the
+// brute-force tracer (tests/test_mixture.py).
+// ----------------------------------------------------------------------------
+static double light_pdf_value(const Hitable* l, Vec3 o, Vec3 v, Ctx& cx) {
+    HitRecord rec;
+    Ctx scratch;  // the pdf's own hit test is not part of the traversal counters
+    (void)cx;
+    if (!l->hit(Ray{o, v}, 0.001, INF, rec, scratch)) return 0.;
+    if (const Rect* r = dynamic_cast<const Rect*>(l)) {
+        double area = (r->a1 - r->a0) * (r->b1 - r->b0);
+        double distance_squared = rec.t * rec.t * v_sqlen(v);
+        double cosine = std::fabs(v.y / v_len(v));
+        return distance_squared / (cosine * area);
+    }
+    const Sphere* s = static_cast<const Sphere*>(l);
+    double cos_theta_max = std::sqrt(1. - s->radius * s->radius / v_sqlen(v_sub(s->center, o)));
+    double solid_angle = 2. * PI * (1. - cos_theta_max);
+    return 1. / solid_angle;
+}
+static Vec3 light_random(const Hitable* l, Vec3 o, Rng& rng) {
+    if (const Rect* r = dynamic_cast<const Rect*>(l)) {
+        double u = rng.gen_range(0., 1.), v = rng.gen_range(0., 1.);
+        Vec3 p(r->a0 + (r->a1 - r->a0) * u, r->k, r->b0 + (r->b1 - r->b0) * v);
+        return v_sub(p, o);
+    }
+    const Sphere* s = static_cast<const Sphere*>(l);
+    Vec3 direction = v_sub(s->center, o);
+    double distance_squared = v_sqlen(direction);
+    // orthonormal basis around w = unit(direction) (book 3 onb::build_from_w)
+    Vec3 w = v_unit(direction);
+    Vec3 a = (std::fabs(w.x) > 0.9) ? Vec3(0, 1, 0) : Vec3(1, 0, 0);
+    Vec3 vv = v_unit(v_cross(w, a));
+    Vec3 uu = v_cross(w, vv);
+    // uniform direction in the cone of half-angle acos(cos_max): z uniform in [cos_max, 1], azimuth from a disk sample
+    Vec3 dsk = random_in_unit_disk(rng);
+    double s2 = dsk.x * dsk.x + dsk.y * dsk.y;
+    double cos_theta_max = std::sqrt(1. - s->radius * s->radius / distance_squared);
+    double z = 1. + s2 * (cos_theta_max - 1.);
+    double rr = std::sqrt(std::fmax(0., 1. - z * z));
+    double inv_s = (s2 > 0.) ? 1. / std::sqrt(s2) : 0.;
+    double x = dsk.x * inv_s * rr, y = dsk.y * inv_s * rr;
+    return v_add(v_add(v_muls(uu, x), v_muls(vv, y)), v_muls(w, z));
+}
+
+static Vec3 sample_ray_mixture(const Scene& sc, Ray ray, int max_depth, double t_min, Ctx& cx) {
+    Vec3 throughput(1, 1, 1);
+    Vec3 radiance(0, 0, 0);
+    Ray curr = ray;
+    int depth = max_depth;
+    HitRecord rec;
+    const size_t n_lights = sc.lights.size();
+    for (;;) {
+        cx.cnt.n_segments++;
+        if (!sc.root->hit(curr, t_min, INF, rec, cx)) break;
+        if (depth <= 0) break;
+        depth -= 1;
+        radiance = v_add(radiance, v_elemul(throughput, rec.mat->emitted(rec)));
+        ScatterResult sr = rec.mat->scatter(curr, rec, cx);
+        if (!(sr.has_ray && sr.has_att)) break;
+        if (sr.kind == Diffuse) {
+            Vec3 dir = sr.ray.dir;  // the cosine-distributed sample the reference's scatter drew
+            if (cx.rng.gen_f64() < 0.5) {
+                size_t li = (size_t)(cx.rng.gen_f64() * (double)n_lights);
+                if (li >= n_lights) li = n_lights - 1;
+                dir = light_random(sc.lights[li], rec.p, cx.rng);
+            }
+            double cosine = v_dot(rec.normal, v_unit(dir));
+            double scattering_pdf = (cosine < 0.) ? 0. : cosine / PI;
+            double lp = 0.;
+            for (size_t i = 0; i < n_lights; i++) lp = lp + light_pdf_value(sc.lights[i], rec.p, dir, cx);
+            double pdf_val = 0.5 * (lp / (double)n_lights) + 0.5 * scattering_pdf;
+            double wgt = scattering_pdf / pdf_val;
+            if (!(wgt > 0.)) break;  // direction below the surface (or a NaN): the path carries nothing further
+            throughput = v_muls(v_elemul(throughput, sr.att), wgt);
+            curr = Ray{rec.p, dir};
+        } else {
+            throughput = v_elemul(throughput, sr.att);
+            curr = sr.ray;
+        }
+    }
+    return radiance;
+}
+
 struct RenderArgs {
     int width, height, spp, max_depth;
     double t_min;
     uint64_t seed;
     int x0, y0, x1, y1;  // pixel window [x0,x1) x [y0,y1) rendered with the full-frame camera mapping
+    int integrator = 0;  // 0: sample_ray (BSDF sampling only); 1: sample_ray_mixture (light/cosine mixture pdf)
 };
 
 // Camera::capture_image -- camera.rs:66-128.  n_jobs row bands executed FIFO by
@@ -719,6 +820,7 @@ struct RenderArgs {
 // (sum / spp) f64 RGB, row-major, y down, window-local indexing.
 static int render(const Scene& sc, const RenderArgs& a, int n_jobs, int n_workers, double* out_rgb, Counters* total) {
     if (!sc.root || !sc.cam_set) return -1;
+    if (a.integrator == 1 && sc.lights.empty()) return -1;
     const int wh = a.y1 - a.y0, ww = a.x1 - a.x0;
     if (n_jobs < 1) n_jobs = 1;
     if (n_workers < 1) n_workers = 1;
@@ -742,7 +844,8 @@ static int render(const Scene& sc, const RenderArgs& a, int n_jobs, int n_worker
                             double u = ((double)x + cx.rng.gen_f64()) / (double)(a.width - 1);
                             double v = ((double)y + cx.rng.gen_f64()) / (double)(a.height - 1);
                             Ray r = sc.cam.get_ray(u, 1.0 - v, cx.rng);
-                            pixel = v_add(pixel, sample_ray(sc, r, a.max_depth, a.t_min, cx));
+                            pixel = v_add(pixel, a.integrator == 1 ? sample_ray_mixture(sc, r, a.max_depth, a.t_min, cx)
+                                                                   : sample_ray(sc, r, a.max_depth, a.t_min, cx));
                             cx.cnt.n_samples++;
                         }
                         pixel = v_divs(pixel, (double)a.spp);
@@ -1049,6 +1152,20 @@ int orc_set_root(void* s, int o) {
     sc.root = obj(sc, o);
     return ORC_OK;
 }
+// World::new's lights (world.rs:18): each must be a Sphere or an XZ rectangle (the reference's two Light impls)
+int orc_set_lights(void* s, int n, const int* ids) {
+    Scene& sc = *(Scene*)s;
+    std::vector<const Hitable*> v;
+    for (int i = 0; i < n; i++) {
+        const Hitable* h = obj(sc, ids[i]);
+        if (!h) return ORC_ERR_ARG;
+        const Rect* r = dynamic_cast<const Rect*>(h);
+        if (!(dynamic_cast<const Sphere*>(h) || (r && r->axis == 1))) return ORC_ERR_ARG;
+        v.push_back(h);
+    }
+    sc.lights = v;
+    return ORC_OK;
+}
 int orc_bounding_box(void* s, int o, double* out6) {
     Scene& sc = *(Scene*)s;
     AABB b;
@@ -1060,10 +1177,10 @@ int orc_bounding_box(void* s, int o, double* out6) {
 
 // counters out: n_aabb, n_sphere, n_rect, n_tri, n_xform, n_segments, n_samples
 int orc_render(void* s, int width, int height, int spp, int max_depth, double t_min, uint64_t seed, int x0, int y0, int x1, int y1,
-               int n_jobs, int n_workers, double* out_rgb, uint64_t* counters7) {
+               int n_jobs, int n_workers, double* out_rgb, uint64_t* counters7, int integrator) {
     Scene& sc = *(Scene*)s;
     if (width <= 0 || height <= 0 || spp <= 0 || x0 < 0 || y0 < 0 || x1 > width || y1 > height || x1 <= x0 || y1 <= y0 || !out_rgb) return ORC_ERR_ARG;
-    RenderArgs a{width, height, spp, max_depth, t_min, seed, x0, y0, x1, y1};
+    RenderArgs a{width, height, spp, max_depth, t_min, seed, x0, y0, x1, y1, integrator};
     Counters c;
     int rc = render(sc, a, n_jobs, n_workers, out_rgb, &c);
     if (counters7) {

@@ -61,6 +61,7 @@ void rt_default_params(rt_params* p) {
     p->spp_chunk = 0;
     p->kernel = 0;
     p->device = -1;
+    p->integrator = 0;
 }
 int rt_device_count(void) { return device_count(); }
 
@@ -230,6 +231,22 @@ int rt_world_new(rt_scene* s, int n, const int* objects, uint64_t bvh_seed) {
         return s->root;
     });
 }
+int rt_scene_set_lights(rt_scene* s, int n, const int* objects) {
+    return guard([&] {
+        not_committed_only(s);
+        REQUIRE(n >= 0 && (n == 0 || objects), "bad light list");
+        std::vector<int> v;
+        for (int i = 0; i < n; i++) {
+            check_obj(*s, objects[i]);
+            const ObjectRec& o = s->objects[objects[i]];
+            if (!(o.type == OBJ_SPHERE || (o.type == OBJ_RECT && o.axis == 1)))
+                throw RtError(RT_ERR_ARG, "a light must be a sphere or an XZ rectangle (light.rs:67-86,127-146)");
+            v.push_back(objects[i]);
+        }
+        s->lights = v;
+        return (int)RT_OK;
+    });
+}
 int rt_scene_set_root(rt_scene* s, int object) {
     return guard([&] {
         not_committed_only(s);
@@ -259,7 +276,9 @@ int rt_scene_cornell_box(rt_scene* s, const char* cube_obj_path, double aspect_r
         const double c1[3] = {140., 100., 240.}, c2[3] = {400., 100., 360.};
         items.push_back(add_sphere(*s, c1, 100., add_material(*s, MAT_DIELECTRIC, ctex(0.999, 0.999, 0.999), 1.5)));
         items.push_back(add_sphere(*s, c2, 100., add_material(*s, MAT_METAL, ctex(0.999, 0.999, 0.999), 0.)));
-        items.push_back(add_rect(*s, 1, 213., 227., 343., 332., 554., light));
+        const int light_obj = add_rect(*s, 1, 213., 227., 343., 332., 554., light);
+        items.push_back(light_obj);
+        s->lights = {light_obj};  // scene.rs:110 vec![Arc::new(light)]
         ObjMesh m = load_obj_file(cube_obj_path);
         if (!m.has_normals) throw RtError(RT_ERR_NO_NORMALS, "cube.obj without normals");
         int mesh = add_mesh(*s, (int)(m.pos.size() / 3), m.pos.data(), m.nrm.data(), (int)(m.idx.size() / 3), m.idx.data(), white, false,
@@ -308,6 +327,7 @@ static RenderPlan make_plan(const rt_params* p) {
     REQUIRE(p->max_depth >= 0, "max_depth must be >= 0");
     REQUIRE(p->world >= 1 && p->rank >= 0 && p->rank < p->world, "bad rank/world");
     REQUIRE(p->kernel >= 0 && p->kernel <= 3, "unknown kernel id");
+    REQUIRE(p->integrator == 0 || p->integrator == 1, "unknown integrator id");
     RenderPlan pl;
     pl.width = p->width; pl.height = p->height; pl.spp = p->spp; pl.max_depth = p->max_depth;
     pl.t_min = p->t_min; pl.seed = p->seed; pl.rank = p->rank; pl.world = p->world;
@@ -317,6 +337,7 @@ static RenderPlan make_plan(const rt_params* p) {
     pl.tiles_owned = (pl.tiles_total - p->rank + p->world - 1) / p->world;
     if (pl.tiles_owned < 0) pl.tiles_owned = 0;
     pl.kernel = p->kernel;
+    pl.integrator = p->integrator;
     // sample-buffer budget: <= ~1.5 GiB per launch (24 B per pixel-sample), at most 256 spp per launch
     int chunk = p->spp_chunk;
     if (chunk <= 0) {

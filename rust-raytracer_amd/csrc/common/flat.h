@@ -88,6 +88,7 @@ struct FlatView {  // by-value kernel argument
     uint32_t stage2_begin, stage2_end;  // kernel 2 stages [stage2_begin, stage2_end): [spheres|rects|tris|xforms|vpos|n2|items2|inst2]
     uint32_t stack2;          // stack entries a lane can need
     uint32_t off_tripre;      // per triangle {pa, pb-pa, pc-pa, pad}: 10 f64 (hot part, after tris)
+    uint32_t off_lights, n_lights;  // cold part: per light {NK_SPHERE | NK_RECT_XZ, payload index}
     double origin_limit2;     // accel boxes are padded for ray origins with max-abs coordinate <= this (camera checked per render)
 };
 

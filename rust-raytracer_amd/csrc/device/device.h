@@ -19,6 +19,7 @@ struct RenderPlan {
     int spp_chunk;  // samples per pixel per launch (sample-buffer capacity)
     int sub_spp;    // samples per pixel per work unit (one wave drains 64*sub_spp paths)
     int kernel;
+    int integrator;  // 0 BSDF sampling, 1 light/cosine mixture pdf
 };
 
 // Renders plan.tiles_owned tiles into d_tiles (device, tile-major f64 RGB) on `stream`; blocks until done.

@@ -128,6 +128,8 @@ struct Acc {  // typed views into the blob (LDS or global; the address space is 
     const uint2* items2;     // {kind | payload << 4, order}
     const uint2* inst2;      // {xform, root ref}
     uint32_t root2;
+    const uint2* lights;     // {NK_SPHERE | NK_RECT_XZ, payload}
+    uint32_t n_lights;
 };
 template <class P>
 DEV Acc make_acc(P hot, const char* gbase, const FlatView& v) {  // hot: LDS copy or the global blob; cold part always global
@@ -151,6 +153,8 @@ DEV Acc make_acc(P hot, const char* gbase, const FlatView& v) {  // hot: LDS cop
     a.items2 = (const uint2*)(hot + v.off_items2);
     a.inst2 = (const uint2*)(hot + v.off_inst2);
     a.root2 = v.root2;
+    a.lights = (const uint2*)(gbase + v.off_lights);
+    a.n_lights = v.n_lights;
     return a;
 }
 
@@ -592,9 +596,10 @@ DEV Rec materialize(const Acc& A, const Hit& h, D3 wo, D3 wd, int* err) {
 }
 
 // Material::emitted + Material::scatter, material.rs:88-212.  Returns false on Absorb.
-DEV bool shade(const Acc& A, const Rec& rec, D3 rdir, Rng& rng, D3& emitted, D3& att, D3& out_dir, int* err) {
+DEV bool shade(const Acc& A, const Rec& rec, D3 rdir, Rng& rng, D3& emitted, D3& att, D3& out_dir, bool& diffuse, int* err) {
     const MatDev mt = A.mats[rec.mat];
     emitted = mk(0., 0., 0.);
+    diffuse = (mt.type == 0 || mt.type == 3);  // Interaction::Diffuse (material.rs:111,207)
     if (mt.type == 0 || mt.type == 3) {  // Lambertian / DiffuseLight: scattered_direction, material.rs:92-98
         D3 dir = add(rec.normal, unit(random_in_unit_sphere(rng), err));
         if (near_zero(dir)) dir = rec.normal;
@@ -639,8 +644,75 @@ DEV bool shade(const Acc& A, const Rec& rec, D3 rdir, Rng& rng, D3& emitted, D3&
     return true;
 }
 
+// ------------------------------------------------------ light importance sampling ----
+// Integrator 1 (rt_params.integrator): book-3 MixturePDF semantics on Diffuse interactions; the reference has no pdf
+// code (its sketch: the dead Light::sample_li, light.rs:107-124,170-183, and random_point_on_area, light.rs:148-154).
+// Trig-free so that the CPU oracle and the device agree bit for bit.  See the oracle's sample_ray_mixture for the spec.
+DEV double light_pdf_value(const Acc& A, uint2 l, D3 o, D3 v) {
+    const double PI = 3.14159265358979323846264338327950288;
+    double t;
+    if (l.x == NK_SPHERE) {
+        const double2* s = A.spheres + 2 * l.y;
+        if (!sphere_hit(s, o, v, sqlen(v), 0.001, INFINITY, t)) return 0.;
+        double2 c0 = s[0], c1 = s[1];
+        double cos_theta_max = sqrt(1. - c1.y * c1.y / sqlen(sub(mk(c0.x, c0.y, c1.x), o)));
+        double solid_angle = 2. * PI * (1. - cos_theta_max);
+        return 1. / solid_angle;
+    }
+    const double2* r = A.rects + 3 * l.y;
+    if (!rect_hit(r, 1, o, v, 0.001, INFINITY, t)) return 0.;
+    double2 r0 = r[0], r1 = r[1];
+    double area = (r1.x - r0.x) * (r1.y - r0.y);
+    double distance_squared = t * t * sqlen(v);
+    double cosine = fabs(v.y / sqrt(sqlen(v)));
+    return distance_squared / (cosine * area);
+}
+DEV D3 light_random(const Acc& A, uint2 l, D3 o, Rng& rng, int* err) {
+    if (l.x == NK_SPHERE) {
+        const double2* s = A.spheres + 2 * l.y;
+        double2 c0 = s[0], c1 = s[1];
+        D3 direction = sub(mk(c0.x, c0.y, c1.x), o);
+        double distance_squared = sqlen(direction);
+        D3 w = unit(direction, err);
+        D3 a = (fabs(w.x) > 0.9) ? mk(0., 1., 0.) : mk(1., 0., 0.);
+        D3 vv = unit(cross(w, a), err);
+        D3 uu = cross(w, vv);
+        D3 dsk = random_in_unit_disk(rng);
+        double s2 = dsk.x * dsk.x + dsk.y * dsk.y;
+        double cos_theta_max = sqrt(1. - c1.y * c1.y / distance_squared);
+        double z = 1. + s2 * (cos_theta_max - 1.);
+        double rr = sqrt(fmax(0., 1. - z * z));
+        double inv_s = (s2 > 0.) ? 1. / sqrt(s2) : 0.;
+        double x = dsk.x * inv_s * rr, y = dsk.y * inv_s * rr;
+        return add(add(muls(uu, x), muls(vv, y)), muls(w, z));
+    }
+    const double2* r = A.rects + 3 * l.y;
+    double2 r0 = r[0], r1 = r[1], r2 = r[2];
+    double u = rng.gen_range(0., 1.), v = rng.gen_range(0., 1.);
+    D3 p = mk(r0.x + (r1.x - r0.x) * u, r2.x, r0.y + (r1.y - r0.y) * v);
+    return sub(p, o);
+}
+// mixture step after a Diffuse scatter: returns false when the path ends (weight not > 0)
+DEV bool mixture_step(const Acc& A, const Rec& rec, Rng& rng, D3 att, D3& beta, D3& dir, int* err) {
+    const double PI = 3.14159265358979323846264338327950288;
+    if (rng.gen_f64() < 0.5) {
+        uint32_t li = (uint32_t)(rng.gen_f64() * (double)A.n_lights);
+        if (li >= A.n_lights) li = A.n_lights - 1;
+        dir = light_random(A, A.lights[li], rec.p, rng, err);
+    }
+    double cosine = dot(rec.normal, unit(dir, err));
+    double scattering_pdf = (cosine < 0.) ? 0. : cosine / PI;
+    double lp = 0.;
+    for (uint32_t i = 0; i < A.n_lights; i++) lp = lp + light_pdf_value(A, A.lights[i], rec.p, dir);
+    double pdf_val = 0.5 * (lp / (double)A.n_lights) + 0.5 * scattering_pdf;
+    double wgt = scattering_pdf / pdf_val;
+    if (!(wgt > 0.)) return false;
+    beta = muls(elemul(beta, att), wgt);
+    return true;
+}
+
 // ------------------------------------------------------------ pt_kernel ---
-template <bool LDS, bool GENERAL, int ACCEL>
+template <bool LDS, bool GENERAL, int ACCEL, bool MIX>
 __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, RenderK rk, double* __restrict__ samples,
                                                       unsigned int* __restrict__ counter, int* __restrict__ err) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -723,13 +795,18 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
                     depth -= 1;
                     Rec rec = materialize<GENERAL>(A, h, o, d, err);
                     D3 emitted, att, ndir;
-                    bool scattered = shade(A, rec, d, rng, emitted, att, ndir, err);
+                    bool diffuse;
+                    bool scattered = shade(A, rec, d, rng, emitted, att, ndir, diffuse, err);
                     L = add(L, elemul(beta, emitted));  // radiance += throughput * Le
                     if (scattered) {  // Diffuse continues like Specular/Reflect/Refract (photon_mapper.rs:346-347)
-                        beta = elemul(beta, att);
-                        o = rec.p;
-                        d = ndir;
-                        done = false;
+                        bool go = true;
+                        if (MIX && diffuse) go = mixture_step(A, rec, rng, att, beta, ndir, err);
+                        else beta = elemul(beta, att);
+                        if (go) {
+                            o = rec.p;
+                            d = ndir;
+                            done = false;
+                        }
                     }
                 }
                 if (done) {
@@ -953,7 +1030,8 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_sm(FlatView sv, const CamK
                     depth -= 1;
                     Rec rec = materialize<GENERAL>(A, h, wo, wd, err);
                     D3 emitted, att, ndir;
-                    bool scattered = shade(A, rec, wd, rng, emitted, att, ndir, err);
+                    bool diffuse;
+                    bool scattered = shade(A, rec, wd, rng, emitted, att, ndir, diffuse, err);
                     L = add(L, elemul(beta, emitted));
                     if (scattered) {
                         beta = elemul(beta, att);
@@ -1253,12 +1331,20 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
     const bool lds = hot_bytes > 0 && hot_bytes + stack_bytes <= lds_max;
     pt_fn fn = nullptr;
     pt_sm_fn fn_sm = nullptr;
+    const bool mix = plan.integrator == 1;
+    if (mix && view.n_lights == 0) throw RtError(RT_ERR_ARG, "integrator 1 (light importance sampling) needs rt_scene_set_lights");
+    if (mix && kernel == 3) throw RtError(RT_ERR_UNSUPPORTED, "the diagnostic kernel 3 implements integrator 0 only");
     if (kernel == 3)
         fn_sm = lds ? (general ? pt_kernel_sm<true, true> : pt_kernel_sm<true, false>) : (general ? pt_kernel_sm<false, true> : pt_kernel_sm<false, false>);
+    else if (mix)  // the mixture variants are built for the general primitive set only
+        fn = (kernel == 2) ? (lds ? pt_kernel<true, true, 2, true> : pt_kernel<false, true, 2, true>)
+                           : (lds ? pt_kernel<true, true, 1, true> : pt_kernel<false, true, 1, true>);
     else if (kernel == 2)
-        fn = lds ? (general ? pt_kernel<true, true, 2> : pt_kernel<true, false, 2>) : (general ? pt_kernel<false, true, 2> : pt_kernel<false, false, 2>);
+        fn = lds ? (general ? pt_kernel<true, true, 2, false> : pt_kernel<true, false, 2, false>)
+                 : (general ? pt_kernel<false, true, 2, false> : pt_kernel<false, false, 2, false>);
     else
-        fn = lds ? (general ? pt_kernel<true, true, 1> : pt_kernel<true, false, 1>) : (general ? pt_kernel<false, true, 1> : pt_kernel<false, false, 1>);
+        fn = lds ? (general ? pt_kernel<true, true, 1, false> : pt_kernel<true, false, 1, false>)
+                 : (general ? pt_kernel<false, true, 1, false> : pt_kernel<false, false, 1, false>);
     const size_t smem = (lds ? hot_bytes : 0) + stack_bytes;
     const void* fptr = (kernel == 3) ? (const void*)fn_sm : (const void*)fn;
     if (smem > 48 * 1024) HIP_CHECK(hipFuncSetAttribute(fptr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));

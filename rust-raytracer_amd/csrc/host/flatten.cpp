@@ -30,6 +30,7 @@ struct Builder {
     std::vector<uint32_t> mesh_base;
     uint32_t kinds = 0;
     int xf_depth = 0, depth = 0, max_depth = 0;
+    std::map<int, bool> in_xform;  // object id -> emitted inside a Transform
     // accel (kernel 2) item collection: context 0 = world space, context 1+i = object space of instance i
     struct InstCtx {
         std::vector<AccelItem> items;
@@ -68,6 +69,7 @@ struct Builder {
 
     void emit(int id) {
         const ObjectRec& o = s.objects[id];
+        if (xf_depth > 0) in_xform[id] = true;
         depth++;
         if (depth > max_depth) max_depth = depth;
         switch (o.type) {
@@ -193,6 +195,32 @@ void flatten(rt_scene& s) {
     }
     b.emit(s.root);
 
+    // World::new's lights -> {kind, payload} pairs addressing the sphere / rect tables
+    std::vector<uint32_t> lights;
+    for (int lid : s.lights) {
+        const ObjectRec& o = s.objects[lid];
+        if (b.in_xform.count(lid)) throw RtError(RT_ERR_UNSUPPORTED, "a light under a Transform is not supported");
+        if (o.type == OBJ_SPHERE) {
+            auto it = b.sphere_of.find(lid);
+            if (it == b.sphere_of.end()) {  // a light that is not part of the hitable list: still addressable
+                it = b.sphere_of.emplace(lid, (uint32_t)b.sphere_mat.size()).first;
+                b.spheres.insert(b.spheres.end(), {o.c[0], o.c[1], o.c[2], o.r});
+                b.sphere_mat.push_back(o.material);
+            }
+            lights.push_back(NK_SPHERE);
+            lights.push_back(it->second);
+        } else {
+            auto it = b.rect_of.find(lid);
+            if (it == b.rect_of.end()) {
+                it = b.rect_of.emplace(lid, (uint32_t)b.rect_mat.size()).first;
+                b.rects.insert(b.rects.end(), {o.a0, o.b0, o.a1, o.b1, o.k, 0.0});
+                b.rect_mat.push_back(o.material);
+            }
+            lights.push_back(NK_RECT_XZ);
+            lights.push_back(it->second);
+        }
+    }
+
     std::vector<MatDev> mats;
     for (auto& m : s.materials) mats.push_back(MatDev{m.type, m.tex, m.param});
     std::vector<TexDev> texs;
@@ -282,6 +310,8 @@ void flatten(rt_scene& s) {
     v.off_rect_mat = append(f.blob, b.rect_mat);
     v.off_mats = append(f.blob, mats);
     v.off_texs = append(f.blob, texs);
+    v.off_lights = append(f.blob, lights);
+    v.n_lights = (uint32_t)(lights.size() / 2);
     v.off_vpos = append(f.blob, b.vpos);  // kept for introspection; the kernels read tripre instead
     v.off_vnrm = append(f.blob, b.vnrm);
     v.off_texels = append(f.blob, texels);

@@ -76,6 +76,7 @@ struct rt_scene {
     std::vector<rtamd::ObjectRec> objects;
     std::vector<std::unique_ptr<rtamd::MeshData>> meshes;
     int root = -1;
+    std::vector<int> lights;  // World::new's lights (object ids)
     bool committed = false;
     rtamd::FlatScene flat;
     // device copies of the blob, one per HIP device, created lazily by the render entry points

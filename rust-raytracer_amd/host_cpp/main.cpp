@@ -2,7 +2,7 @@
 //   let world = select_scene(0); let result = world.cam.capture_image(integrator); result.save("output/test.png")
 // and the same "Total / RT" timing print.  Also renders the reference's scene files.
 //   rtamd_render [--scene cornell|FILE.json|FILE.yaml] [--cube data/mesh/cube.obj] [-w W] [-h H] [--spp N]
-//                [--depth D] [--seed S] [--aspect A] [-o out.png] [--describe] [--vec3-selftest]
+//                [--depth D] [--seed S] [--aspect A] [--integrator 0|1] [-o out.png] [--describe] [--vec3-selftest]
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -54,6 +54,7 @@ int main(int argc, char** argv) {
         else if (a == "--depth") cfg.max_depth = std::atoi(next());
         else if (a == "--seed") cfg.seed = std::strtoull(next(), nullptr, 10);
         else if (a == "--aspect") aspect = std::atof(next());
+        else if (a == "--integrator") cfg.integrator = std::atoi(next());
         else if (a == "-o") out = next();
         else if (a == "--describe") describe = true;
         else if (a == "--vec3-selftest") return vec3_selftest();

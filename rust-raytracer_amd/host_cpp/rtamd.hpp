@@ -302,19 +302,22 @@ struct Config {
     int max_depth = 50;             // photon_mapper.rs:334
     double t_min = 0.001;           // photon_mapper.rs:335
     uint64_t seed = 1;
+    int integrator = 0;             // 0 BSDF sampling (the reference's structure); 1 light/cosine mixture pdf
 };
 
 // world.rs:8-30.  World::new(hitable_list, cam, lights): root = BVHNode::new(hitable_list).
 class World {
    public:
     Camera cam;
-    World(const HitableList& hitable_list, Camera camera, uint64_t bvh_seed = 1) : cam(camera) {
+    World(const HitableList& hitable_list, Camera camera, const HitableList& lights = {}, uint64_t bvh_seed = 1) : cam(camera) {
         check(rt_scene_create(&s_));
         try {
             Emitter e(s_, bvh_seed);
-            std::vector<int> ids;
+            std::vector<int> ids, lids;
             for (auto& h : hitable_list) ids.push_back(e.once(h.get()));
+            for (auto& l : lights) lids.push_back(e.once(l.get()));  // a light shared with the hitable list is emitted once
             check(rt_world_new(s_, (int)ids.size(), ids.data(), bvh_seed));
+            if (!lids.empty()) check(rt_scene_set_lights(s_, (int)lids.size(), lids.data()));
             check(rt_scene_commit(s_));
         } catch (...) {
             rt_scene_destroy(s_);
@@ -335,7 +338,7 @@ class World {
         rt_params p;
         rt_default_params(&p);
         p.width = cfg.width; p.height = cfg.height; p.spp = cfg.sample_per_pixel; p.max_depth = cfg.max_depth;
-        p.t_min = cfg.t_min; p.seed = cfg.seed;
+        p.t_min = cfg.t_min; p.seed = cfg.seed; p.integrator = cfg.integrator;
         std::vector<double> rad((size_t)cfg.width * cfg.height * 3);
         check(rt_render(s_, &cam.c, &p, rad.data(), stats));
         RgbImage img;
@@ -371,7 +374,7 @@ inline std::unique_ptr<World> cornell_box_scene(const std::string& cube_obj, dou
         std::make_shared<Cube>(Vec3(300., 0., 100.), Vec3(380., 100., 180.), white),
     };
     Camera cam({Vec3(278., 278., -800.), Vec3(278., 278., 278.)}, Vec3(0., 1., 0.), 50., aspect_ratio, 0.0, 10.0);
-    return std::make_unique<World>(hitable_list, cam, bvh_seed);
+    return std::make_unique<World>(hitable_list, cam, HitableList{light}, bvh_seed);  // scene.rs:100-111: lights = vec![light]
 }
 
 }  // namespace rtamd_host

@@ -38,7 +38,7 @@ class rt_camera(C.Structure):
 class rt_params(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("spp", C.c_int32), ("max_depth", C.c_int32), ("t_min", C.c_double),
                 ("seed", C.c_uint64), ("rank", C.c_int32), ("world", C.c_int32), ("spp_chunk", C.c_int32), ("kernel", C.c_int32),
-                ("device", C.c_int32), ("reserved", C.c_int32)]
+                ("device", C.c_int32), ("integrator", C.c_int32)]
 
 
 class rt_stats(C.Structure):
@@ -94,6 +94,7 @@ _SIGS = [
     ("rt_object_bounding_box", C.c_int, [C.c_void_p, C.c_int, C.c_double * 6]),
     ("rt_world_new", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_uint64]),
     ("rt_scene_set_root", C.c_int, [C.c_void_p, C.c_int]),
+    ("rt_scene_set_lights", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     ("rt_scene_cornell_box", C.c_int, [C.c_void_p, C.c_char_p, C.c_double, C.c_uint64, C.POINTER(rt_camera)]),
     ("rt_scene_load_file", C.c_int, [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(rt_camera)]),
     ("rt_scene_commit", C.c_int, [C.c_void_p]),
@@ -302,11 +303,17 @@ class World:
         return np.array(out[:])
 
     # --- World::new / commit ---
-    def new(self, hitable_list, bvh_seed=1):
-        """World::new (world.rs:15-25): root = BVHNode::new(hitable_list); then commit."""
+    def new(self, hitable_list, lights=(), bvh_seed=1):
+        """World::new(hitable_list, cam, lights) (world.rs:15-25): root = BVHNode::new(hitable_list); then commit."""
         arr = (C.c_int * len(hitable_list))(*hitable_list)
         _chk(self.L.rt_world_new(self.h, len(hitable_list), arr, int(bvh_seed)))
+        if len(lights):
+            self.set_lights(list(lights))
         return self.commit()
+
+    def set_lights(self, lights):
+        arr = (C.c_int * len(lights))(*lights)
+        _chk(self.L.rt_scene_set_lights(self.h, len(lights), arr))
 
     def set_root(self, obj):
         _chk(self.L.rt_scene_set_root(self.h, obj))
@@ -323,10 +330,10 @@ class World:
 
     # --- the hot path ---
     def render(self, camera, width=800, height=800, spp=256, max_depth=50, t_min=1e-3, seed=1, rank=0, world=1, spp_chunk=0,
-               kernel=0, device=-1):
+               kernel=0, device=-1, integrator=0):
         """rt_render: linear radiance f64 [H,W,3] on the host + stats dict."""
         p = default_params(width=width, height=height, spp=spp, max_depth=max_depth, t_min=t_min, seed=seed, rank=rank, world=world,
-                           spp_chunk=spp_chunk, kernel=kernel, device=device)
+                           spp_chunk=spp_chunk, kernel=kernel, device=device, integrator=integrator)
         out = np.zeros((height, width, 3), dtype=np.float64)
         st = rt_stats()
         _chk(self.L.rt_render(self.h, C.byref(camera.c), C.byref(p), out.ctypes.data_as(_dp), C.byref(st)))

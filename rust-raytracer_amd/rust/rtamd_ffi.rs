@@ -43,7 +43,7 @@ pub struct rt_params {
     pub spp_chunk: i32,
     pub kernel: i32,
     pub device: i32,
-    pub reserved: i32,
+    pub integrator: i32,
 }
 
 #[repr(C)]
@@ -91,6 +91,7 @@ extern "C" {
     pub fn rt_object_bvh_node(s: *mut rt_scene, left: c_int, right: c_int) -> c_int;
     pub fn rt_object_bvh_build(s: *mut rt_scene, n: c_int, objs: *const c_int, bvh_seed: u64) -> c_int;
     pub fn rt_world_new(s: *mut rt_scene, n: c_int, objs: *const c_int, bvh_seed: u64) -> c_int;
+    pub fn rt_scene_set_lights(s: *mut rt_scene, n: c_int, objs: *const c_int) -> c_int;
     pub fn rt_scene_load_file(path: *const c_char, out: *mut *mut rt_scene, cam: *mut rt_camera) -> c_int;
     pub fn rt_scene_commit(s: *mut rt_scene) -> c_int;
     pub fn rt_render(s: *const rt_scene, cam: *const rt_camera, p: *const rt_params, out_rgb: *mut c_double, stats: *mut rt_stats) -> c_int;

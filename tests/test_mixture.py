@@ -1,0 +1,124 @@
+"""Integrator 1: light importance sampling with the 0.5*lights + 0.5*cosine mixture pdf (SURVEY s8f next #2,
+book-3 MixturePDF semantics).  The reference has no pdf code, so this mode is pinned by
+  (1) HIP == oracle, bit-exact, for identical seeds (both kernels, rect and sphere lights);
+  (2) equality in expectation with the brute-force tracer (integrator 0), for the oracle and for the HIP path;
+  (3) variance: with a small light the mixture estimator must be markedly less noisy."""
+import numpy as np
+import pytest
+
+from conftest import scene_path
+
+
+def sphere_light_scene(B, rect_light=False):
+    """A diffuse floor and ball lit by one small light; works on both builders (rtamd.World / oracle.Scene)."""
+    white = B.Lambertian(B.ConstantTexture((0.8, 0.8, 0.8)))
+    red = B.Lambertian(B.ConstantTexture((0.8, 0.3, 0.3)))
+    lm = B.DiffuseLight(B.ConstantTexture((40.0, 40.0, 40.0)))
+    floor = B.XZRectangle((-20.0, -20.0), (20.0, 20.0), 0.0, white)
+    ball = B.Sphere((0.0, 1.0, 0.0), 1.0, red)
+    glass = B.Sphere((2.5, 1.0, 0.5), 1.0, B.Dielectric(1.5, B.ConstantTexture((1.0, 1.0, 1.0))))
+    light = B.XZRectangle((-0.5, -0.5), (0.5, 0.5), 6.0, lm) if rect_light else B.Sphere((-1.0, 5.0, 1.0), 0.4, lm)
+    return [floor, ball, glass, light], [light]
+
+
+CAM = dict(look_from=(0.0, 3.0, -9.0), look_at=(0.0, 1.0, 0.0), vup=(0.0, 1.0, 0.0), vfov=40.0, aspect=1.0, aperture=0.0, focus=9.0)
+
+
+def oracle_scene(rect_light):
+    import oracle
+    o = oracle.Scene()
+    items, lights = sphere_light_scene(o, rect_light)
+    o.World(items, 1)
+    o.set_lights(lights)
+    o.Camera(CAM["look_from"], CAM["look_at"], CAM["vup"], CAM["vfov"], CAM["aspect"], CAM["aperture"], CAM["focus"])
+    return o
+
+
+def hip_scene(rect_light):
+    import rtamd
+    w = rtamd.World()
+    items, lights = sphere_light_scene(w, rect_light)
+    w.new(items, lights=lights, bvh_seed=1)
+    cam = rtamd.Camera((CAM["look_from"], CAM["look_at"]), CAM["vup"], CAM["vfov"], CAM["aspect"], CAM["aperture"], CAM["focus"])
+    return w, cam
+
+
+@pytest.mark.parametrize("rect_light", [False, True])
+def test_oracle_mixture_equals_brute_force_in_expectation(rect_light):
+    o = oracle_scene(rect_light)
+    bf, _ = o.render(24, 24, 3000, seed=1, integrator=0, max_depth=6)
+    mx, _ = o.render(24, 24, 600, seed=2, integrator=1, max_depth=6)
+    # image means agree within Monte-Carlo error (brute force is the noisy side)
+    assert mx.mean() == pytest.approx(bf.mean(), rel=0.05)
+    # coarse 4x4 block means too
+    b4 = bf.reshape(4, 6, 4, 6, 3).mean(axis=(1, 3, 4))
+    m4 = mx.reshape(4, 6, 4, 6, 3).mean(axis=(1, 3, 4))
+    assert np.allclose(m4, b4, rtol=0.25, atol=0.02)
+
+
+def test_oracle_mixture_reduces_variance_for_a_small_light():
+    o = oracle_scene(False)
+    ref, _ = o.render(16, 16, 1500, seed=9, integrator=1, max_depth=4)
+    a, _ = o.render(16, 16, 32, seed=1, integrator=0, max_depth=4)
+    b, _ = o.render(16, 16, 32, seed=1, integrator=1, max_depth=4)
+    assert ((b - ref) ** 2).mean() < 0.5 * ((a - ref) ** 2).mean()
+
+
+def test_mixture_needs_lights():
+    import oracle
+    o = oracle.load_scene_file(scene_path("scene_10.json"))
+    with pytest.raises(oracle.OracleError):
+        o.render(8, 8, 1, integrator=1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kernel", [1, 2])
+@pytest.mark.parametrize("rect_light", [False, True])
+def test_hip_mixture_bit_exact_vs_oracle(rect_light, kernel):
+    o = oracle_scene(rect_light)
+    w, cam = hip_scene(rect_light)
+    img, st = w.render(cam, width=48, height=40, spp=16, seed=3, integrator=1, kernel=kernel)
+    exp, _ = o.render(48, 40, 16, seed=3, integrator=1)
+    assert np.array_equal(img, exp)
+    assert st["kernel_used"] == kernel
+    plain, _ = w.render(cam, width=48, height=40, spp=16, seed=3, integrator=0, kernel=kernel)
+    assert np.array_equal(plain, o.render(48, 40, 16, seed=3, integrator=0)[0]) and not np.array_equal(plain, img)
+
+
+@pytest.mark.gpu
+def test_hip_cornell_mixture_bit_exact_and_unbiased():
+    """C3: the Cornell box with its XZRectLight (scene.rs:26-32,110) under the mixture pdf."""
+    import oracle
+    import rtamd
+    cube = scene_path("cube.obj")
+    w, cam = rtamd.select_scene(cube, 1.0, 1)
+    o = oracle.cornell_box_scene(cube, 1.0, seed=1)
+    img, _ = w.render(cam, width=40, height=40, spp=8, seed=1, integrator=1)
+    exp, _ = o.render(40, 40, 8, seed=1, integrator=1)
+    assert np.array_equal(img, exp)
+    # equality in expectation on the GPU at a sample count the oracle could not afford: 8 independent renders per
+    # estimator give block means and their standard errors; the two estimators must agree within Monte-Carlo error
+    def blocks(integrator, spp, seeds):
+        runs = np.stack([w.render(cam, width=64, height=64, spp=spp, seed=s, integrator=integrator)[0] for s in seeds])
+        b = runs.reshape(len(seeds), 8, 8, 8, 8, 3).mean(axis=(2, 4, 5))          # [run, 8, 8] block means
+        return b.mean(axis=0), b.std(axis=0, ddof=1) / np.sqrt(len(seeds)), runs.mean()
+    bm, bse, btot = blocks(0, 1024, range(10, 18))
+    mm, mse, mtot = blocks(1, 256, range(20, 28))
+    assert mtot == pytest.approx(btot, rel=0.01)
+    z = (mm - bm) / np.sqrt(bse ** 2 + mse ** 2 + 1e-30)
+    assert np.abs(z).max() < 6.0 and np.abs(z).mean() < 1.6, (np.abs(z).max(), np.abs(z).mean())
+    # per-sample variance: the mixture estimator is the less noisy one (standard errors at 256 vs 1024 spp)
+    assert (mse ** 2).mean() * 256 < (bse ** 2).mean() * 1024
+
+
+@pytest.mark.gpu
+def test_hip_mixture_errors():
+    import rtamd
+    w, cam = rtamd.load_scene_file(scene_path("scene_10.json"))
+    with pytest.raises(rtamd.RtError) as e:
+        w.render(cam, width=8, height=8, spp=1, integrator=1)     # no lights in a scene file
+    assert e.value.code == -1
+    w2 = rtamd.World()
+    m = w2.Lambertian(w2.ConstantTexture((1, 1, 1)))
+    with pytest.raises(rtamd.RtError):
+        w2.set_lights([w2.XYRectangle((0, 0), (1, 1), 0, m)])        # only spheres / XZ rects are Lights
