@@ -393,7 +393,7 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
     h.kp = 0;
     int cur_xf = -1;
     Ray32 r = make_ray32(o, inv, t_min, t_max);
-    int sp = 0;
+    int sp = 0;  // stack offset in words (a multiple of stride): avoids an integer multiply per push/pop
     uint32_t cur = A.root2;
     for (;;) {
         while ((cur >> REF_TAG_SHIFT) == 0u) {  // inner node: test both children
@@ -406,16 +406,16 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
             if (h0 && h1) {
                 bool swap = e1 < e0;
                 uint32_t nearc = swap ? c1 : c0, farc = swap ? c0 : c1;
-                stk[sp * stride] = farc;
-                sp++;
+                stk[sp] = farc;
+                sp += stride;
                 cur = nearc;
             } else if (h0) {
                 cur = c0;
             } else if (h1) {
                 cur = c1;
             } else if (sp > 0) {
-                sp--;
-                cur = stk[sp * stride];
+                sp -= stride;
+                cur = stk[sp];
             } else {
                 cur = REF_DONE;
             }
@@ -459,8 +459,8 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
                 a = sqlen(d);
                 cur_xf = (int)in.x;
                 r = make_ray32(o, inv, t_min, h.t);
-                stk[sp * stride] = REF_RESTORE;
-                sp++;
+                stk[sp] = REF_RESTORE;
+                sp += stride;
                 cur = in.y;
                 continue;
             }
@@ -473,8 +473,8 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
             r = make_ray32(o, inv, t_min, h.t);
         }
         if (sp > 0) {
-            sp--;
-            cur = stk[sp * stride];
+            sp -= stride;
+            cur = stk[sp];
         } else {
             cur = REF_DONE;
         }
