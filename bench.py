@@ -64,7 +64,7 @@ def main():
     ap.add_argument("--spp", type=int, default=1000)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--kernel", type=int, default=0, help="0 = library default; 1/2/3 force a path-trace kernel (A/B runs only)")
-    ap.add_argument("--cpu-spp", type=int, default=12, help="spp of the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-spp", type=int, default=32, help="spp of the bounded CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
 
     import torch
