@@ -1319,12 +1319,13 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
     // kernel 2 (accel) is the default when an accel exists and its padding covers this camera's origin
     // (flatten.cpp: boxes are padded for ray origins up to origin_limit2); otherwise kernel 1 (reference order).
     double cam_abs = std::fmax(std::fmax(std::fabs(cam.origin[0]), std::fabs(cam.origin[1])), std::fabs(cam.origin[2])) + std::fabs(cam.lens_radius);
-    const bool accel_usable = view.accel_ok && cam_abs <= view.origin_limit2 && std::isfinite(cam_abs);
+    const bool accel_usable = view.accel_ok && cam_abs <= view.origin_limit2 && std::isfinite(cam_abs) &&
+                              (size_t)view.stack2 * PT_BLOCK * sizeof(uint32_t) <= lds_max;  // per-lane stacks live in LDS
     int kernel = plan.kernel;
     if (kernel == 0) kernel = accel_usable ? 2 : 1;
     if (kernel >= 2 && !accel_usable)
-        throw RtError(RT_ERR_UNSUPPORTED, "kernel 2 requested but no usable accel for this scene/camera (unbounded item, depth overflow, or camera "
-                                          "farther than 64x the scene extent); use kernel 0/1");
+        throw RtError(RT_ERR_UNSUPPORTED, "kernel 2 requested but no usable accel for this scene/camera (unbounded item, depth overflow, stacks "
+                                          "larger than LDS, or camera farther than 64x the scene extent); use kernel 0/1");
     const size_t stack_bytes = (kernel >= 2) ? (size_t)view.stack2 * PT_BLOCK * sizeof(uint32_t) : 0;
     const size_t hot_bytes = (kernel >= 2) ? (size_t)(view.stage2_end - view.stage2_begin) : (size_t)view.stage_bytes;
     if (stack_bytes > lds_max) throw RtError(RT_ERR_UNSUPPORTED, "accel stack does not fit LDS");

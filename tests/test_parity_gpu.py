@@ -205,3 +205,42 @@ def test_kernels_agree_on_random_sphere_soups_with_ties():
     i2, _ = w.render(cam, width=48, height=48, spp=4, kernel=2)
     i3, _ = w.render(cam, width=48, height=48, spp=4, kernel=3)
     assert np.array_equal(i1, i2) and np.array_equal(i1, i3)
+
+
+@pytest.mark.parametrize("kernel", [1, 2])
+def test_image_texture_and_every_material_bit_exact(kernel):
+    """ImageTexture (material.rs:70-84) on a sphere (uv by acos/atan2, sphere.rs:16-20) and on rectangles (uv by
+    position), CheckerTexture, fuzzy Metal, Dielectric, a sphere light, a rotated + non-uniformly scaled Transform
+    of a mesh and a Cube: every device shading branch in one scene, compared with the oracle."""
+    import oracle
+    import rtamd
+    rng = np.random.default_rng(42)
+    img = rng.integers(0, 256, size=(16, 32, 3), dtype=np.uint8)
+    P, N, I = oracle.load_obj(scene_path("cube.obj"))
+
+    def build(B, mesh_fn):
+        it = B.Lambertian(B.ImageTexture(img))
+        ch = B.Lambertian(B.CheckerTexture(B.ConstantTexture((0.2, 0.3, 0.1)), B.ConstantTexture((0.9, 0.9, 0.9))))
+        items = [
+            B.XZRectangle((-8.0, -8.0), (8.0, 8.0), 0.0, ch),
+            B.XYRectangle((-8.0, 0.0), (8.0, 8.0), 6.0, it),
+            B.YZRectangle((0.0, -8.0), (8.0, 8.0), -7.0, B.Metal(B.ConstantTexture((0.8, 0.7, 0.6)), 0.3)),
+            B.Sphere((-2.0, 1.0, 0.0), 1.0, it),
+            B.Sphere((0.5, 1.0, -1.0), 1.0, B.Dielectric(1.5, B.ConstantTexture((0.95, 0.95, 1.0)))),
+            B.Sphere((0.5, 1.0, -1.0), -0.8 if False else 0.8, B.Dielectric(1.0 / 1.5, B.ConstantTexture((1.0, 1.0, 1.0)))),
+            B.Sphere((3.0, 4.0, 1.0), 0.7, B.DiffuseLight(B.ConstantTexture((9.0, 8.0, 7.0)))),
+            B.Cube((-5.0, 0.0, -3.0), (-3.5, 1.5, -1.5), B.Lambertian(B.ConstantTexture((0.3, 0.4, 0.8)))),
+            B.Transform((20.0, 35.0, 10.0), (0.7, 1.1, 0.5), (2.5, 1.2, 2.0), mesh_fn(B)),
+        ]
+        return items
+
+    w = rtamd.World()
+    w.new(build(w, lambda B: B.Mesh(P, N, I, B.Lambertian(B.ConstantTexture((0.7, 0.7, 0.2))), bvh_seed=4)), bvh_seed=2)
+    o = oracle.Scene()
+    o.World(build(o, lambda B: B.Mesh(P, N, I, B.Lambertian(B.ConstantTexture((0.7, 0.7, 0.2))), 4)), 2)
+    cam = rtamd.Camera(((0.0, 3.0, -10.0), (0.0, 1.0, 0.0)), (0, 1, 0), 45.0, 1.5, 0.05, 10.0)
+    o.Camera((0.0, 3.0, -10.0), (0.0, 1.0, 0.0), (0, 1, 0), 45.0, 1.5, 0.05, 10.0)
+    got, _ = w.render(cam, width=96, height=64, spp=8, seed=11, kernel=kernel)
+    exp, _ = o.render(96, 64, 8, seed=11)
+    _assert_same(got, exp, "material zoo, kernel %d" % kernel)
+    assert got.max() > 0.5
