@@ -80,8 +80,9 @@ def main():
         dist.init_process_group(backend="nccl", rank=rank, world_size=world_size)
     if not torch.cuda.is_available() or rtamd.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device: the product has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = int(os.environ.get("RTAMD_BENCH_DEVICE", local_rank))  # override only to rehearse N>1 on a 1-GPU box
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
 
     world, cam = rtamd.load_scene_file(SCENE)
     params = rtamd.default_params(width=args.width, height=args.height, spp=args.spp, max_depth=50, t_min=1e-3, seed=args.seed,

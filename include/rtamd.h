@@ -81,7 +81,8 @@ typedef struct rt_params {
     int32_t device;      /* HIP device ordinal; -1 = current */
     int32_t integrator;  /* 0 = sample_ray as the reference structures it (BSDF sampling only; default);
                             1 = light importance sampling: on Diffuse hits the direction is drawn from the
-                                0.5*lights + 0.5*cosine mixture pdf (book-3 MixturePDF semantics; needs rt_scene_set_lights) */
+                                0.5*lights + 0.5*cosine mixture pdf (book-3 MixturePDF semantics; needs rt_scene_set_lights);
+                            2 = the reference's SPPM sample_ray (only through rt_render_sppm) */
 } rt_params;
 
 typedef struct rt_stats {
@@ -127,9 +128,11 @@ int rt_object_rect_xz(rt_scene* s, double x0, double z0, double x1, double z1, d
 int rt_object_rect_yz(rt_scene* s, double y0, double z0, double y1, double z1, double x, int material);
 /* objects/cube.rs:16 Cube::new(box_min, box_max, mat) */
 int rt_object_cube(rt_scene* s, const double box_min[3], const double box_max[3], int material);
-/* light.rs:74-86,134-146 : a light seen as a Hitable = primitive + DiffuseLight(ConstantTexture(flux)) */
-int rt_object_sphere_light(rt_scene* s, const double center[3], double radius, const double flux[3]);
-int rt_object_xz_rect_light(rt_scene* s, double x0, double z0, double x1, double z1, double y, const double flux[3]);
+/* SphereDiffuseLight::new(center, radius, flux, scale) light.rs:74-86 / XZRectLight::new(xz0, xz1, y, flux, scale)
+ * light.rs:134-146 : as a Hitable the light is its primitive + DiffuseLight(ConstantTexture(flux)); `scale` only feeds
+ * the photon power (flux * scale) of the SPPM pre-pass */
+int rt_object_sphere_light(rt_scene* s, const double center[3], double radius, const double flux[3], double scale);
+int rt_object_xz_rect_light(rt_scene* s, double x0, double z0, double x1, double z1, double y, const double flux[3], double scale);
 /* objects/mesh.rs:149 Mesh::load_obj given parsed arrays: positions/normals n_vert*3, indices n_tri*3.
  * normals == NULL -> RT_ERR_NO_NORMALS unless synthesize_normals != 0 (area-weighted smooth normals). */
 int rt_object_mesh(rt_scene* s, int n_vert, const double* positions, const double* normals, int n_tri, const uint32_t* indices,
@@ -178,6 +181,25 @@ int rt_scene_info_get(const rt_scene* s, rt_scene_info* out);
  * row-major, y down, into caller-owned HOST memory out_rgb[height*width*3].  world > 1 renders only this
  * rank's tiles (others left 0). */
 int rt_render(const rt_scene* s, const rt_camera* cam, const rt_params* p, double* out_rgb, rt_stats* stats);
+
+/* The reference's main.rs:52-54 as it really is: SPPMIntegrator::new(world) (photon_mapper.rs:139-233: `iterations` x
+ * {photons_per_iter photon paths -> global + caustic photon maps; one eye ray per pixel; progressive radius update}) followed
+ * by capture_image with SPPMIntegrator::sample_ray (photon_mapper.rs:327-365: the first Diffuse hit adds the pixel's estimates
+ * and ends the path).  Needs rt_scene_set_lights with lights made by rt_object_*_light.  One GPU, whole frame.
+ * stats_out (optional, HOST, height*width*10 f64): per pixel {global: flux[3], radius2, photons; caustic: flux[3], radius2, photons}.
+ * spp == 0 runs the pre-pass only (out_rgb may be NULL).  rt_stats.reserved[0] = pre-pass time in microseconds. */
+typedef struct rt_sppm_config {
+    int32_t iterations;        /* max_iter_cnt      photon_mapper.rs:148  default 50     */
+    int32_t photons_per_iter;  /* photon_per_iter   photon_mapper.rs:149  default 500000 */
+    int32_t k_global;          /* GLOBAL_INIT_PHOTONS  :18  default 100 */
+    int32_t k_caustic;         /* CAUSTIC_INIT_PHOTONS :19  default 50  */
+    int32_t max_bounces;       /* cap on photon / eye path length (the reference loops until absorbed); default 4096 */
+    int32_t reserved;
+    double alpha;              /* ALPHA :17  default 0.7 */
+} rt_sppm_config;
+void rt_default_sppm_config(rt_sppm_config* c);
+int rt_render_sppm(const rt_scene* s, const rt_camera* cam, const rt_params* p, const rt_sppm_config* cfg, double* out_rgb,
+                   double* stats_out, uint64_t photons_stored[2], rt_stats* stats);
 
 /* Same, device-resident: renders this rank's 8x8 tiles into d_tiles (DEVICE memory,
  * rt_tiles_owned(p)*64*3 f64, tile-major) on `hip_stream` (hipStream_t as void*, NULL = default stream).

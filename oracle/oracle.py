@@ -63,7 +63,9 @@ def lib():
     L.orc_bounding_box.argtypes = [C.c_void_p, C.c_int, c_double_p]
     L.orc_render.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_uint64,
                              C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_double_p, c_u64_p, C.c_int]
-    L.orc_set_lights.argtypes = [C.c_void_p, C.c_int, c_int_p]
+    L.orc_set_lights.argtypes = [C.c_void_p, C.c_int, c_int_p, c_double_p, c_double_p]
+    L.orc_render_sppm.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_uint64, c_int_p, C.c_double, C.c_int,
+                                  c_double_p, c_double_p, c_u64_p]
     L.orc_hit.argtypes = [C.c_void_p, C.c_int, c_double_p, c_double_p, C.c_double, C.c_double, c_double_p]
     L.orc_aabb_hit.argtypes = [c_double_p, c_double_p, c_double_p, C.c_double, C.c_double]
     L.orc_scatter.argtypes = [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p, C.c_int, C.c_double, C.c_double,
@@ -210,10 +212,26 @@ class Scene:
         return np.array(out[:])
 
     # queries
-    def set_lights(self, ids):
-        """World::new's `lights` (world.rs:18); used by the mixture-pdf integrator only."""
+    def set_lights(self, ids, flux=None, scale=None):
+        """World::new's `lights` (world.rs:18).  flux/scale: XZRectLight / SphereDiffuseLight fields (photon power =
+        flux * scale, SPPM only); default flux (1,1,1), scale 1."""
         arr = (C.c_int * len(ids))(*ids)
-        self._chk(self.L.orc_set_lights(self.h, len(ids), arr), "set_lights")
+        fl = np.ascontiguousarray(flux if flux is not None else np.ones((len(ids), 3)), dtype=np.float64).reshape(-1)
+        sc = np.ascontiguousarray(scale if scale is not None else np.ones(len(ids)), dtype=np.float64).reshape(-1)
+        self._chk(self.L.orc_set_lights(self.h, len(ids), arr, fl.ctypes.data_as(c_double_p), sc.ctypes.data_as(c_double_p)), "set_lights")
+
+    def render_sppm(self, width, height, spp, iterations=50, photons_per_iter=500000, alpha=0.7, k_global=100, k_caustic=50,
+                    max_bounces=4096, max_depth=50, t_min=1e-3, seed=1, n_workers=None):
+        """SPPMIntegrator::new + capture_image (main.rs:52-54): returns (radiance [H,W,3], stats [H,W,10], (n_global, n_caustic))."""
+        if n_workers is None:
+            n_workers = os.cpu_count() or 1
+        cfg = (C.c_int * 5)(iterations, photons_per_iter, k_global, k_caustic, max_bounces)
+        out = np.zeros((height, width, 3), dtype=np.float64)
+        stats = np.zeros((height, width, 10), dtype=np.float64)
+        tot = (C.c_uint64 * 2)()
+        self._chk(self.L.orc_render_sppm(self.h, width, height, spp, max_depth, float(t_min), int(seed), cfg, float(alpha), n_workers,
+                                         out.ctypes.data_as(c_double_p), stats.ctypes.data_as(c_double_p), tot), "render_sppm")
+        return out, stats, (int(tot[0]), int(tot[1]))
 
     def render(self, width, height, spp, max_depth=50, t_min=1e-3, seed=1, window=None, n_jobs=64, n_workers=None, integrator=0):
         """Camera::capture_image: returns (radiance f64 [wh,ww,3], counters dict).
@@ -438,6 +456,6 @@ def cornell_box_scene(cube_obj_path, aspect_ratio=1.0, seed=1):
         sc.Cube((300.0, 0.0, 100.0), (380.0, 100.0, 180.0), white),
     ]
     sc.World(items, seed)
-    sc.set_lights([light])  # scene.rs:110 vec![Arc::new(light)]
+    sc.set_lights([light], flux=[(1.0, 1.0, 1.0)], scale=[1000000.0])  # scene.rs:26-32,110: XZRectLight(.., flux (1,1,1), scale 1e6)
     sc.Camera((278.0, 278.0, -800.0), (278.0, 278.0, 278.0), (0.0, 1.0, 0.0), 50.0, aspect_ratio, 0.0, 10.0)
     return sc

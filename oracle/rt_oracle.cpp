@@ -679,6 +679,8 @@ struct Scene {
     std::vector<std::unique_ptr<Hitable>> objects;
     const Hitable* root = nullptr;
     std::vector<const Hitable*> lights;  // World::new's `lights` (world.rs:18): Sphere / XZ Rect hitables
+    std::vector<Vec3> light_flux;        // XZRectLight / SphereDiffuseLight `flux` (light.rs:69-72,129-132)
+    std::vector<double> light_scale;     // ... and `scale` (photon power = flux * scale)
     Camera cam;
     bool cam_set = false;
     std::string err;
@@ -807,12 +809,328 @@ static Vec3 sample_ray_mixture(const Scene& sc, Ray ray, int max_depth, double t
     return radiance;
 }
 
+// ----------------------------------------------------------------------------
+// SPPM -- the reference's actual integrator (integrator/photon_mapper.rs:17-324): per iteration, trace
+// photons from the lights into a global and a caustic photon map, shoot one eye ray per pixel to its first
+// diffuse hit and update that pixel's progressive statistics; the final render adds the per-pixel radiance
+// estimate on the first Diffuse hit and stops (photon_mapper.rs:345-352).  SURVEY.md s8f "next" #3.
+// Restated with seeded streams.  The photon maps are queried by BRUTE FORCE here (the reference uses the
+// un-vendored kd-tree 0.4.1 crate; only the query RESULTS matter):
+//   nearests(p, k)        -> the k photons of smallest squared distance      (photon_mapper.rs:85)
+//   within_radius(p, r)   -> photons with  d^2 < r*r                         (photon_mapper.rs:105)
+// DIVERGENCE D6: the flux of a query is accumulated in fixed point (terms rounded to 2^-S, S from the
+// brightest light) so that the sum does not depend on the order in which a spatial index returns photons --
+// the reference's order is that of the kd-tree crate and cannot be reproduced; the difference is ~1e-12
+// relative.  D7: photon and eye paths are capped at `max_bounces` (the reference loops until absorbed).
+// PARITY UNPINNED (no reference test touches this code).
+// ----------------------------------------------------------------------------
+struct Photon {  // light.rs:19-25
+    Vec3 position, power, direction, norm;
+};
+struct SPPM {  // photon_mapper.rs:33-40
+    Vec3 flux;
+    double radius2 = 0.;
+    uint64_t photons = 0;
+};
+struct SPPMPixel {  // photon_mapper.rs:66-70
+    SPPM global, caustic;
+};
+struct SppmConfig {
+    int iterations = 50;          // max_iter_cnt, photon_mapper.rs:148
+    int photons_per_iter = 500000;  // photon_mapper.rs:149
+    double alpha = 0.7;           // ALPHA :17
+    int k_global = 100;           // GLOBAL_INIT_PHOTONS :18
+    int k_caustic = 50;           // CAUSTIC_INIT_PHOTONS :19
+    int max_bounces = 4096;       // D7
+};
+static const uint64_t SALT_PHOTON = 0x50484F544F4E5F31ULL, SALT_EYE = 0x5350504D4559455FULL;
+
+static int sppm_fixed_shift(const Scene& sc) {
+    double maxp = 0.;
+    for (size_t i = 0; i < sc.lights.size(); i++) {
+        Vec3 p = v_muls(sc.light_flux[i], sc.light_scale[i]);
+        maxp = std::fmax(maxp, std::fmax(std::fabs(p.x), std::fmax(std::fabs(p.y), std::fabs(p.z))));
+    }
+    if (!(maxp > 0.) || !std::isfinite(maxp)) return 40;
+    int e;
+    std::frexp(maxp, &e);  // maxp = m * 2^e, m in [0.5, 1)
+    int S = 40 - e;
+    return S < 0 ? 0 : (S > 60 ? 60 : S);
+}
+struct FixedFlux {
+    int64_t x = 0, y = 0, z = 0;
+    void add(Vec3 t, int S) {
+        x += std::llrint(std::ldexp(t.x, S));
+        y += std::llrint(std::ldexp(t.y, S));
+        z += std::llrint(std::ldexp(t.z, S));
+    }
+    Vec3 get(int S) const { return Vec3(std::ldexp((double)x, -S), std::ldexp((double)y, -S), std::ldexp((double)z, -S)); }
+};
+
+// AllLights::emit (light.rs:220-225): WeightedIndex over |power| ; then Light::emit
+static void lights_emit(const Scene& sc, const std::vector<double>& cum, double total, Rng& rng, Ray& ray, Vec3& power) {
+    double chosen = rng.gen_range(0., total);  // WeightedIndex: Uniform::new(0, total_weight)
+    size_t idx = 0;
+    while (idx + 1 < sc.lights.size() && cum[idx] <= chosen) idx++;  // partition_point(|w| w <= chosen) over the first n-1 sums
+    const Hitable* l = sc.lights[idx];
+    Vec3 flux = sc.light_flux[idx];
+    double scale = sc.light_scale[idx];
+    if (const Rect* r = dynamic_cast<const Rect*>(l)) {  // XZRectLight::emit, light.rs:158-166
+        double u = rng.gen_range(0., 1.), v = rng.gen_range(0., 1.);
+        Vec3 orig(r->a0 + (r->a1 - r->a0) * u, r->k, r->b0 + (r->b1 - r->b0) * v);
+        Vec3 w = random_in_hemisphere(rng, Vec3(0., -1., 0.));
+        ray = Ray{orig, w};
+        power = v_muls(v_muls(flux, scale), std::fmax(v_dot(Vec3(0., -1., 0.), w), 0.));
+    } else {  // SphereDiffuseLight::emit, light.rs:98-103
+        const Sphere* s = static_cast<const Sphere*>(l);
+        Vec3 norm = random_in_unit_sphere(rng);
+        Vec3 point = v_add(s->center, v_muls(norm, s->radius + 0.0001));
+        Vec3 dir = random_in_hemisphere(rng, norm);
+        ray = Ray{point, dir};
+        power = v_muls(flux, scale);
+    }
+}
+
+// SPPMIntegrator::generate_photon_map (photon_mapper.rs:234-276) for photon paths [g0, g1) of the global numbering
+static void trace_photons(const Scene& sc, const SppmConfig& cfg, uint64_t seed, uint64_t g0, uint64_t g1, std::vector<Photon>& all,
+                          std::vector<Photon>& caustic) {
+    std::vector<double> cum;
+    double total = 0.;
+    {
+        std::vector<double> lp;
+        double tot = 0.;
+        for (size_t i = 0; i < sc.lights.size(); i++) {  // AllLights::new, light.rs:202-217
+            lp.push_back(v_len(v_muls(sc.light_flux[i], sc.light_scale[i])));
+            tot = tot + lp.back();
+        }
+        for (size_t i = 0; i < lp.size(); i++) {
+            total = total + lp[i] / tot;
+            cum.push_back(total);
+        }
+    }
+    Ctx cx;
+    for (uint64_t g = g0; g < g1; g++) {
+        cx.rng = Rng(seed ^ SALT_PHOTON, g, 0);
+        Ray ray;
+        Vec3 power;
+        lights_emit(sc, cum, total, cx.rng, ray, power);
+        bool has_specular = false, has_diffuse = false;
+        HitRecord rec;
+        for (int bounce = 0; bounce < cfg.max_bounces; bounce++) {
+            if (!sc.root->hit(ray, 0.0001, INF, rec, cx)) break;
+            // Material::scatter_photon, material.rs:27-45 (Russian roulette on max(f))
+            ScatterResult sr = rec.mat->scatter(ray, rec, cx);
+            Interaction kind = Absorb;
+            bool cont = false;
+            Vec3 new_power;
+            if (sr.has_att) {
+                double hmax = v_max(sr.att);
+                if (cx.rng.gen_f64() > hmax) {
+                    kind = Absorb;
+                } else {
+                    kind = sr.kind;
+                    new_power = v_elemul(power, v_divs(sr.att, v_max(sr.att)));
+                    cont = sr.has_ray;
+                }
+            }
+            if (kind == Diffuse) {
+                Photon ph{rec.p, power, ray.dir, rec.normal};
+                all.push_back(ph);
+                if (!has_diffuse && has_specular) caustic.push_back(ph);
+                has_diffuse = true;
+            } else if (kind == Absorb) {
+                break;
+            } else {
+                has_specular = true;
+            }
+            if (cont) {
+                ray = sr.ray;
+                power = new_power;
+            }
+        }
+    }
+}
+
+struct GatherPoint {  // what update_sppm needs from the eye path's first Diffuse hit
+    bool valid = false;
+    Vec3 p, bsdf;  // rec.p and rec.mat.bsdf(., rec) (constant over photons for every material of the reference)
+};
+static double disk_factor(Vec3 p, const Photon& ph) {  // photon_mapper.rs:77-79
+    return std::fabs(v_dot(ph.norm, v_unit(v_sub(ph.position, p))));
+}
+// PhotonMap::estimate_flux_by_count, photon_mapper.rs:82-100
+static void estimate_by_count(const std::vector<Photon>& pm, const GatherPoint& gp, size_t k, int S, Vec3& flux, double& radius2) {
+    std::vector<double> d2(pm.size());
+    for (size_t i = 0; i < pm.size(); i++) d2[i] = v_sqlen(v_sub(pm[i].position, gp.p));
+    radius2 = 0.;
+    FixedFlux acc;
+    if (!pm.empty()) {
+        size_t kk = std::min(k, pm.size());
+        std::vector<double> tmp = d2;
+        std::nth_element(tmp.begin(), tmp.begin() + (kk - 1), tmp.end());
+        double r2k = tmp[kk - 1];  // squared distance of the k-th nearest
+        for (size_t i = 0; i < pm.size(); i++)
+            if (d2[i] <= r2k) {  // exact ties at the k-th distance are all taken (measure zero)
+                radius2 = std::fmax(radius2, d2[i]);
+                acc.add(v_muls(v_elemul(gp.bsdf, pm[i].power), 1. - disk_factor(gp.p, pm[i])), S);
+            }
+    }
+    flux = acc.get(S);
+}
+// PhotonMap::estimate_flux_within_radius, photon_mapper.rs:101-114
+static void estimate_within_radius(const std::vector<Photon>& pm, const GatherPoint& gp, double radius, int S, Vec3& flux, uint64_t& count) {
+    FixedFlux acc;
+    count = 0;
+    for (size_t i = 0; i < pm.size(); i++) {
+        double d2 = v_sqlen(v_sub(pm[i].position, gp.p));
+        if (d2 < radius * radius) {
+            count++;
+            acc.add(v_muls(v_elemul(gp.bsdf, pm[i].power), 1. - disk_factor(gp.p, pm[i])), S);
+        }
+    }
+    flux = acc.get(S);
+}
+// SPPM::update, photon_mapper.rs:49-63
+static void sppm_update(SPPM& s, const GatherPoint& gp, const std::vector<Photon>& pm, size_t photon_init, double alpha, int S) {
+    if (s.photons == 0) {
+        s.photons = photon_init;
+        estimate_by_count(pm, gp, photon_init, S, s.flux, s.radius2);
+    } else {
+        Vec3 flux;
+        uint64_t found;
+        estimate_within_radius(pm, gp, std::sqrt(s.radius2), S, flux, found);
+        uint64_t prev = s.photons;
+        s.photons += (uint64_t)(alpha * (double)found);
+        double frac = (double)s.photons / (double)(prev + found);
+        s.radius2 *= frac;
+        s.flux = v_muls(v_add(s.flux, flux), frac);
+    }
+}
+// SPPMIntegrator::update_sppm's eye path, photon_mapper.rs:277-296
+static GatherPoint eye_gather_point(const Scene& sc, Ray ray, const SppmConfig& cfg, Ctx& cx) {
+    GatherPoint gp;
+    Ray curr = ray;
+    HitRecord rec;
+    for (int bounce = 0; bounce < cfg.max_bounces; bounce++) {
+        if (!sc.root->hit(curr, 0.001, INF, rec, cx)) break;
+        ScatterResult sr = rec.mat->scatter(curr, rec, cx);
+        if (sr.kind == Diffuse) {
+            gp.valid = true;
+            gp.p = rec.p;
+            gp.bsdf = rec.mat->bsdf(curr.dir, rec);
+            break;
+        }
+        if (sr.has_ray && sr.has_att) curr = sr.ray;
+        else break;
+    }
+    return gp;
+}
+
+// SPPMIntegrator::new (photon_mapper.rs:139-233): returns per-pixel stats, pixel-major [y*W + x]
+static int sppm_prepass(const Scene& sc, const SppmConfig& cfg, int width, int height, uint64_t seed, int n_workers,
+                        std::vector<SPPMPixel>& px, uint64_t* n_global_total, uint64_t* n_caustic_total) {
+    if (!sc.root || !sc.cam_set || sc.lights.empty()) return -1;
+    px.assign((size_t)width * height, SPPMPixel());
+    const int S = sppm_fixed_shift(sc);
+    if (n_workers < 1) n_workers = 1;
+    std::atomic<int> err{0};
+    uint64_t tg = 0, tc = 0;
+    for (int it = 0; it < cfg.iterations; it++) {
+        // photon tracing pass (parallel over photon paths; the maps are sets, their order is irrelevant by D6)
+        std::vector<std::vector<Photon>> all_t(n_workers), cau_t(n_workers);
+        {
+            std::vector<std::thread> th;
+            for (int w = 0; w < n_workers; w++)
+                th.emplace_back([&, w]() {
+                    uint64_t P = (uint64_t)cfg.photons_per_iter;
+                    uint64_t a = P * w / n_workers, b = P * (w + 1) / n_workers;
+                    try {
+                        trace_photons(sc, cfg, seed, (uint64_t)it * P + a, (uint64_t)it * P + b, all_t[w], cau_t[w]);
+                    } catch (const UnitZero&) {
+                        err.store(-2);
+                    }
+                });
+            for (auto& t : th) t.join();
+        }
+        std::vector<Photon> all, cau;
+        for (int w = 0; w < n_workers; w++) {
+            all.insert(all.end(), all_t[w].begin(), all_t[w].end());
+            cau.insert(cau.end(), cau_t[w].begin(), cau_t[w].end());
+        }
+        tg += all.size();
+        tc += cau.size();
+        // eye pass: one jittered ray per pixel (photon_mapper.rs:186-201)
+        std::atomic<int> next_row{0};
+        std::vector<std::thread> th;
+        for (int w = 0; w < n_workers; w++)
+            th.emplace_back([&]() {
+                Ctx cx;
+                for (;;) {
+                    int y = next_row.fetch_add(1);
+                    if (y >= height) break;
+                    for (int x = 0; x < width; x++) {
+                        try {
+                            uint64_t pix = (uint64_t)y * width + x;
+                            cx.rng = Rng(seed ^ SALT_EYE, pix, (uint64_t)it);
+                            double u = ((double)x + cx.rng.gen_f64()) / (double)(width - 1);
+                            double v = ((double)y + cx.rng.gen_f64()) / (double)(height - 1);
+                            Ray r = sc.cam.get_ray(u, 1.0 - v, cx.rng);
+                            GatherPoint gp = eye_gather_point(sc, r, cfg, cx);
+                            if (gp.valid) {
+                                sppm_update(px[pix].caustic, gp, cau, (size_t)cfg.k_caustic, cfg.alpha, S);  // caustic first (:284)
+                                sppm_update(px[pix].global, gp, all, (size_t)cfg.k_global, cfg.alpha, S);
+                            }
+                        } catch (const UnitZero&) {
+                            err.store(-2);
+                        }
+                    }
+                }
+            });
+        for (auto& t : th) t.join();
+    }
+    if (n_global_total) *n_global_total = tg;
+    if (n_caustic_total) *n_caustic_total = tc;
+    return err.load();
+}
+// adjust_flux, photon_mapper.rs:117-119 ; N = max_iter_cnt * photon_per_iter for both maps (:227-228)
+static Vec3 sppm_estimate(const SPPM& s, double n_emitted) { return v_divs(s.flux, PI * s.radius2 * n_emitted); }
+
+// SPPMIntegrator::sample_ray LITERALLY (photon_mapper.rs:327-365): Diffuse adds the pixel's estimates and stops
+static Vec3 sample_ray_sppm(const Scene& sc, Ray ray, int max_depth, double t_min, Vec3 est_caustic, Vec3 est_global, Ctx& cx) {
+    Vec3 throughput(1, 1, 1);
+    Vec3 radiance(0, 0, 0);
+    Ray curr = ray;
+    int depth = max_depth;
+    HitRecord rec;
+    for (;;) {
+        cx.cnt.n_segments++;
+        if (!sc.root->hit(curr, t_min, INF, rec, cx)) break;
+        if (depth <= 0) break;
+        depth -= 1;
+        radiance = v_add(radiance, v_elemul(throughput, rec.mat->emitted(rec)));
+        ScatterResult sr = rec.mat->scatter(curr, rec, cx);
+        if (sr.kind == Diffuse && sr.has_ray && sr.has_att) {
+            radiance = v_add(radiance, v_elemul(throughput, est_caustic));
+            radiance = v_add(radiance, v_elemul(throughput, est_global));
+            break;
+        } else if (sr.has_ray && sr.has_att) {
+            throughput = v_elemul(throughput, sr.att);
+            curr = sr.ray;
+        } else {
+            break;
+        }
+    }
+    return radiance;
+}
+
 struct RenderArgs {
     int width, height, spp, max_depth;
     double t_min;
     uint64_t seed;
     int x0, y0, x1, y1;  // pixel window [x0,x1) x [y0,y1) rendered with the full-frame camera mapping
-    int integrator = 0;  // 0: sample_ray (BSDF sampling only); 1: sample_ray_mixture (light/cosine mixture pdf)
+    int integrator = 0;  // 0: sample_ray (BSDF sampling only); 1: sample_ray_mixture; 2: sample_ray_sppm (needs `sppm`)
+    const SPPMPixel* sppm = nullptr;  // per-pixel statistics of the pre-pass, [y*W + x]
+    double sppm_emitted = 0.;         // iterations * photons_per_iter
 };
 
 // Camera::capture_image -- camera.rs:66-128.  n_jobs row bands executed FIFO by
@@ -821,6 +1139,7 @@ struct RenderArgs {
 static int render(const Scene& sc, const RenderArgs& a, int n_jobs, int n_workers, double* out_rgb, Counters* total) {
     if (!sc.root || !sc.cam_set) return -1;
     if (a.integrator == 1 && sc.lights.empty()) return -1;
+    if (a.integrator == 2 && !a.sppm) return -1;
     const int wh = a.y1 - a.y0, ww = a.x1 - a.x0;
     if (n_jobs < 1) n_jobs = 1;
     if (n_workers < 1) n_workers = 1;
@@ -839,13 +1158,20 @@ static int render(const Scene& sc, const RenderArgs& a, int n_jobs, int n_worker
                 for (int x = a.x0; x < a.x1; x++) {  // x is the OUTER loop, camera.rs:91
                     for (int y = row_begin; y < row_end; y++) {
                         Vec3 pixel(0, 0, 0);
+                        Vec3 est_c, est_g;
+                        if (a.integrator == 2) {
+                            const SPPMPixel& sp = a.sppm[(size_t)y * a.width + x];
+                            est_c = sppm_estimate(sp.caustic, a.sppm_emitted);
+                            est_g = sppm_estimate(sp.global, a.sppm_emitted);
+                        }
                         for (int s = 0; s < a.spp; s++) {
                             cx.rng = Rng(a.seed, (uint64_t)y * (uint64_t)a.width + (uint64_t)x, (uint64_t)s);
                             double u = ((double)x + cx.rng.gen_f64()) / (double)(a.width - 1);
                             double v = ((double)y + cx.rng.gen_f64()) / (double)(a.height - 1);
                             Ray r = sc.cam.get_ray(u, 1.0 - v, cx.rng);
-                            pixel = v_add(pixel, a.integrator == 1 ? sample_ray_mixture(sc, r, a.max_depth, a.t_min, cx)
-                                                                   : sample_ray(sc, r, a.max_depth, a.t_min, cx));
+                            pixel = v_add(pixel, a.integrator == 2   ? sample_ray_sppm(sc, r, a.max_depth, a.t_min, est_c, est_g, cx)
+                                                 : a.integrator == 1 ? sample_ray_mixture(sc, r, a.max_depth, a.t_min, cx)
+                                                                     : sample_ray(sc, r, a.max_depth, a.t_min, cx));
                             cx.cnt.n_samples++;
                         }
                         pixel = v_divs(pixel, (double)a.spp);
@@ -1153,9 +1479,15 @@ int orc_set_root(void* s, int o) {
     return ORC_OK;
 }
 // World::new's lights (world.rs:18): each must be a Sphere or an XZ rectangle (the reference's two Light impls)
-int orc_set_lights(void* s, int n, const int* ids) {
+int orc_set_lights(void* s, int n, const int* ids, const double* flux3, const double* scales) {
     Scene& sc = *(Scene*)s;
     std::vector<const Hitable*> v;
+    sc.light_flux.clear();
+    sc.light_scale.clear();
+    for (int i = 0; i < n; i++) {
+        sc.light_flux.push_back(flux3 ? Vec3(flux3[3 * i], flux3[3 * i + 1], flux3[3 * i + 2]) : Vec3(1, 1, 1));
+        sc.light_scale.push_back(scales ? scales[i] : 1.);
+    }
     for (int i = 0; i < n; i++) {
         const Hitable* h = obj(sc, ids[i]);
         if (!h) return ORC_ERR_ARG;
@@ -1180,7 +1512,8 @@ int orc_render(void* s, int width, int height, int spp, int max_depth, double t_
                int n_jobs, int n_workers, double* out_rgb, uint64_t* counters7, int integrator) {
     Scene& sc = *(Scene*)s;
     if (width <= 0 || height <= 0 || spp <= 0 || x0 < 0 || y0 < 0 || x1 > width || y1 > height || x1 <= x0 || y1 <= y0 || !out_rgb) return ORC_ERR_ARG;
-    RenderArgs a{width, height, spp, max_depth, t_min, seed, x0, y0, x1, y1, integrator};
+    RenderArgs a{width, height, spp, max_depth, t_min, seed, x0, y0, x1, y1, integrator, nullptr, 0.};
+    if (integrator == 2) return ORC_ERR_ARG;  // use orc_render_sppm
     Counters c;
     int rc = render(sc, a, n_jobs, n_workers, out_rgb, &c);
     if (counters7) {
@@ -1262,6 +1595,35 @@ int orc_camera_ray(void* s, int width, int height, int x, int y, uint64_t seed, 
     out6[0] = r.orig.x; out6[1] = r.orig.y; out6[2] = r.orig.z;
     out6[3] = r.dir.x; out6[4] = r.dir.y; out6[5] = r.dir.z;
     return ORC_OK;
+}
+
+// SPPMIntegrator::new + capture_image (main.rs:52-54).  cfg5 = {iterations, photons_per_iter, k_global, k_caustic, max_bounces};
+// stats out (optional): per pixel 10 doubles {g.flux[3], g.radius2, g.photons, c.flux[3], c.radius2, c.photons}; totals2 = photons stored.
+int orc_render_sppm(void* s, int width, int height, int spp, int max_depth, double t_min, uint64_t seed, const int* cfg5, double alpha,
+                    int n_workers, double* out_rgb, double* stats_out, uint64_t* totals2) {
+    Scene& sc = *(Scene*)s;
+    if (width <= 0 || height <= 0 || spp < 0 || !cfg5) return ORC_ERR_ARG;
+    SppmConfig cfg;
+    cfg.iterations = cfg5[0]; cfg.photons_per_iter = cfg5[1]; cfg.k_global = cfg5[2]; cfg.k_caustic = cfg5[3]; cfg.max_bounces = cfg5[4];
+    cfg.alpha = alpha;
+    std::vector<SPPMPixel> px;
+    uint64_t tg = 0, tc = 0;
+    int rc = sppm_prepass(sc, cfg, width, height, seed, n_workers, px, &tg, &tc);
+    if (rc < 0) return rc;
+    if (totals2) { totals2[0] = tg; totals2[1] = tc; }
+    if (stats_out)
+        for (size_t i = 0; i < px.size(); i++) {
+            double* o = stats_out + 10 * i;
+            const SPPM* two[2] = {&px[i].global, &px[i].caustic};
+            for (int k = 0; k < 2; k++) {
+                o[5 * k] = two[k]->flux.x; o[5 * k + 1] = two[k]->flux.y; o[5 * k + 2] = two[k]->flux.z;
+                o[5 * k + 3] = two[k]->radius2; o[5 * k + 4] = (double)two[k]->photons;
+            }
+        }
+    if (spp == 0 || !out_rgb) return ORC_OK;
+    RenderArgs a{width, height, spp, max_depth, t_min, seed, 0, 0, width, height, 2, px.data(),
+                 (double)cfg.iterations * (double)cfg.photons_per_iter};
+    return render(sc, a, 64, n_workers, out_rgb, nullptr);
 }
 
 void orc_tonemap_u8(const double* rgb, size_t n_channels, uint8_t* out) {

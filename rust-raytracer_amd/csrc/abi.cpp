@@ -150,20 +150,26 @@ int rt_object_cube(rt_scene* s, const double box_min[3], const double box_max[3]
         return add_cube(*s, box_min, box_max, material);
     });
 }
-int rt_object_sphere_light(rt_scene* s, const double center[3], double radius, const double flux[3]) {
+static int mark_light(rt_scene* s, int obj, const double flux[3], double scale) {
+    ObjectRec& o = s->objects[obj];
+    for (int i = 0; i < 3; i++) o.light_flux[i] = flux[i];
+    o.light_scale = scale;
+    return obj;
+}
+int rt_object_sphere_light(rt_scene* s, const double center[3], double radius, const double flux[3], double scale) {
     return guard([&] {  // SphereDiffuseLight::new, light.rs:74-86
         not_committed_only(s);
         REQUIRE(center && flux, "null argument");
         int m = add_material(*s, MAT_DIFFUSE_LIGHT, add_texture_constant(*s, flux), 0.);
-        return add_sphere(*s, center, radius, m);
+        return mark_light(s, add_sphere(*s, center, radius, m), flux, scale);
     });
 }
-int rt_object_xz_rect_light(rt_scene* s, double x0, double z0, double x1, double z1, double y, const double flux[3]) {
-    return guard([&] {  // XZRectLight::new, light.rs:134-146 (scale only feeds photon power)
+int rt_object_xz_rect_light(rt_scene* s, double x0, double z0, double x1, double z1, double y, const double flux[3], double scale) {
+    return guard([&] {  // XZRectLight::new, light.rs:134-146 (scale only feeds the photon power)
         not_committed_only(s);
         REQUIRE(flux, "null flux");
         int m = add_material(*s, MAT_DIFFUSE_LIGHT, add_texture_constant(*s, flux), 0.);
-        return add_rect(*s, 1, x0, z0, x1, z1, y, m);
+        return mark_light(s, add_rect(*s, 1, x0, z0, x1, z1, y, m), flux, scale);
     });
 }
 int rt_object_mesh(rt_scene* s, int n_vert, const double* positions, const double* normals, int n_tri, const uint32_t* indices,
@@ -277,6 +283,8 @@ int rt_scene_cornell_box(rt_scene* s, const char* cube_obj_path, double aspect_r
         items.push_back(add_sphere(*s, c1, 100., add_material(*s, MAT_DIELECTRIC, ctex(0.999, 0.999, 0.999), 1.5)));
         items.push_back(add_sphere(*s, c2, 100., add_material(*s, MAT_METAL, ctex(0.999, 0.999, 0.999), 0.)));
         const int light_obj = add_rect(*s, 1, 213., 227., 343., 332., 554., light);
+        const double one[3] = {1., 1., 1.};
+        mark_light(s, light_obj, one, 1000000.);  // XZRectLight::new((213,227),(343,332),554, flux (1,1,1), scale 1e6), scene.rs:26-32
         items.push_back(light_obj);
         s->lights = {light_obj};  // scene.rs:110 vec![Arc::new(light)]
         ObjMesh m = load_obj_file(cube_obj_path);
@@ -327,7 +335,7 @@ static RenderPlan make_plan(const rt_params* p) {
     REQUIRE(p->max_depth >= 0, "max_depth must be >= 0");
     REQUIRE(p->world >= 1 && p->rank >= 0 && p->rank < p->world, "bad rank/world");
     REQUIRE(p->kernel >= 0 && p->kernel <= 3, "unknown kernel id");
-    REQUIRE(p->integrator == 0 || p->integrator == 1, "unknown integrator id");
+    REQUIRE(p->integrator >= 0 && p->integrator <= 2, "unknown integrator id");
     RenderPlan pl;
     pl.width = p->width; pl.height = p->height; pl.spp = p->spp; pl.max_depth = p->max_depth;
     pl.t_min = p->t_min; pl.seed = p->seed; pl.rank = p->rank; pl.world = p->world;
@@ -458,6 +466,54 @@ int rt_render(const rt_scene* s, const rt_camera* cam, const rt_params* p, doubl
     });
 }
 
+void rt_default_sppm_config(rt_sppm_config* c) {
+    if (!c) return;
+    std::memset(c, 0, sizeof(*c));
+    c->iterations = 50;            // photon_mapper.rs:148
+    c->photons_per_iter = 500000;  // photon_mapper.rs:149
+    c->k_global = 100;             // GLOBAL_INIT_PHOTONS
+    c->k_caustic = 50;             // CAUSTIC_INIT_PHOTONS
+    c->max_bounces = 4096;
+    c->alpha = 0.7;                // ALPHA
+}
+int rt_render_sppm(const rt_scene* s, const rt_camera* cam, const rt_params* p, const rt_sppm_config* cfg, double* out_rgb, double* stats_out,
+                   uint64_t photons_stored[2], rt_stats* stats) {
+    return guard([&] {
+        REQUIRE(s && cam && p && cfg, "null argument");
+        REQUIRE(p->spp == 0 || out_rgb, "null output buffer");
+        if (!s->committed) throw RtError(RT_ERR_NOT_COMMITTED, "rt_scene_commit has not been called");
+        if (device_count() < 1) throw RtError(RT_ERR_NO_DEVICE, "no HIP device: librtamd has no CPU fallback");
+        auto t0 = std::chrono::steady_clock::now();
+        if (p->device >= 0) dev_set_device(p->device);
+        rt_params q = *p;
+        if (q.spp == 0) q.spp = 1;  // make_plan wants a positive spp; the pre-pass-only case never launches the render
+        q.integrator = 0;
+        RenderPlan pl = make_plan(&q);
+        pl.spp = p->spp;
+        CameraDev cd = make_camera(*cam);
+        struct Buf {
+            void* p = nullptr;
+            ~Buf() {
+                if (p) dev_free(p);
+            }
+        } tiles, frame;
+        size_t frame_bytes = (size_t)pl.width * pl.height * 3 * sizeof(double);
+        tiles.p = dev_alloc((size_t)std::max<int64_t>(1, pl.tiles_owned) * TILE_PIX * 3 * sizeof(double));
+        frame.p = dev_alloc(frame_bytes);
+        rt_stats st{};
+        render_sppm(*s, cd, pl, *cfg, (double*)tiles.p, stats_out, nullptr, &st, photons_stored);
+        if (p->spp > 0) {
+            assemble_frame(pl, (const double*)tiles.p, pl.tiles_owned, (double*)frame.p, nullptr);
+            dev_copy_to_host(out_rgb, frame.p, frame_bytes);
+        }
+        if (stats) {
+            *stats = st;
+            stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            stats->samples = (uint64_t)pl.width * pl.height * (uint64_t)p->spp;
+        }
+        return (int)RT_OK;
+    });
+}
 int rt_tonemap_u8(const double* rgb, size_t n_channels, uint8_t* out) {
     return guard([&] {
         REQUIRE((rgb && out) || n_channels == 0, "null argument");

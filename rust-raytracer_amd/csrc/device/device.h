@@ -19,12 +19,16 @@ struct RenderPlan {
     int spp_chunk;  // samples per pixel per launch (sample-buffer capacity)
     int sub_spp;    // samples per pixel per work unit (one wave drains 64*sub_spp paths)
     int kernel;
-    int integrator;  // 0 BSDF sampling, 1 light/cosine mixture pdf
+    int integrator;  // 0 BSDF sampling, 1 light/cosine mixture pdf, 2 SPPM final gather (needs sppm_est)
+    const double* sppm_est = nullptr;  // device: per pixel {caustic estimate[3], global estimate[3]}
 };
 
 // Renders plan.tiles_owned tiles into d_tiles (device, tile-major f64 RGB) on `stream`; blocks until done.
 // Throws RtError.
 void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& plan, double* d_tiles, void* stream, rt_stats* st);
+// SPPMIntegrator::new + capture_image: pre-pass statistics (optional host copy, 10 f64 per pixel) and the final render
+void render_sppm(const rt_scene& s, const CameraDev& cam, RenderPlan plan, const rt_sppm_config& cfg, double* d_tiles, double* stats_host,
+                 void* stream, rt_stats* st, uint64_t* totals2);
 void assemble_frame(const RenderPlan& plan, const double* d_gathered, int64_t tiles_per_rank_stride, double* d_frame, void* stream);
 void debug_rng_device(uint64_t seed, uint64_t pixel, uint64_t sample, int n, uint64_t* out_host);
 void debug_math_device(int op, size_t n, const double* a, const double* b, double* out);

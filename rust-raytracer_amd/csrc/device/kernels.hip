@@ -22,7 +22,9 @@
 
 #include <cmath>
 #include <cstdio>
+#include <chrono>
 #include <cstdlib>
+#include <cstring>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -171,6 +173,7 @@ struct RenderK {
     int tiles_x, rank, world;
     int chunk_spp;  // sample-buffer stride
     int restart_th; // kernel 3: lanes that must have finished a segment before the wave shades
+    const double* sppm_est;  // INTEG 2: per pixel {caustic estimate[3], global estimate[3]}, index y*width + x
 };
 
 // ------------------------------------------------------ intersection ------
@@ -712,7 +715,9 @@ DEV bool mixture_step(const Acc& A, const Rec& rec, Rng& rng, D3 att, D3& beta, 
 }
 
 // ------------------------------------------------------------ pt_kernel ---
-template <bool LDS, bool GENERAL, int ACCEL, bool MIX>
+// INTEG: 0 = sample_ray with BSDF sampling; 1 = light/cosine mixture pdf; 2 = the reference's literal SPPM sample_ray:
+// the first Diffuse hit adds the pixel's pre-computed photon estimates and ends the path (photon_mapper.rs:345-352)
+template <bool LDS, bool GENERAL, int ACCEL, int INTEG>
 __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, RenderK rk, double* __restrict__ samples,
                                                       unsigned int* __restrict__ counter, int* __restrict__ err) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -751,6 +756,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
         bool alive = false;
         D3 o = mk(0, 0, 0), d = mk(0, 0, 1), beta = mk(1, 1, 1), L = mk(0, 0, 0);
         int depth = 0;
+        int pix_id = 0;
         size_t out_idx = 0;
         Rng rng;
         rng.s = 0;
@@ -777,6 +783,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
                         beta = mk(1., 1., 1.);
                         L = mk(0., 0., 0.);
                         depth = rk.max_depth;
+                        pix_id = y * rk.width + x;
                         out_idx = ((size_t)((size_t)lt * rk.chunk_spp + (s - rk.s_begin)) * TILE_PIX + pix) * 3;
                         alive = true;
                     }
@@ -800,8 +807,16 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
                     L = add(L, elemul(beta, emitted));  // radiance += throughput * Le
                     if (scattered) {  // Diffuse continues like Specular/Reflect/Refract (photon_mapper.rs:346-347)
                         bool go = true;
-                        if (MIX && diffuse) go = mixture_step(A, rec, rng, att, beta, ndir, err);
-                        else beta = elemul(beta, att);
+                        if (INTEG == 2 && diffuse) {
+                            const double* e = rk.sppm_est + 6 * (size_t)pix_id;
+                            L = add(L, elemul(beta, mk(e[0], e[1], e[2])));  // caustic estimate
+                            L = add(L, elemul(beta, mk(e[3], e[4], e[5])));  // global estimate
+                            go = false;
+                        } else if (INTEG == 1 && diffuse) {
+                            go = mixture_step(A, rec, rng, att, beta, ndir, err);
+                        } else {
+                            beta = elemul(beta, att);
+                        }
                         if (go) {
                             o = rec.p;
                             d = ndir;
@@ -1121,6 +1136,8 @@ __global__ void assemble_kernel(const double* __restrict__ gathered, int64_t str
     frame[3 * i + 2] = src[2];
 }
 
+#include "sppm.inc"
+
 // ------------------------------------------------------- debug kernels ----
 __global__ void rng_kernel(uint64_t seed, uint64_t pixel, uint64_t sample, int n, uint64_t* out) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -1332,20 +1349,24 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
     const bool lds = hot_bytes > 0 && hot_bytes + stack_bytes <= lds_max;
     pt_fn fn = nullptr;
     pt_sm_fn fn_sm = nullptr;
-    const bool mix = plan.integrator == 1;
-    if (mix && view.n_lights == 0) throw RtError(RT_ERR_ARG, "integrator 1 (light importance sampling) needs rt_scene_set_lights");
-    if (mix && kernel == 3) throw RtError(RT_ERR_UNSUPPORTED, "the diagnostic kernel 3 implements integrator 0 only");
+    const int integ = plan.integrator;
+    if (integ == 1 && view.n_lights == 0) throw RtError(RT_ERR_ARG, "integrator 1 (light importance sampling) needs rt_scene_set_lights");
+    if (integ == 2 && !plan.sppm_est) throw RtError(RT_ERR_ARG, "integrator 2 (SPPM) is reached through rt_render_sppm");
+    if (integ != 0 && kernel == 3) throw RtError(RT_ERR_UNSUPPORTED, "the diagnostic kernel 3 implements integrator 0 only");
     if (kernel == 3)
         fn_sm = lds ? (general ? pt_kernel_sm<true, true> : pt_kernel_sm<true, false>) : (general ? pt_kernel_sm<false, true> : pt_kernel_sm<false, false>);
-    else if (mix)  // the mixture variants are built for the general primitive set only
-        fn = (kernel == 2) ? (lds ? pt_kernel<true, true, 2, true> : pt_kernel<false, true, 2, true>)
-                           : (lds ? pt_kernel<true, true, 1, true> : pt_kernel<false, true, 1, true>);
+    else if (integ == 1)  // the mixture / SPPM variants are built for the general primitive set only
+        fn = (kernel == 2) ? (lds ? pt_kernel<true, true, 2, 1> : pt_kernel<false, true, 2, 1>)
+                           : (lds ? pt_kernel<true, true, 1, 1> : pt_kernel<false, true, 1, 1>);
+    else if (integ == 2)
+        fn = (kernel == 2) ? (lds ? pt_kernel<true, true, 2, 2> : pt_kernel<false, true, 2, 2>)
+                           : (lds ? pt_kernel<true, true, 1, 2> : pt_kernel<false, true, 1, 2>);
     else if (kernel == 2)
-        fn = lds ? (general ? pt_kernel<true, true, 2, false> : pt_kernel<true, false, 2, false>)
-                 : (general ? pt_kernel<false, true, 2, false> : pt_kernel<false, false, 2, false>);
+        fn = lds ? (general ? pt_kernel<true, true, 2, 0> : pt_kernel<true, false, 2, 0>)
+                 : (general ? pt_kernel<false, true, 2, 0> : pt_kernel<false, false, 2, 0>);
     else
-        fn = lds ? (general ? pt_kernel<true, true, 1, false> : pt_kernel<true, false, 1, false>)
-                 : (general ? pt_kernel<false, true, 1, false> : pt_kernel<false, false, 1, false>);
+        fn = lds ? (general ? pt_kernel<true, true, 1, 0> : pt_kernel<true, false, 1, 0>)
+                 : (general ? pt_kernel<false, true, 1, 0> : pt_kernel<false, false, 1, 0>);
     const size_t smem = (lds ? hot_bytes : 0) + stack_bytes;
     const void* fptr = (kernel == 3) ? (const void*)fn_sm : (const void*)fn;
     if (smem > 48 * 1024) HIP_CHECK(hipFuncSetAttribute(fptr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -1382,6 +1403,7 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
         rk.n_units = (int)units;
         rk.tiles_x = plan.tiles_x; rk.rank = plan.rank; rk.world = plan.world;
         rk.chunk_spp = plan.spp_chunk;
+        rk.sppm_est = plan.sppm_est;
         rk.restart_th = SM_RESTART;
         if (const char* e = getenv("RTAMD_SM_RESTART")) rk.restart_th = std::max(1, atoi(e));  // tuning knob (A/B runs)
         HIP_CHECK(hipMemsetAsync(counter.p, 0, sizeof(unsigned int), stream));
@@ -1446,6 +1468,228 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
                     hs[2 * i] ? 100.0 * hs[2 * i + 1] / (64.0 * hs[2 * i]) : 0.0);
     }
     if (h_err) throw RtError(RT_ERR_UNIT_ZERO, "unitizing zero vector (device)");
+}
+
+// ---------------------------------------------------------------- SPPM driver ----
+// SPPMIntegrator::new (photon_mapper.rs:139-233) + Camera::capture_image with the SPPM sample_ray.
+namespace {
+struct Grid {
+    DevBuf cell_start, cursor, cell_of, index, block_sums, mnmx;
+    size_t cap_cells = 0, cap_photons = 0;
+    GridK k{};
+};
+void build_grid(Grid& g, const PhotonBuf& pb, unsigned int n, hipStream_t stream) {
+    g.k = GridK{};
+    g.k.n = n;
+    g.k.dim[0] = g.k.dim[1] = g.k.dim[2] = 1;
+    g.k.cell = 1.;
+    g.k.inv_cell = 1.;
+    if (n == 0) return;
+    if (!g.mnmx.p) g.mnmx.alloc(6 * sizeof(unsigned long long));
+    unsigned long long init[6] = {~0ull, ~0ull, ~0ull, 0ull, 0ull, 0ull}, keys[6];
+    HIP_CHECK(hipMemcpyAsync(g.mnmx.p, init, sizeof(init), hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(bbox_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, (const double*)pb.pos, n, (unsigned long long*)g.mnmx.p);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(keys, g.mnmx.p, sizeof(keys), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    double lo[3], hi[3], ext[3];
+    for (int a = 0; a < 3; a++) {
+        lo[a] = f64_unkey(keys[a]);
+        hi[a] = f64_unkey(keys[3 + a]);
+        ext[a] = hi[a] - lo[a];
+        if (!(ext[a] >= 0.) || !std::isfinite(ext[a])) throw RtError(RT_ERR_UNSUPPORTED, "photon positions are not finite");
+    }
+    // photons lie on surfaces: aim at ~4 per occupied cell  ->  cell ~ 2 * sqrt(area / n)
+    double area = 2. * (ext[0] * ext[1] + ext[1] * ext[2] + ext[2] * ext[0]);
+    double longest = std::fmax(ext[0], std::fmax(ext[1], ext[2]));
+    double cell = 2. * std::sqrt(area / (double)n);
+    if (!(cell > 0.)) cell = longest > 0. ? longest : 1.;
+    const double min_cell = longest / 160.;  // at most 160 cells per axis
+    if (cell < min_cell) cell = min_cell;
+    if (!(cell > 0.)) cell = 1.;
+    size_t cells = 1;
+    for (int a = 0; a < 3; a++) {
+        int d = (int)std::floor(ext[a] / cell) + 1;
+        if (d < 1) d = 1;
+        if (d > 161) d = 161;
+        g.k.dim[a] = d;
+        g.k.lo[a] = lo[a];
+        cells *= (size_t)d;
+    }
+    g.k.cell = cell;
+    g.k.inv_cell = 1. / cell;
+    const size_t n_scan = cells + 1;
+    if (g.cap_cells < n_scan) {
+        g.cell_start = DevBuf();
+        g.cursor = DevBuf();
+        g.block_sums = DevBuf();
+        g.cell_start.alloc(n_scan * 4);
+        g.cursor.alloc(n_scan * 4);
+        g.block_sums.alloc(((n_scan + 1023) / 1024 + 1) * 4);
+        g.cap_cells = n_scan;
+    }
+    if (g.cap_photons < n) {
+        g.cell_of = DevBuf();
+        g.index = DevBuf();
+        g.cell_of.alloc((size_t)n * 4);
+        g.index.alloc((size_t)n * 4);
+        g.cap_photons = n;
+    }
+    HIP_CHECK(hipMemsetAsync(g.cell_start.p, 0, n_scan * 4, stream));
+    HIP_CHECK(hipMemsetAsync(g.cursor.p, 0, n_scan * 4, stream));
+    hipLaunchKernelGGL(cell_count_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, (const double*)pb.pos, n, g.k, (unsigned int*)g.cell_start.p,
+                       (unsigned int*)g.cell_of.p);
+    const unsigned int nb = (unsigned int)((n_scan + 1023) / 1024);
+    hipLaunchKernelGGL(scan_block_kernel, dim3(nb), dim3(1024), 0, stream, (unsigned int*)g.cell_start.p, (unsigned int)n_scan, (unsigned int*)g.block_sums.p);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, stream, (unsigned int*)g.block_sums.p, nb);
+    hipLaunchKernelGGL(scan_add_kernel, dim3(nb), dim3(1024), 0, stream, (unsigned int*)g.cell_start.p, (unsigned int)n_scan, (const unsigned int*)g.block_sums.p, 0u);
+    hipLaunchKernelGGL(cell_fill_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, (const unsigned int*)g.cell_of.p, (const unsigned int*)g.cell_start.p,
+                       (unsigned int*)g.cursor.p, (unsigned int*)g.index.p);
+    HIP_CHECK(hipGetLastError());
+    g.k.cell_start = (const unsigned int*)g.cell_start.p;
+    g.k.index = (const unsigned int*)g.index.p;
+}
+struct PhotonStore {
+    DevBuf pos, power, norm, count;
+    PhotonBuf b{};
+    void alloc(unsigned int cap) {
+        pos = DevBuf(); power = DevBuf(); norm = DevBuf();
+        pos.alloc((size_t)cap * 24);
+        power.alloc((size_t)cap * 24);
+        norm.alloc((size_t)cap * 24);
+        if (!count.p) count.alloc(4);
+        b.pos = (double*)pos.p; b.power = (double*)power.p; b.norm = (double*)norm.p; b.count = (unsigned int*)count.p; b.cap = cap;
+    }
+};
+}  // namespace
+
+void render_sppm(const rt_scene& s, const CameraDev& cam, RenderPlan plan, const rt_sppm_config& cfg, double* d_tiles, double* stats_host,
+                 void* stream_, rt_stats* st, uint64_t* totals2) {
+    if (!s.committed) throw RtError(RT_ERR_NOT_COMMITTED, "scene not committed");
+    if (s.lights.empty()) throw RtError(RT_ERR_ARG, "SPPM needs lights (rt_scene_set_lights)");
+    if (cfg.iterations < 1 || cfg.photons_per_iter < 1 || cfg.k_global < 1 || cfg.k_caustic < 1 || cfg.max_bounces < 1 || !(cfg.alpha > 0.))
+        throw RtError(RT_ERR_ARG, "bad rt_sppm_config");
+    if (plan.world != 1) throw RtError(RT_ERR_UNSUPPORTED, "rt_render_sppm renders the whole frame on one GPU");
+    hipStream_t stream = (hipStream_t)stream_;
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    const DevInfo& di = dev_info(dev);
+    FlatView view = s.flat.view;
+    view.base = device_blob(s, dev);
+    double cam_abs = std::fmax(std::fmax(std::fabs(cam.origin[0]), std::fabs(cam.origin[1])), std::fabs(cam.origin[2])) + std::fabs(cam.lens_radius);
+    const bool accel = view.accel_ok && cam_abs <= view.origin_limit2 && std::isfinite(cam_abs) && (size_t)view.stack2 * 256 * 4 <= di.lds_max;
+    const size_t smem = accel ? (size_t)view.stack2 * 256 * sizeof(uint32_t) : 0;
+
+    // AllLights::new (light.rs:202-217) + the fixed-point shift of the flux accumulators
+    const int nl = (int)s.lights.size();
+    std::vector<double> h_flux(3 * nl), h_scale(nl), h_cum(nl), lp(nl);
+    double tot = 0., maxp = 0.;
+    for (int i = 0; i < nl; i++) {
+        const ObjectRec& o = s.objects[s.lights[i]];
+        for (int c = 0; c < 3; c++) h_flux[3 * i + c] = o.light_flux[c];
+        h_scale[i] = o.light_scale;
+        double px = o.light_flux[0] * o.light_scale, py = o.light_flux[1] * o.light_scale, pz = o.light_flux[2] * o.light_scale;
+        lp[i] = std::sqrt(px * px + py * py + pz * pz);
+        tot = tot + lp[i];
+        maxp = std::fmax(maxp, std::fmax(std::fabs(px), std::fmax(std::fabs(py), std::fabs(pz))));
+    }
+    double total = 0.;
+    for (int i = 0; i < nl; i++) {
+        total = total + lp[i] / tot;
+        h_cum[i] = total;
+    }
+    int S = 40;
+    if (maxp > 0. && std::isfinite(maxp)) {
+        int e;
+        std::frexp(maxp, &e);
+        S = 40 - e;
+        S = S < 0 ? 0 : (S > 60 ? 60 : S);
+    }
+    DevBuf d_flux, d_scale, d_cum, d_cam, d_err, d_gp, d_stats, d_est;
+    d_flux.alloc(h_flux.size() * 8); d_scale.alloc(nl * 8); d_cum.alloc(nl * 8);
+    HIP_CHECK(hipMemcpy(d_flux.p, h_flux.data(), h_flux.size() * 8, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(d_scale.p, h_scale.data(), nl * 8, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(d_cum.p, h_cum.data(), nl * 8, hipMemcpyHostToDevice));
+    LightK lk{nl, total, (const double*)d_cum.p, (const double*)d_flux.p, (const double*)d_scale.p};
+    CamK ck = to_camk(cam);
+    d_cam.alloc(sizeof(CamK));
+    HIP_CHECK(hipMemcpy(d_cam.p, &ck, sizeof(CamK), hipMemcpyHostToDevice));
+    d_err.alloc(4);
+    HIP_CHECK(hipMemset(d_err.p, 0, 4));
+    const size_t npix = (size_t)plan.width * plan.height;
+    d_gp.alloc(npix * 7 * 8);
+    d_stats.alloc(npix * 10 * 8);
+    d_est.alloc(npix * 6 * 8);
+    HIP_CHECK(hipMemset(d_stats.p, 0, npix * 10 * 8));
+
+    PhotonStore pg, pc;
+    unsigned int cap_g = (unsigned int)std::min<uint64_t>((uint64_t)cfg.photons_per_iter * 8 + 1024, 0x7FFFFFFFu);
+    unsigned int cap_c = (unsigned int)std::min<uint64_t>((uint64_t)cfg.photons_per_iter * 2 + 1024, 0x7FFFFFFFu);
+    pg.alloc(cap_g);
+    pc.alloc(cap_c);
+    Grid gg, gc;
+    SppmK sk;
+    sk.width = plan.width; sk.height = plan.height; sk.photons_per_iter = cfg.photons_per_iter;
+    sk.k_global = cfg.k_global; sk.k_caustic = cfg.k_caustic; sk.max_bounces = cfg.max_bounces; sk.alpha = cfg.alpha;
+    sk.seed = plan.seed; sk.S = S; sk.iteration = 0;
+    const int pblocks = std::min<int64_t>(((int64_t)cfg.photons_per_iter + 255) / 256, (int64_t)di.cus * 8);
+    const int eblocks = (int)std::min<size_t>((npix + 255) / 256, (size_t)di.cus * 8);
+    uint64_t tg = 0, tc = 0;
+    auto t0 = std::chrono::steady_clock::now();
+    for (int it = 0; it < cfg.iterations; it++) {
+        sk.iteration = it;
+        unsigned int ng = 0, nc = 0;
+        for (;;) {  // photon pass; repeated with larger buffers if one overflowed (the pass is deterministic)
+            HIP_CHECK(hipMemsetAsync(pg.count.p, 0, 4, stream));
+            HIP_CHECK(hipMemsetAsync(pc.count.p, 0, 4, stream));
+            if (accel) hipLaunchKernelGGL(photon_kernel<true>, dim3(pblocks), dim3(256), smem, stream, view, sk, lk, pg.b, pc.b, (int*)d_err.p);
+            else hipLaunchKernelGGL(photon_kernel<false>, dim3(pblocks), dim3(256), 0, stream, view, sk, lk, pg.b, pc.b, (int*)d_err.p);
+            HIP_CHECK(hipGetLastError());
+            int h_err = 0;
+            HIP_CHECK(hipMemcpyAsync(&ng, pg.count.p, 4, hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipMemcpyAsync(&nc, pc.count.p, 4, hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipMemcpyAsync(&h_err, d_err.p, 4, hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipStreamSynchronize(stream));
+            if (h_err & 1) throw RtError(RT_ERR_UNIT_ZERO, "unitizing zero vector (device, photon pass)");
+            if (!(h_err & 2)) break;
+            HIP_CHECK(hipMemset(d_err.p, 0, 4));
+            if (ng > pg.b.cap) {
+                if (pg.b.cap >= 0x40000000u) throw RtError(RT_ERR_UNSUPPORTED, "photon map too large");
+                pg.alloc(std::max(ng + 1024u, pg.b.cap * 2u));
+            }
+            if (nc > pc.b.cap) {
+                if (pc.b.cap >= 0x40000000u) throw RtError(RT_ERR_UNSUPPORTED, "photon map too large");
+                pc.alloc(std::max(nc + 1024u, pc.b.cap * 2u));
+            }
+        }
+        tg += ng;
+        tc += nc;
+        build_grid(gg, pg.b, ng, stream);
+        build_grid(gc, pc.b, nc, stream);
+        if (accel) hipLaunchKernelGGL(eye_kernel<true>, dim3(eblocks), dim3(256), smem, stream, view, (const CamK*)d_cam.p, sk, (double*)d_gp.p, (int*)d_err.p);
+        else hipLaunchKernelGGL(eye_kernel<false>, dim3(eblocks), dim3(256), 0, stream, view, (const CamK*)d_cam.p, sk, (double*)d_gp.p, (int*)d_err.p);
+        hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, stream, sk, (const double*)d_gp.p, gg.k, pg.b, gc.k, pc.b,
+                           (double*)d_stats.p, (int*)d_err.p);
+        HIP_CHECK(hipGetLastError());
+    }
+    hipLaunchKernelGGL(estimate_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, stream, (const double*)d_stats.p, npix,
+                       (double)cfg.iterations * (double)cfg.photons_per_iter, (double*)d_est.p);
+    int h_err = 0;
+    HIP_CHECK(hipMemcpyAsync(&h_err, d_err.p, 4, hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    if (h_err & 1) throw RtError(RT_ERR_UNIT_ZERO, "unitizing zero vector (device, SPPM pre-pass)");
+    const double prepass_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (stats_host) HIP_CHECK(hipMemcpy(stats_host, d_stats.p, npix * 10 * 8, hipMemcpyDeviceToHost));
+    if (totals2) {
+        totals2[0] = tg;
+        totals2[1] = tc;
+    }
+    if (plan.spp > 0 && d_tiles) {
+        plan.integrator = 2;
+        plan.sppm_est = (const double*)d_est.p;
+        render_tiles(s, cam, plan, d_tiles, stream_, st);
+    }
+    if (st) st->reserved[0] = (uint64_t)(prepass_s * 1e6);  // SPPM pre-pass time, microseconds
 }
 
 void assemble_frame(const RenderPlan& plan, const double* d_gathered, int64_t stride, double* d_frame, void* stream_) {

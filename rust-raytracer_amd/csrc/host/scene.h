@@ -55,6 +55,9 @@ struct ObjectRec {
     double M[16], Minv[16];                     // transform (row-major)
     bool has_box = false;
     Box box;
+    // XZRectLight / SphereDiffuseLight fields (light.rs:67-72,128-132): photon power = flux * scale (SPPM only)
+    double light_flux[3] = {1., 1., 1.};
+    double light_scale = 1.;
 };
 
 struct FlatScene {

@@ -267,9 +267,9 @@ inline int Transform::emit(Emitter& e) const {
     return check(rt_object_transform(e.s, rotate_in_degree.data(), scale.data(), translate.data(), e.once(obj.get())));
 }
 inline int XZRectLight::emit(Emitter& e) const {
-    return check(rt_object_xz_rect_light(e.s, xz0.first, xz0.second, xz1.first, xz1.second, y, flux.data()));
+    return check(rt_object_xz_rect_light(e.s, xz0.first, xz0.second, xz1.first, xz1.second, y, flux.data(), scale));
 }
-inline int SphereDiffuseLight::emit(Emitter& e) const { return check(rt_object_sphere_light(e.s, center.data(), radius, flux.data())); }
+inline int SphereDiffuseLight::emit(Emitter& e) const { return check(rt_object_sphere_light(e.s, center.data(), radius, flux.data(), scale)); }
 
 // image::RgbImage stand-in (camera.rs:88,114)
 struct RgbImage {

@@ -50,6 +50,11 @@ class rt_stats(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
 
 
+class rt_sppm_config(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("photons_per_iter", C.c_int32), ("k_global", C.c_int32), ("k_caustic", C.c_int32),
+                ("max_bounces", C.c_int32), ("reserved", C.c_int32), ("alpha", C.c_double)]
+
+
 class rt_scene_info(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("n_nodes", "n_boxes", "n_spheres", "n_rects", "n_tris", "n_xforms", "n_materials",
                                          "n_textures", "n_verts", "max_depth", "committed", "reserved")] + [("bytes", C.c_uint64)] + \
@@ -83,8 +88,8 @@ _SIGS = [
     ("rt_object_rect_xz", C.c_int, [C.c_void_p] + [C.c_double] * 5 + [C.c_int]),
     ("rt_object_rect_yz", C.c_int, [C.c_void_p] + [C.c_double] * 5 + [C.c_int]),
     ("rt_object_cube", C.c_int, [C.c_void_p, _d3, _d3, C.c_int]),
-    ("rt_object_sphere_light", C.c_int, [C.c_void_p, _d3, C.c_double, _d3]),
-    ("rt_object_xz_rect_light", C.c_int, [C.c_void_p] + [C.c_double] * 5 + [_d3]),
+    ("rt_object_sphere_light", C.c_int, [C.c_void_p, _d3, C.c_double, _d3, C.c_double]),
+    ("rt_object_xz_rect_light", C.c_int, [C.c_void_p] + [C.c_double] * 5 + [_d3, C.c_double]),
     ("rt_object_mesh", C.c_int, [C.c_void_p, C.c_int, _dp, _dp, C.c_int, C.POINTER(C.c_uint32), C.c_int, C.c_int, C.c_uint64]),
     ("rt_object_mesh_obj", C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_uint64]),
     ("rt_object_transform", C.c_int, [C.c_void_p, _d3, _d3, _d3, C.c_int]),
@@ -100,6 +105,9 @@ _SIGS = [
     ("rt_scene_commit", C.c_int, [C.c_void_p]),
     ("rt_scene_info_get", C.c_int, [C.c_void_p, C.POINTER(rt_scene_info)]),
     ("rt_render", C.c_int, [C.c_void_p, C.POINTER(rt_camera), C.POINTER(rt_params), _dp, C.POINTER(rt_stats)]),
+    ("rt_default_sppm_config", None, [C.POINTER(rt_sppm_config)]),
+    ("rt_render_sppm", C.c_int, [C.c_void_p, C.POINTER(rt_camera), C.POINTER(rt_params), C.POINTER(rt_sppm_config), _dp, _dp,
+                                 C.POINTER(C.c_uint64), C.POINTER(rt_stats)]),
     ("rt_render_tiles_device", C.c_int, [C.c_void_p, C.POINTER(rt_camera), C.POINTER(rt_params), C.c_void_p, C.c_void_p,
                                          C.POINTER(rt_stats)]),
     ("rt_tiles_total", C.c_int64, [C.POINTER(rt_params)]),
@@ -263,11 +271,11 @@ class World:
         return _chk(self.L.rt_object_cube(self.h, _arr3(box_min), _arr3(box_max), material))
 
     def SphereDiffuseLight(self, center, radius, flux, scale=1.0):
-        return _chk(self.L.rt_object_sphere_light(self.h, _arr3(center), float(radius), _arr3(flux)))
+        return _chk(self.L.rt_object_sphere_light(self.h, _arr3(center), float(radius), _arr3(flux), float(scale)))
 
     def XZRectLight(self, xz0, xz1, y, flux, scale=1.0):
         return _chk(self.L.rt_object_xz_rect_light(self.h, float(xz0[0]), float(xz0[1]), float(xz1[0]), float(xz1[1]), float(y),
-                                                   _arr3(flux)))
+                                                   _arr3(flux), float(scale)))
 
     def Mesh(self, positions, normals, indices, material, synthesize_normals=False, bvh_seed=1):
         p = np.ascontiguousarray(positions, dtype=np.float64).reshape(-1, 3)
@@ -338,6 +346,25 @@ class World:
         st = rt_stats()
         _chk(self.L.rt_render(self.h, C.byref(camera.c), C.byref(p), out.ctypes.data_as(_dp), C.byref(st)))
         return out, st.as_dict()
+
+    def render_sppm(self, camera, width=800, height=800, spp=256, iterations=50, photons_per_iter=500000, alpha=0.7, k_global=100,
+                    k_caustic=50, max_bounces=4096, max_depth=50, t_min=1e-3, seed=1, kernel=0, device=-1):
+        """rt_render_sppm = SPPMIntegrator::new + capture_image (main.rs:52-54).
+        Returns (radiance [H,W,3], per-pixel stats [H,W,10], (photons in the global maps, in the caustic maps), stats dict)."""
+        p = default_params(width=width, height=height, spp=spp, max_depth=max_depth, t_min=t_min, seed=seed, kernel=kernel, device=device)
+        cfg = rt_sppm_config()
+        self.L.rt_default_sppm_config(C.byref(cfg))
+        cfg.iterations, cfg.photons_per_iter, cfg.k_global, cfg.k_caustic = iterations, photons_per_iter, k_global, k_caustic
+        cfg.max_bounces, cfg.alpha = max_bounces, alpha
+        out = np.zeros((height, width, 3), dtype=np.float64)
+        stats = np.zeros((height, width, 10), dtype=np.float64)
+        tot = (C.c_uint64 * 2)()
+        st = rt_stats()
+        _chk(self.L.rt_render_sppm(self.h, C.byref(camera.c), C.byref(p), C.byref(cfg), out.ctypes.data_as(_dp), stats.ctypes.data_as(_dp), tot,
+                                   C.byref(st)))
+        d = st.as_dict()
+        d["prepass_seconds"] = st.reserved[0] * 1e-6
+        return out, stats, (int(tot[0]), int(tot[1])), d
 
     def render_tiles_device(self, camera, params, d_tiles_ptr, stream_ptr=None):
         """rt_render_tiles_device: d_tiles_ptr is a raw device pointer (e.g. torch tensor .data_ptr())."""

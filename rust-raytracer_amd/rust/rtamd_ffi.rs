@@ -81,8 +81,8 @@ extern "C" {
     pub fn rt_object_rect_xz(s: *mut rt_scene, x0: c_double, z0: c_double, x1: c_double, z1: c_double, y: c_double, m: c_int) -> c_int;
     pub fn rt_object_rect_yz(s: *mut rt_scene, y0: c_double, z0: c_double, y1: c_double, z1: c_double, x: c_double, m: c_int) -> c_int;
     pub fn rt_object_cube(s: *mut rt_scene, mn: *const c_double, mx: *const c_double, m: c_int) -> c_int;
-    pub fn rt_object_xz_rect_light(s: *mut rt_scene, x0: c_double, z0: c_double, x1: c_double, z1: c_double, y: c_double, flux: *const c_double) -> c_int;
-    pub fn rt_object_sphere_light(s: *mut rt_scene, c: *const c_double, r: c_double, flux: *const c_double) -> c_int;
+    pub fn rt_object_xz_rect_light(s: *mut rt_scene, x0: c_double, z0: c_double, x1: c_double, z1: c_double, y: c_double, flux: *const c_double, scale: c_double) -> c_int;
+    pub fn rt_object_sphere_light(s: *mut rt_scene, c: *const c_double, r: c_double, flux: *const c_double, scale: c_double) -> c_int;
     pub fn rt_object_mesh(s: *mut rt_scene, n_vert: c_int, pos: *const c_double, nrm: *const c_double, n_tri: c_int, idx: *const u32,
                           m: c_int, synth_normals: c_int, bvh_seed: u64) -> c_int;
     pub fn rt_object_mesh_obj(s: *mut rt_scene, path: *const c_char, m: c_int, synth_normals: c_int, bvh_seed: u64) -> c_int;
