@@ -303,6 +303,8 @@ struct Config {
     double t_min = 0.001;           // photon_mapper.rs:335
     uint64_t seed = 1;
     int integrator = 0;             // 0 BSDF sampling (the reference's structure); 1 light/cosine mixture pdf
+    // SPPMIntegrator::new's constants (photon_mapper.rs:17-19,148-149); sppm_iterations == 0: no SPPM pre-pass
+    int sppm_iterations = 0, sppm_photons_per_iter = 500000;
 };
 
 // world.rs:8-30.  World::new(hitable_list, cam, lights): root = BVHNode::new(hitable_list).
@@ -340,7 +342,15 @@ class World {
         p.width = cfg.width; p.height = cfg.height; p.spp = cfg.sample_per_pixel; p.max_depth = cfg.max_depth;
         p.t_min = cfg.t_min; p.seed = cfg.seed; p.integrator = cfg.integrator;
         std::vector<double> rad((size_t)cfg.width * cfg.height * 3);
-        check(rt_render(s_, &cam.c, &p, rad.data(), stats));
+        if (cfg.sppm_iterations > 0) {  // main.rs:52-54: SPPMIntegrator::new(world) then capture_image(integrator)
+            rt_sppm_config sc;
+            rt_default_sppm_config(&sc);
+            sc.iterations = cfg.sppm_iterations;
+            sc.photons_per_iter = cfg.sppm_photons_per_iter;
+            check(rt_render_sppm(s_, &cam.c, &p, &sc, rad.data(), nullptr, nullptr, stats));
+        } else {
+            check(rt_render(s_, &cam.c, &p, rad.data(), stats));
+        }
         RgbImage img;
         img.width = cfg.width;
         img.height = cfg.height;

@@ -63,6 +63,18 @@ pub struct rt_stats {
     pub reserved: [u64; 4],
 }
 
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct rt_sppm_config {
+    pub iterations: i32,
+    pub photons_per_iter: i32,
+    pub k_global: i32,
+    pub k_caustic: i32,
+    pub max_bounces: i32,
+    pub reserved: i32,
+    pub alpha: c_double,
+}
+
 #[link(name = "rtamd")]
 extern "C" {
     pub fn rt_last_error() -> *const c_char;
@@ -97,6 +109,9 @@ extern "C" {
     pub fn rt_render(s: *const rt_scene, cam: *const rt_camera, p: *const rt_params, out_rgb: *mut c_double, stats: *mut rt_stats) -> c_int;
     pub fn rt_render_tiles_device(s: *const rt_scene, cam: *const rt_camera, p: *const rt_params, d_tiles: *mut c_double,
                                   hip_stream: *mut c_void, stats: *mut rt_stats) -> c_int;
+    pub fn rt_default_sppm_config(c: *mut rt_sppm_config);
+    pub fn rt_render_sppm(s: *const rt_scene, cam: *const rt_camera, p: *const rt_params, cfg: *const rt_sppm_config, out_rgb: *mut c_double,
+                          stats_out: *mut c_double, photons_stored: *mut u64, stats: *mut rt_stats) -> c_int;
     pub fn rt_tonemap_u8(rgb: *const c_double, n: usize, out: *mut u8) -> c_int;
     pub fn rt_write_png(path: *const c_char, w: c_int, h: c_int, rgb: *const u8) -> c_int;
 }

@@ -42,3 +42,16 @@ def test_cpp_main_renders_the_oracles_image(tmp_path):
     assert r.returncode == 0 and "Msamples/s" in r.stdout, r.stdout + r.stderr
     gold = np.load(os.path.join(ROOT, "tests", "golden", "cornell_48x48_8spp_seed1.npy"))
     assert np.array_equal(np.asarray(Image.open(out)), oracle.tonemap_u8(gold))
+
+
+@pytest.mark.gpu
+def test_cpp_main_is_the_reference_binary_with_sppm(tmp_path):
+    """main.rs:49-72 end to end through the C++ host: cornell_box_scene -> SPPMIntegrator::new -> capture_image -> save."""
+    import oracle
+    from PIL import Image
+    out = str(tmp_path / "test.png")
+    r = run("--cube", scene_path("cube.obj"), "-w", "24", "-h", "24", "--spp", "3", "--seed", "1", "--sppm", "3", "6000", "-o", out)
+    assert r.returncode == 0 and "SPPM:" in r.stdout, r.stdout + r.stderr
+    exp, _, _ = oracle.cornell_box_scene(scene_path("cube.obj"), 1.0, seed=1).render_sppm(24, 24, 3, iterations=3, photons_per_iter=6000,
+                                                                                          k_global=100, k_caustic=50, seed=1)
+    assert np.array_equal(np.asarray(Image.open(out)), oracle.tonemap_u8(exp))
