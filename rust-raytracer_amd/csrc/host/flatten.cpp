@@ -40,6 +40,7 @@ struct Builder {
     };
     std::vector<InstCtx> actx{1};
     std::vector<size_t> ctx_stack{0};
+    std::map<int, size_t> ctx_of_xform;  // Transform object id -> its context
     bool accel_ok = true;
 
     void accel_item(int obj_id, const ObjectRec& o, uint32_t kp, uint32_t node_index, const Box* tight = nullptr) {
@@ -147,12 +148,18 @@ struct Builder {
                 }
                 uint32_t n = node(NK_XFORM_BEGIN, it->second);
                 // accel: the Transform is one item of the enclosing space; its subtree gets its own object-space BVH
-                uint32_t inst_index = (uint32_t)(actx.size() - 1);
+                // (a Transform emitted twice -- BVHNode::new's 1-object leaf, Q14 -- re-enters its own context, so its
+                // items take the later visit's indices exactly as a re-emitted primitive does)
+                auto ci = ctx_of_xform.find(id);
+                if (ci == ctx_of_xform.end()) {
+                    actx.emplace_back();
+                    actx.back().xform = it->second;
+                    actx.back().Minv = o.Minv;
+                    ci = ctx_of_xform.emplace(id, actx.size() - 1).first;
+                }
+                uint32_t inst_index = (uint32_t)(ci->second - 1);
                 accel_item(id, o, NK_INSTANCE | (inst_index << NK_BITS), n);
-                actx.emplace_back();
-                actx.back().xform = it->second;
-                actx.back().Minv = o.Minv;
-                ctx_stack.push_back(actx.size() - 1);
+                ctx_stack.push_back(ci->second);
                 xf_depth++;
                 emit(o.children[0]);
                 xf_depth--;
