@@ -2,6 +2,7 @@
 // Every function converts C++ exceptions into rt_status codes; nothing unwinds
 // across the boundary.
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -361,6 +362,7 @@ static RenderPlan make_plan(const rt_params* p) {
     int64_t subs = std::max<int64_t>(1, want_units / std::max<int64_t>(1, pl.tiles_owned));
     int sub = (int)((chunk + subs - 1) / subs);
     pl.sub_spp = std::max(std::min(chunk, 4), std::min(sub, 16));
+    if (const char* e = getenv("RTAMD_SUB_SPP")) pl.sub_spp = std::max(1, std::min(chunk, atoi(e)));  // tuning knob (A/B runs)
     return pl;
 }
 

@@ -89,6 +89,8 @@ struct FlatView {  // by-value kernel argument
     uint32_t stack2;          // stack entries a lane can need
     uint32_t off_tripre;      // per triangle {pa, pb-pa, pc-pa, pad}: 10 f64 (hot part, after tris)
     uint32_t off_lights, n_lights;  // cold part: per light {NK_SPHERE | NK_RECT_XZ, payload index}
+    uint32_t off_tripre2;     // accel: triangle records {pa, e0, e1, pad} in ITEM order (leaf-contiguous)
+    uint32_t n_nodes2;        // Node2 count; the array is sorted by depth, so a prefix of it = the top of every BVH
     double origin_limit2;     // accel boxes are padded for ray origins with max-abs coordinate <= this (camera checked per render)
 };
 

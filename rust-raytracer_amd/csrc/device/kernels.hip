@@ -118,6 +118,9 @@ struct Acc {  // typed views into the blob (LDS or global; the address space is 
     const int* rect_mat;
     const uint4* tris;       // a,b,c,mat
     const double2* tripre;   // 5 x double2 per triangle: pa, e0 = pb-pa, e1 = pc-pa (mesh.rs:69, hoisted to commit time)
+    const double2* tripre2;  // the same records in accel ITEM order (a leaf's triangles are contiguous)
+    const float4* n2_top;    // LDS copy of the first n2_top_count Node2 (the shallowest levels) when the scene itself is not in LDS
+    uint32_t n2_top_count;
     const double* xforms;    // 32 per transform: M^-1 then M, row-major
     const MatDev* mats;
     const TexDev* texs;
@@ -142,6 +145,9 @@ DEV Acc make_acc(P hot, const char* gbase, const FlatView& v) {  // hot: LDS cop
     a.rects = (const double2*)(hot + v.off_rects);
     a.tris = (const uint4*)(hot + v.off_tris);
     a.tripre = (const double2*)(hot + v.off_tripre);
+    a.tripre2 = (const double2*)(hot + v.off_tripre2);
+    a.n2_top = nullptr;
+    a.n2_top_count = 0;
     a.xforms = (const double*)(hot + v.off_xforms);
     a.vpos = (const double*)(gbase + v.off_vpos);
     a.sphere_mat = (const int*)(gbase + v.off_sphere_mat);
@@ -174,6 +180,7 @@ struct RenderK {
     int chunk_spp;  // sample-buffer stride
     int restart_th; // kernel 3: lanes that must have finished a segment before the wave shades
     const double* sppm_est;  // INTEG 2: per pixel {caustic estimate[3], global estimate[3]}, index y*width + x
+    int n2_top;              // kernel 2 with the scene in L2/HBM: number of (depth-sorted) Node2 cached in LDS
 };
 
 // ------------------------------------------------------ intersection ------
@@ -236,8 +243,7 @@ DEV bool rect_hit(const double2* r, int axis, D3 o, D3 d, double t_min, double t
 }
 DEV D3 ld3(const double* p, uint32_t i) { return mk(p[3 * i], p[3 * i + 1], p[3 * i + 2]); }
 // Triangle::hit, mesh.rs:57-102 ; returns t and the barycentrics b1,b2
-DEV bool tri_hit(const Acc& A, uint32_t tri, D3 o, D3 dir, double t_min, double t_max, double& t_out, double& b1o, double& b2o) {
-    const double2* q = A.tripre + 5 * tri;
+DEV bool tri_hit(const double2* q, D3 o, D3 dir, double t_min, double t_max, double& t_out, double& b1o, double& b2o) {
     double2 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4];
     D3 pa = mk(q0.x, q0.y, q1.x), e0 = mk(q1.y, q2.x, q2.y), e1 = mk(q3.x, q3.y, q4.x);
     D3 s0 = cross(dir, e1);
@@ -306,7 +312,7 @@ DEV Hit traverse(const Acc& A, D3 wo, D3 wd, double t_min, double t_max) {
                 }
             } else if (kind == NK_TRI) {
                 double t, b1, b2;
-                if (tri_hit(A, pl, o, d, t_min, h.t, t, b1, b2)) {
+                if (tri_hit(A.tripre + 5 * pl, o, d, t_min, h.t, t, b1, b2)) {
                     h.t = t;
                     h.node = (int)n;
                     h.xf = cur_xf;
@@ -400,8 +406,14 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
     uint32_t cur = A.root2;
     for (;;) {
         while ((cur >> REF_TAG_SHIFT) == 0u) {  // inner node: test both children
-            const float4* p = A.n2 + 4 * cur;
-            float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];  // (lox0,lox1,loy0,loy1) (loz0,loz1,hix0,hix1) (hiy0,hiy1,hiz0,hiz1) (c0,c1,-,-)
+            float4 q0, q1, q2, q3;  // (lox0,lox1,loy0,loy1) (loz0,loz1,hix0,hix1) (hiy0,hiy1,hiz0,hiz1) (c0,c1,-,-)
+            if (cur < A.n2_top_count) {  // the shallowest levels are cached in LDS when the scene lives in L2/HBM
+                const float4* p = A.n2_top + 4 * cur;
+                q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
+            } else {
+                const float4* p = A.n2 + 4 * cur;
+                q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
+            }
             float e0, e1;
             bool h0 = box32(q0.x, q0.z, q1.x, q1.z, q2.x, q2.z, r, e0);
             bool h1 = box32(q0.y, q0.w, q1.y, q1.w, q2.y, q2.w, r, e1);
@@ -439,7 +451,7 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
                         got = rect_hit(A.rects + 3 * pl, (int)kind - (int)NK_RECT_YZ, o, d, t_min, h.t, t);
                     } else if (kind == NK_TRI) {
                         double b1, b2;
-                        got = tri_hit(A, pl, o, d, t_min, h.t, t, b1, b2);
+                        got = tri_hit(A.tripre2 + 5 * (first + i), o, d, t_min, h.t, t, b1, b2);
                     } else {  // NK_INSTANCE: descend into its object-space BVH after the remaining items
                         enter = pl;
                     }
@@ -575,7 +587,7 @@ DEV Rec materialize(const Acc& A, const Hit& h, D3 wo, D3 wd, int* err) {
         uint4 tr = A.tris[pl];
         rec.mat = (int)tr.w;
         double t, b1 = 0., b2 = 0.;
-        tri_hit(A, pl, o, d, -INFINITY, INFINITY, t, b1, b2);
+        tri_hit(A.tripre + 5 * pl, o, d, -INFINITY, INFINITY, t, b1, b2);
         double b0 = 1.0 - b1 - b2;
         D3 na = ld3(A.vnrm, tr.x), nb = ld3(A.vnrm, tr.y), nc = ld3(A.vnrm, tr.z);
         outward = unit(add(add(muls(na, b0), muls(nb, b1)), muls(nc, b2)), err);
@@ -734,7 +746,18 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
     } else {
         A = make_acc(sv.base, sv.base, sv);
     }
-    uint32_t* stk = (uint32_t*)(smem + (LDS ? (st_end - st_begin) : 0u)) + threadIdx.x;
+    // LDS map (non-LDS scene, kernel 2): [top-of-BVH Node2 cache, rk.n2_top nodes][stacks]
+    uint32_t top_bytes = 0;
+    if (!LDS && ACCEL == 2 && rk.n2_top > 0) {
+        const uint4* src = (const uint4*)(sv.base + sv.off_n2);
+        uint4* dst = (uint4*)smem;
+        for (uint32_t i = threadIdx.x; i < (uint32_t)rk.n2_top * 4u; i += blockDim.x) dst[i] = src[i];
+        __syncthreads();
+        A.n2_top = (const float4*)smem;
+        A.n2_top_count = (uint32_t)rk.n2_top;
+        top_bytes = (uint32_t)rk.n2_top * 64u;
+    }
+    uint32_t* stk = (uint32_t*)(smem + (LDS ? (st_end - st_begin) : top_bytes)) + threadIdx.x;
     const int stk_stride = (int)blockDim.x;
     const int lane = threadIdx.x & 63;
     const uint64_t lanemask_lt = (1ull << lane) - 1ull;
@@ -993,7 +1016,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_sm(FlatView sv, const CamK
                                     got = rect_hit(A.rects + 3 * pl, (int)kind - (int)NK_RECT_YZ, ro, rdir, t_min, h.t, t);
                                 } else if (kind == NK_TRI) {
                                     double b1, b2;
-                                    got = tri_hit(A, pl, ro, rdir, t_min, h.t, t, b1, b2);
+                                    got = tri_hit(A.tripre2 + 5 * (first + i), ro, rdir, t_min, h.t, t, b1, b2);
                                 } else {
                                     enter = pl;
                                 }
@@ -1367,7 +1390,14 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
     else
         fn = lds ? (general ? pt_kernel<true, true, 1, 0> : pt_kernel<true, false, 1, 0>)
                  : (general ? pt_kernel<false, true, 1, 0> : pt_kernel<false, false, 1, 0>);
-    const size_t smem = (lds ? hot_bytes : 0) + stack_bytes;
+    // scene too large for LDS: spend what is left after the stacks on the shallowest BVH levels (the Node2 array is depth-sorted)
+    int n2_top = 0;
+    if (kernel == 2 && !lds && lds_max > stack_bytes) {
+        size_t room = (lds_max - stack_bytes) / 64;
+        if (const char* e = getenv("RTAMD_N2_TOP")) room = std::min<size_t>(room, (size_t)std::max(0, atoi(e)));  // tuning knob (A/B runs)
+        n2_top = (int)std::min<size_t>(room, view.n_nodes2);
+    }
+    const size_t smem = (lds ? hot_bytes : (size_t)n2_top * 64) + stack_bytes;
     const void* fptr = (kernel == 3) ? (const void*)fn_sm : (const void*)fn;
     if (smem > 48 * 1024) HIP_CHECK(hipFuncSetAttribute(fptr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     int blocks_per_cu = 0;
@@ -1404,6 +1434,7 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
         rk.tiles_x = plan.tiles_x; rk.rank = plan.rank; rk.world = plan.world;
         rk.chunk_spp = plan.spp_chunk;
         rk.sppm_est = plan.sppm_est;
+        rk.n2_top = n2_top;
         rk.restart_th = SM_RESTART;
         if (const char* e = getenv("RTAMD_SM_RESTART")) rk.restart_th = std::max(1, atoi(e));  // tuning knob (A/B runs)
         HIP_CHECK(hipMemsetAsync(counter.p, 0, sizeof(unsigned int), stream));

@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <limits>
 
 namespace rtamd {
@@ -49,6 +50,14 @@ struct Ctx {
 
 const double C_BOX = 1.0, C_PRIM = 2.0;  // relative costs of a child-box pair test and a primitive test
 const int BINS = 16;
+int max_leaf() {  // items per leaf, 1..ACCEL_MAX_LEAF (RTAMD_MAX_LEAF: tuning knob, read at commit time)
+    static int v = [] {
+        const char* e = getenv("RTAMD_MAX_LEAF");
+        int m = e ? atoi(e) : ACCEL_MAX_LEAF;
+        return m < 1 ? 1 : (m > ACCEL_MAX_LEAF ? ACCEL_MAX_LEAF : m);
+    }();
+    return v;
+}
 
 uint32_t make_leaf(Ctx& c, int begin, int end) {
     uint32_t first = (uint32_t)(c.out.items.size() / 2);
@@ -127,7 +136,7 @@ uint32_t build(Ctx& c, int begin, int end, int depth) {
         }
     }
     int mid = -1;
-    if (best_axis >= 0 && (n > ACCEL_MAX_LEAF || has_instance || best_cost < C_PRIM * n)) {
+    if (best_axis >= 0 && (n > max_leaf() || has_instance || best_cost < C_PRIM * n)) {
         double lo = cb.mn[best_axis], ext = cb.mx[best_axis] - cb.mn[best_axis];
         auto it = std::stable_partition(c.items.begin() + begin, c.items.begin() + end, [&](const AccelItem& it2) {
             double ctr = 0.5 * (it2.box.mn[best_axis] + it2.box.mx[best_axis]);
@@ -140,7 +149,7 @@ uint32_t build(Ctx& c, int begin, int end, int depth) {
         if (mid == begin || mid == end) mid = -1;
     }
     if (mid < 0) {
-        if (n <= ACCEL_MAX_LEAF && !has_instance) return make_leaf(c, begin, end);
+        if (n <= max_leaf() && !has_instance) return make_leaf(c, begin, end);
         mid = begin + n / 2;  // identical centroids (e.g. concentric spheres): split by index
     }
     uint32_t idx = (uint32_t)c.out.nodes.size();

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <map>
 
+#include <algorithm>
 #include <cmath>
 
 #include "accel.h"
@@ -286,6 +287,60 @@ void flatten(rt_scene& s) {
         ab.ok = false;
     }
     if (ab.max_depth + 2 > ACCEL_MAX_STACK) ab.ok = false;
+    std::vector<double> tripre2;  // triangle records in ACCEL ITEM order: a leaf's 1..4 triangles are contiguous
+    if (ab.ok) {
+        // (b) relabel the Node2 array by depth (all BVHs interleaved): the first K nodes are the K shallowest, which is
+        // what the kernels cache in LDS when the whole scene does not fit
+        const size_t nn = ab.nodes.size();
+        std::vector<int> depth(nn, 0);
+        std::vector<uint32_t> stack;
+        auto walk = [&](uint32_t root) {
+            if ((root >> REF_TAG_SHIFT) != 0u) return;
+            depth[root] = 0;
+            stack.assign(1, root);
+            while (!stack.empty()) {
+                uint32_t n = stack.back();
+                stack.pop_back();
+                for (int k = 0; k < 2; k++) {
+                    uint32_t c = ab.nodes[n].child[k];
+                    if ((c >> REF_TAG_SHIFT) == 0u) {
+                        depth[c] = depth[n] + 1;
+                        stack.push_back(c);
+                    }
+                }
+            }
+        };
+        walk(root2);
+        for (size_t i = 0; i + 1 < ab.inst.size(); i += 2) walk(ab.inst[i + 1]);
+        std::vector<uint32_t> order(nn);
+        for (size_t i = 0; i < nn; i++) order[i] = (uint32_t)i;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t c) { return depth[a] < depth[c]; });
+        std::vector<uint32_t> new_of(nn);
+        for (size_t i = 0; i < nn; i++) new_of[order[i]] = (uint32_t)i;
+        auto remap = [&](uint32_t r) { return ((r >> REF_TAG_SHIFT) == 0u) ? new_of[r] : r; };
+        std::vector<Node2> sorted(nn);
+        for (size_t i = 0; i < nn; i++) {
+            Node2 nd = ab.nodes[order[i]];
+            nd.child[0] = remap(nd.child[0]);
+            nd.child[1] = remap(nd.child[1]);
+            sorted[i] = nd;
+        }
+        ab.nodes.swap(sorted);
+        root2 = remap(root2);
+        for (size_t i = 0; i + 1 < ab.inst.size(); i += 2) ab.inst[i + 1] = remap(ab.inst[i + 1]);
+        // (a) per item slot, the triangle's {pa, e0, e1} record (zeros for non-triangles)
+        const size_t n_items = ab.items.size() / 2;
+        if (!b.tripre.empty()) {
+            tripre2.assign(n_items * 10, 0.0);
+            for (size_t j = 0; j < n_items; j++) {
+                uint32_t kp = ab.items[2 * j];
+                if ((kp & NK_MASK) == NK_TRI) {
+                    const double* src = &b.tripre[(size_t)(kp >> NK_BITS) * 10];
+                    std::copy(src, src + 10, &tripre2[j * 10]);
+                }
+            }
+        }
+    }
 
     // hot part (read once per visited node): candidates for LDS residency
     v.off_meta = append(f.blob, b.meta);
@@ -308,6 +363,10 @@ void flatten(rt_scene& s) {
     v.off_inst2 = append(f.blob, ab.inst);
     f.blob.resize((f.blob.size() + 15) & ~size_t(15));
     v.stage2_end = (uint32_t)f.blob.size();
+    v.off_tripre2 = append(f.blob, tripre2);  // big meshes only matter here; staged with the rest when everything fits
+    f.blob.resize((f.blob.size() + 15) & ~size_t(15));
+    if (!tripre2.empty()) v.stage2_end = (uint32_t)f.blob.size();
+    v.n_nodes2 = (uint32_t)ab.nodes.size();
     v.accel_ok = ab.ok ? 1u : 0u;
     v.root2 = root2;
     v.stack2 = (uint32_t)(ab.max_depth + 2);
