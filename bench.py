@@ -73,16 +73,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available() or rtamd.device_count() < 1:
+        raise SystemExit("bench.py needs a HIP device: the product has no CPU fallback")
+    dev_index = int(os.environ.get("RTAMD_BENCH_DEVICE", local_rank))  # override only to rehearse N>1 on a 1-GPU box
+    torch.cuda.set_device(dev_index)  # before the process group: RCCL binds the communicator to the current device
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world_size > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world_size)
-    if not torch.cuda.is_available() or rtamd.device_count() < 1:
-        raise SystemExit("bench.py needs a HIP device: the product has no CPU fallback")
-    dev_index = int(os.environ.get("RTAMD_BENCH_DEVICE", local_rank))  # override only to rehearse N>1 on a 1-GPU box
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
 
     world, cam = rtamd.load_scene_file(SCENE)
     params = rtamd.default_params(width=args.width, height=args.height, spp=args.spp, max_depth=50, t_min=1e-3, seed=args.seed,
