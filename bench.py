@@ -57,7 +57,7 @@ def cpu_baseline(width, height, spp_cpu, seed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--width", type=int, default=1200)
     ap.add_argument("--height", type=int, default=1200)

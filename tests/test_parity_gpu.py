@@ -290,3 +290,26 @@ def test_accel_is_conservative_fuzz(scale):
         bad = np.argwhere((a != b).any(axis=1))
         assert len(bad) == 0, "trial %d: %d rays differ, first %s:\n k1 %s\n k2 %s" % (trial, len(bad), rays[bad[0, 0]], a[bad[0, 0]], b[bad[0, 0]])
         assert a[:, 0].sum() > n // 20
+
+
+@pytest.mark.parametrize("kernel", [1, 2])
+def test_large_mesh_instance_outside_lds_bit_exact(kernel):
+    """C4's shape at test size: the Cornell box with a 6,400-triangle torus instance (rtamd.shapes).  Its tables exceed
+    LDS, so this runs the global-memory variants (kernel 2: depth-sorted Node2 array with the top levels cached in LDS,
+    leaf-ordered triangle records, TLAS -> object-space BLAS) against the oracle's reference-order recursion."""
+    import oracle
+    import rtamd
+    from rtamd import shapes
+    P, N, I = shapes.torus(40, 80)
+    w = rtamd.World()
+    w.new(shapes.cornell_with_mesh(w, P, N, I), bvh_seed=1)
+    o = oracle.Scene()
+    o.World(shapes.cornell_with_mesh(o, P, N, I), 1)
+    o.Camera((278, 278, -800), (278, 278, 278), (0, 1, 0), 50, 1.0, 0.0, 10.0)
+    cam = rtamd.Camera(((278, 278, -800), (278, 278, 278)), (0, 1, 0), 50, 1.0, 0.0, 10.0)
+    info = w.info()
+    assert info["n_tris"] == 6400 and info["accel_ok"] == 1 and info["accel_instances"] == 1
+    img, st = w.render(cam, width=48, height=48, spp=4, seed=1, kernel=kernel)
+    exp, _ = o.render(48, 48, 4, seed=1)
+    _assert_same(img, exp, "cornell + torus, kernel %d" % kernel)
+    assert st["scene_in_lds"] == 0
