@@ -37,7 +37,7 @@ def lib():
     global _LIB
     if _LIB is not None:
         return _LIB
-    L = C.CDLL(build())
+    L = C.CDLL(os.environ.get("ORACLE_LIB") or build())  # ORACLE_LIB: e.g. the -fsanitize=address,undefined build
     L.orc_scene_new.restype = C.c_void_p
     L.orc_scene_free.argtypes = [C.c_void_p]
     L.orc_last_error.restype = C.c_char_p

@@ -1369,7 +1369,7 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
     const size_t stack_bytes = (kernel >= 2) ? (size_t)view.stack2 * PT_BLOCK * sizeof(uint32_t) : 0;
     const size_t hot_bytes = (kernel >= 2) ? (size_t)(view.stage2_end - view.stage2_begin) : (size_t)view.stage_bytes;
     if (stack_bytes > lds_max) throw RtError(RT_ERR_UNSUPPORTED, "accel stack does not fit LDS");
-    const bool lds = hot_bytes > 0 && hot_bytes + stack_bytes <= lds_max;
+    const bool lds = hot_bytes > 0 && hot_bytes + stack_bytes <= lds_max && !getenv("RTAMD_NO_LDS");  // RTAMD_NO_LDS: A/B knob
     pt_fn fn = nullptr;
     pt_sm_fn fn_sm = nullptr;
     const int integ = plan.integrator;
