@@ -1656,6 +1656,7 @@ void render_sppm(const rt_scene& s, const CameraDev& cam, RenderPlan plan, const
     PhotonStore pg, pc;
     unsigned int cap_g = (unsigned int)std::min<uint64_t>((uint64_t)cfg.photons_per_iter * 8 + 1024, 0x7FFFFFFFu);
     unsigned int cap_c = (unsigned int)std::min<uint64_t>((uint64_t)cfg.photons_per_iter * 2 + 1024, 0x7FFFFFFFu);
+    if (const char* e = getenv("RTAMD_SPPM_CAP")) cap_g = cap_c = (unsigned int)std::max(1, atoi(e));  // test knob: forces the grow-and-retry path
     pg.alloc(cap_g);
     pc.alloc(cap_c);
     Grid gg, gc;

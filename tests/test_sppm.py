@@ -111,3 +111,14 @@ def test_hip_sppm_errors_and_prepass_only():
     assert not img.any() and st[..., 4].max() > 0 and tot[0] > 0     # pre-pass only
     with pytest.raises(rtamd.RtError):
         w2.render(cam2, width=8, height=8, spp=1, integrator=2)      # integrator 2 only through rt_render_sppm
+
+
+@pytest.mark.gpu
+def test_hip_sppm_photon_buffer_overflow_retries_identically(monkeypatch):
+    """a photon buffer that is too small makes the (deterministic) photon pass repeat with a larger one: same result."""
+    import rtamd
+    w, cam = rtamd.select_scene(scene_path("cube.obj"), 1.0, 1)
+    a = w.render_sppm(cam, width=16, height=16, spp=2, seed=1, **CFG)
+    monkeypatch.setenv("RTAMD_SPPM_CAP", "64")
+    b = w.render_sppm(cam, width=16, height=16, spp=2, seed=1, **CFG)
+    assert a[2] == b[2] and np.array_equal(a[1], b[1]) and np.array_equal(a[0], b[0], equal_nan=True)
