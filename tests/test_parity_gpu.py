@@ -313,3 +313,42 @@ def test_large_mesh_instance_outside_lds_bit_exact(kernel):
     exp, _ = o.render(48, 48, 4, seed=1)
     _assert_same(img, exp, "cornell + torus, kernel %d" % kernel)
     assert st["scene_in_lds"] == 0
+
+
+@pytest.mark.parametrize("kernel", [1, 2])
+def test_many_spheres_outside_lds_bit_exact(kernel):
+    """30,000 spheres: the sphere-only kernels with the scene in L2/HBM instead of LDS (variants <LDS=false, GENERAL=false>)."""
+    import oracle
+    import rtamd
+    rng = np.random.default_rng(2024)
+    n = 30000
+    centers = (rng.random((n, 3)) - 0.5) * np.array([60.0, 4.0, 60.0])
+    radii = rng.uniform(0.05, 0.35, n)
+    kinds = rng.integers(0, 4, n)
+
+    def build(B):
+        mats = [B.Lambertian(B.ConstantTexture((0.6, 0.5, 0.4))), B.Metal(B.ConstantTexture((0.8, 0.8, 0.9)), 0.1),
+                B.Dielectric(1.5, B.ConstantTexture((1.0, 1.0, 1.0))), B.DiffuseLight(B.ConstantTexture((3.0, 2.5, 2.0)))]
+        return [B.Sphere(tuple(centers[i]), float(radii[i]), mats[kinds[i]]) for i in range(n)]
+
+    w = rtamd.World()
+    w.new(build(w), bvh_seed=5)
+    o = oracle.Scene()
+    o.World(build(o), 5)
+    o.Camera((0.0, 6.0, -40.0), (0.0, 0.0, 0.0), (0, 1, 0), 35.0, 1.0, 0.0, 40.0)
+    cam = rtamd.Camera(((0.0, 6.0, -40.0), (0.0, 0.0, 0.0)), (0, 1, 0), 35.0, 1.0, 0.0, 40.0)
+    img, st = w.render(cam, width=40, height=40, spp=4, seed=2, kernel=kernel)
+    exp, _ = o.render(40, 40, 4, seed=2)
+    _assert_same(img, exp, "30k spheres, kernel %d" % kernel)
+    assert st["scene_in_lds"] == 0 and img.max() > 0
+
+
+@pytest.mark.parametrize("w,h", [(1, 1), (1, 9), (9, 1), (2, 2)])
+def test_degenerate_image_sizes_match_the_oracle(w, h):
+    """W-1 / H-1 divisors (camera.rs:97-98, Q2): a 1-pixel-wide image divides by zero -> inf/NaN rays in the reference; the
+    kernels must follow without hanging and give the oracle's (black or NaN) pixels."""
+    world, cam, ref = _pair("scene_10.json")
+    exp, _ = ref.render(w, h, 3, seed=1)
+    for kernel in (1, 2):
+        img, _ = world.render(cam, width=w, height=h, spp=3, seed=1, kernel=kernel)
+        assert np.array_equal(img, exp, equal_nan=True), (kernel, img, exp)
