@@ -59,11 +59,15 @@ struct TexDev {   // material.rs:48-84
 //   instance (8 B): {xform index, root ref of its object-space BVH}
 // ---------------------------------------------------------------------------
 static const uint32_t NK_INSTANCE = 8;
+#ifndef RT_NODE2_PAD
+#define RT_NODE2_PAD 2
+#endif
 struct Node2 {
     float lo_x[2], lo_y[2], lo_z[2], hi_x[2], hi_y[2], hi_z[2];  // [child]
     uint32_t child[2];
-    uint32_t pad[2];
+    uint32_t pad[RT_NODE2_PAD];
 };
+static const uint32_t NODE2_F4 = (14 + RT_NODE2_PAD) / 4;  // Node2 stride in 16-byte words
 static const uint32_t REF_TAG_SHIFT = 30;
 static const uint32_t REF_LEAF = 1u << 30;
 static const uint32_t REF_RESTORE = 2u << 30;

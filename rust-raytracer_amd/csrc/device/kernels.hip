@@ -342,45 +342,50 @@ DEV Hit traverse(const Acc& A, D3 wo, D3 wd, double t_min, double t_max) {
 
 
 // ---------------------------------------------------------------- kernel 2 traversal ----
-// Conservative f32 slab test of BOTH children of a Node2.
+// Conservative f32 slab test of one child box of a Node2: 6 fma + 6 min/max + max3/min3 + one multiply.
 //
-// Claim: if some real t in [t_min, best] puts o + t*d inside the exact f64 box B, the test passes.
-//   stored bounds:  lo <= B.min - pad,  hi >= B.max + pad  (host, rounded outward), with
-//   pad >= 2 * 2^-24 * |o|max, so with of = fl32(o) (|of - o| <= 2^-24 |o|):  lo - of <= (B.min - o) - pad/2.
-//   a = fl(lo - of), p = fl(a * inv32): three roundings (sub, inv64->f32, mul) => p = Y*inv*(1+th), |th| < 3.1 * 2^-24,
-//   where Y*inv is BELOW the true slab entry.  Widening  tn - 4*2^-24*|tn|  (resp. tf + ...) absorbs th; the
-//   widening is monotone, so it is applied once after max3/min3.  NaNs (0*inf, inf-inf) only arise when a
-//   constraint is vacuous and are dropped by max/min, which loosens the test.  t_min / best are rounded outward.
+// Claim: if some real t in [t_min, best] (t_min >= 0) puts o + t*d inside the exact f64 box B, the test passes.
+// With e = 2^-24, of = fl32(o), iv = fl32(1/d) clamped to |iv| <= 2^90, c = fl(of*iv) (per ray, make_ray32):
+//   p = fl(lo*iv - c) = (lo' - o) * iv * (1+d3),  lo' = lo - (of - o) - of*d2,  |d2|,|d3| <= e   (one fma; all operands are
+//   finite because |lo|,|of| < 2^36 (flatten.cpp refuses larger scenes) -- no inf-inf, no 0*inf, no NaN).
+//   |lo' - lo| <= 2.001 e |o|max, and the host stores lo <= B.min - pad, hi >= B.max + pad with pad = 4 e |o|max
+//   (rounded outward), so lo' <= B.min and hi' >= B.max: per axis {p, q} = {nu (1+th), phi (1+th')} where, unless iv was
+//   clamped, nu <= true slab entry, phi >= true slab exit, |th|,|th'| < 2.1 e  (iv = (1/d)(1+d1)).
+//   For t as above (nu <= t <= phi on every axis, t >= 0):
+//     tn = max3(min(p,q)) <= t (1 + 2.1 e)            (a non-positive nu gives a non-positive value)
+//     tf = min3(max(p,q)) >= t (1 - 2.1 e) >= 0,   fl(tf * W) >= t (1 - 2.1 e)(1 - e)(1 + 8 e) >= t (1 + 2.1 e),  W = 1 + 2^-21
+//   hence tn <= fl(tf*W);  tn <= best (1 + 2.1 e) <= r.best;  r.tmin <= t_min <= t <= fl(tf*W): the test passes.
+//   Only the far side is widened; r.tmin = t_min rounded down, r.best = best*(1 + 2^-21) rounded up.
+//   Clamped iv (|d_axis| < 2^-90, including d_axis = 0 where 1/d = +-inf): the axis constrains nothing for a ray that
+//   starts inside [lo', hi'] (|p|,|q| >= 2 e |o|max * 2^90, beyond any t a path can reach: directions have a
+//   component >= 1e-8, so t <= 2e8 * extent) and culls a ray that starts outside it, which is what the exact test does.
+//   A negative t_min is outside this proof: the host then renders with kernel 1 (render_tiles, accel_usable).
 struct Ray32 {
-    float ox, oy, oz, ix, iy, iz;
+    float cx, cy, cz, ix, iy, iz;  // c = fl(of * iv)
     float tmin, best;  // rounded outward
 };
 DEV float f32_down(double x) { float f = (float)x; return __builtin_fmaf(-fabsf(f), 1.1920929e-7f, f); }
 DEV float f32_up(double x) { float f = (float)x; return __builtin_fmaf(fabsf(f), 1.1920929e-7f, f); }
+DEV float ray32_best(double best) { return f32_up(best * (1.0 + 4.76837158203125e-7)); }
+DEV float inv32(double inv) {  // |iv| <= 2^90 keeps lo*iv and of*iv finite
+    float f = (float)inv;
+    const float L = 1.2379400e27f;
+    return fminf(fmaxf(f, -L), L);
+}
 DEV Ray32 make_ray32(D3 o, D3 inv, double t_min, double best) {
     Ray32 r;
-    r.ox = (float)o.x; r.oy = (float)o.y; r.oz = (float)o.z;
-    r.ix = (float)inv.x; r.iy = (float)inv.y; r.iz = (float)inv.z;
+    r.ix = inv32(inv.x); r.iy = inv32(inv.y); r.iz = inv32(inv.z);
+    r.cx = (float)o.x * r.ix; r.cy = (float)o.y * r.iy; r.cz = (float)o.z * r.iz;
     r.tmin = f32_down(t_min);
-    r.best = f32_up(best);
+    r.best = ray32_best(best);
     return r;
 }
-DEV void slab32(float lo, float hi, float o, float inv, float& tn, float& tf) {
-    float p = (lo - o) * inv, q = (hi - o) * inv;
-    bool neg = inv < 0.0f;
-    tn = neg ? q : p;
-    tf = neg ? p : q;
-}
 DEV bool box32(float lox, float loy, float loz, float hix, float hiy, float hiz, const Ray32& r, float& entry) {
-    float nx, fx, ny, fy, nz, fz;
-    slab32(lox, hix, r.ox, r.ix, nx, fx);
-    slab32(loy, hiy, r.oy, r.iy, ny, fy);
-    slab32(loz, hiz, r.oz, r.iz, nz, fz);
-    float tn = fmaxf(fmaxf(nx, ny), nz), tf = fminf(fminf(fx, fy), fz);
-    const float K = 2.3841858e-7f;  // 4 * 2^-24
-    tn = __builtin_fmaf(-fabsf(tn), K, tn);
-    tf = __builtin_fmaf(fabsf(tf), K, tf);
-    tn = fmaxf(tn, r.tmin);
+    float px = __builtin_fmaf(lox, r.ix, -r.cx), qx = __builtin_fmaf(hix, r.ix, -r.cx);
+    float py = __builtin_fmaf(loy, r.iy, -r.cy), qy = __builtin_fmaf(hiy, r.iy, -r.cy);
+    float pz = __builtin_fmaf(loz, r.iz, -r.cz), qz = __builtin_fmaf(hiz, r.iz, -r.cz);
+    float tn = fmaxf(fmaxf(fminf(px, qx), fminf(py, qy)), fmaxf(fminf(pz, qz), r.tmin));
+    float tf = fminf(fminf(fmaxf(px, qx), fmaxf(py, qy)), fmaxf(pz, qz)) * (1.0f + 4.76837158203125e-7f);
     tf = fminf(tf, r.best);
     entry = tn;
     return tn <= tf;
@@ -408,10 +413,10 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
         while ((cur >> REF_TAG_SHIFT) == 0u) {  // inner node: test both children
             float4 q0, q1, q2, q3;  // (lox0,lox1,loy0,loy1) (loz0,loz1,hix0,hix1) (hiy0,hiy1,hiz0,hiz1) (c0,c1,-,-)
             if (cur < A.n2_top_count) {  // the shallowest levels are cached in LDS when the scene lives in L2/HBM
-                const float4* p = A.n2_top + 4 * cur;
+                const float4* p = A.n2_top + NODE2_F4 * cur;
                 q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
             } else {
-                const float4* p = A.n2 + 4 * cur;
+                const float4* p = A.n2 + NODE2_F4 * cur;
                 q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
             }
             float e0, e1;
@@ -462,7 +467,7 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
                     h.node = (int)it.y;
                     h.xf = cur_xf;
                     h.kp = it.x;
-                    r.best = f32_up(t);
+                    r.best = ray32_best(t);
                 }
             }
             if (GENERAL && enter != REF_DONE) {  // Transform::hit, transform.rs:153-156
@@ -751,11 +756,11 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
     if (!LDS && ACCEL == 2 && rk.n2_top > 0) {
         const uint4* src = (const uint4*)(sv.base + sv.off_n2);
         uint4* dst = (uint4*)smem;
-        for (uint32_t i = threadIdx.x; i < (uint32_t)rk.n2_top * 4u; i += blockDim.x) dst[i] = src[i];
+        for (uint32_t i = threadIdx.x; i < (uint32_t)rk.n2_top * NODE2_F4; i += blockDim.x) dst[i] = src[i];
         __syncthreads();
         A.n2_top = (const float4*)smem;
         A.n2_top_count = (uint32_t)rk.n2_top;
-        top_bytes = (uint32_t)rk.n2_top * 64u;
+        top_bytes = (uint32_t)rk.n2_top * (uint32_t)sizeof(Node2);
     }
     uint32_t* stk = (uint32_t*)(smem + (LDS ? (st_end - st_begin) : top_bytes)) + threadIdx.x;
     const int stk_stride = (int)blockDim.x;
@@ -976,7 +981,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_sm(FlatView sv, const CamK
             for (;;) {
                 while (alive && (cur >> REF_TAG_SHIFT) == 0u) {  // inner node: both children, f32 conservative
                     SM_STAT(1, true);
-                    const float4* p = A.n2 + 4 * cur;
+                    const float4* p = A.n2 + NODE2_F4 * cur;
                     float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
                     float e0, e1;
                     bool h0 = box32(q0.x, q0.z, q1.x, q1.z, q2.x, q2.z, r, e0);
@@ -1026,7 +1031,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_sm(FlatView sv, const CamK
                                 h.node = (int)it.y;
                                 h.xf = cur_xf;
                                 h.kp = it.x;
-                                r.best = f32_up(t);
+                                r.best = ray32_best(t);
                             }
                         }
                         if (GENERAL && enter != REF_DONE) {  // Transform::hit entry, transform.rs:153-156
@@ -1359,7 +1364,7 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
     // kernel 2 (accel) is the default when an accel exists and its padding covers this camera's origin
     // (flatten.cpp: boxes are padded for ray origins up to origin_limit2); otherwise kernel 1 (reference order).
     double cam_abs = std::fmax(std::fmax(std::fabs(cam.origin[0]), std::fabs(cam.origin[1])), std::fabs(cam.origin[2])) + std::fabs(cam.lens_radius);
-    const bool accel_usable = view.accel_ok && cam_abs <= view.origin_limit2 && std::isfinite(cam_abs) &&
+    const bool accel_usable = view.accel_ok && cam_abs <= view.origin_limit2 && std::isfinite(cam_abs) && plan.t_min >= 0. &&  // box32x2's proof
                               (size_t)view.stack2 * PT_BLOCK * sizeof(uint32_t) <= lds_max;  // per-lane stacks live in LDS
     int kernel = plan.kernel;
     if (kernel == 0) kernel = accel_usable ? 2 : 1;
@@ -1393,11 +1398,11 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
     // scene too large for LDS: spend what is left after the stacks on the shallowest BVH levels (the Node2 array is depth-sorted)
     int n2_top = 0;
     if (kernel == 2 && !lds && lds_max > stack_bytes) {
-        size_t room = (lds_max - stack_bytes) / 64;
+        size_t room = (lds_max - stack_bytes) / sizeof(Node2);
         if (const char* e = getenv("RTAMD_N2_TOP")) room = std::min<size_t>(room, (size_t)std::max(0, atoi(e)));  // tuning knob (A/B runs)
         n2_top = (int)std::min<size_t>(room, view.n_nodes2);
     }
-    const size_t smem = (lds ? hot_bytes : (size_t)n2_top * 64) + stack_bytes;
+    const size_t smem = (lds ? hot_bytes : (size_t)n2_top * sizeof(Node2)) + stack_bytes;
     const void* fptr = (kernel == 3) ? (const void*)fn_sm : (const void*)fn;
     if (smem > 48 * 1024) HIP_CHECK(hipFuncSetAttribute(fptr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     int blocks_per_cu = 0;
@@ -1765,6 +1770,7 @@ void debug_hit_device(const rt_scene& s, int kernel, size_t n, const double* ray
     HIP_CHECK(hipMemset(err.p, 0, 4));
     HIP_CHECK(hipMemcpy(dr.p, rays, n * 48, hipMemcpyHostToDevice));
     if (kernel == 2 && !view.accel_ok) throw RtError(RT_ERR_UNSUPPORTED, "no accel for this scene");
+    if (kernel == 2 && !(t_min >= 0.)) throw RtError(RT_ERR_UNSUPPORTED, "kernel 2 needs t_min >= 0 (box32x2)");
     hipLaunchKernelGGL(hit_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), (kernel == 2) ? view.stack2 * 64 * sizeof(uint32_t) : 0, 0, view,
                        kernel, n, (const double*)dr.p, t_min, t_max, (double*)dout.p, (int*)err.p);
     HIP_CHECK(hipGetLastError());

@@ -257,7 +257,8 @@ void flatten(rt_scene& s) {
     if (ab.ok && !b.actx[0].items.empty()) {
         // E_w: largest |coordinate| of the world items; boxes are padded so that rounding a ray origin with
         // max-abs coordinate <= 64*E_w to f32 (relative error 2^-24) can never make the f32 slab test cull a box
-        // the exact test keeps: pad >= 2 * 2^-24 * |o|max  (derivation in csrc/device/kernels.hip, aabb2_pair)
+        // the exact test keeps: pad = 4 * 2^-24 * |o|max covers of = fl32(o) and c = fl32(of * iv)  (derivation above box32
+        // in csrc/device/kernels.hip, which also needs every coordinate below 2^36 in magnitude)
         double ew = 0.;
         for (auto& it : b.actx[0].items)
             for (int a = 0; a < 3; a++) ew = std::fmax(ew, std::fmax(std::fabs(it.box.mn[a]), std::fabs(it.box.mx[a])));
@@ -265,7 +266,8 @@ void flatten(rt_scene& s) {
             ab.ok = false;
         } else {
             origin_limit = 64. * ew;
-            const double pad_w = std::ldexp(origin_limit, -22);  // 2 * (2 * 2^-24 * |o|max): factor-2 safety margin
+            const double pad_w = std::ldexp(origin_limit, -22);  // 4 * 2^-24 * |o|max
+            if (!(origin_limit < 68719476736.)) ab.ok = false;  // 2^36
             root2 = accel_build_bvh(ab, b.actx[0].items, pad_w, 0);
             const int depth_tlas = ab.max_depth;
             ab.inst.assign(2 * (b.actx.size() - 1), 0u);
@@ -278,6 +280,7 @@ void flatten(rt_scene& s) {
                                            std::fabs(c.Minv[4 * a + 3]));
                 for (auto& it : c.items)  // hit points inside the instance also serve as origins of secondary rays (in world space only)
                     for (int a = 0; a < 3; a++) oo = std::fmax(oo, std::fmax(std::fabs(it.box.mn[a]), std::fabs(it.box.mx[a])));
+                if (!(oo < 68719476736.)) { ab.ok = false; break; }
                 uint32_t r = accel_build_bvh(ab, c.items, std::ldexp(oo, -22), depth_tlas + 1);
                 ab.inst[2 * (i - 1)] = c.xform;
                 ab.inst[2 * (i - 1) + 1] = r;
