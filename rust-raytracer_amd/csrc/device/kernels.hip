@@ -1587,14 +1587,27 @@ void build_grid(Grid& g, const PhotonBuf& pb, unsigned int n, hipStream_t stream
 }
 struct PhotonStore {
     DevBuf pos, power, norm, count;
+    DevBuf spos, spower, snorm;  // the same photons in grid order (permute_kernel)
     PhotonBuf b{};
+    PhotonSorted s{};
     void alloc(unsigned int cap) {
         pos = DevBuf(); power = DevBuf(); norm = DevBuf();
+        spos = DevBuf(); spower = DevBuf(); snorm = DevBuf();
         pos.alloc((size_t)cap * 24);
         power.alloc((size_t)cap * 24);
         norm.alloc((size_t)cap * 24);
+        spos.alloc((size_t)cap * 24);
+        spower.alloc((size_t)cap * 24);
+        snorm.alloc((size_t)cap * 24);
         if (!count.p) count.alloc(4);
         b.pos = (double*)pos.p; b.power = (double*)power.p; b.norm = (double*)norm.p; b.count = (unsigned int*)count.p; b.cap = cap;
+        s.pos = (const double*)spos.p; s.power = (const double*)spower.p; s.norm = (const double*)snorm.p;
+    }
+    void sort_into_grid(const Grid& g, unsigned int n, hipStream_t stream) {
+        if (n == 0) return;
+        hipLaunchKernelGGL(permute_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, (const unsigned int*)g.index.p, b, (double*)spos.p,
+                           (double*)spower.p, (double*)snorm.p);
+        HIP_CHECK(hipGetLastError());
     }
 };
 }  // namespace
@@ -1669,6 +1682,8 @@ void render_sppm(const rt_scene& s, const CameraDev& cam, RenderPlan plan, const
     sk.width = plan.width; sk.height = plan.height; sk.photons_per_iter = cfg.photons_per_iter;
     sk.k_global = cfg.k_global; sk.k_caustic = cfg.k_caustic; sk.max_bounces = cfg.max_bounces; sk.alpha = cfg.alpha;
     sk.seed = plan.seed; sk.S = S; sk.iteration = 0;
+    sk.knn_cand = KNN_CAND;
+    if (const char* e = getenv("RTAMD_KNN_CAND")) sk.knn_cand = std::min(KNN_CAND, std::max(0, atoi(e)));  // test knob: forces the out-of-LDS selection
     const int pblocks = std::min<int64_t>(((int64_t)cfg.photons_per_iter + 255) / 256, (int64_t)di.cus * 8);
     const int eblocks = (int)std::min<size_t>((npix + 255) / 256, (size_t)di.cus * 8);
     uint64_t tg = 0, tc = 0;
@@ -1703,10 +1718,13 @@ void render_sppm(const rt_scene& s, const CameraDev& cam, RenderPlan plan, const
         tc += nc;
         build_grid(gg, pg.b, ng, stream);
         build_grid(gc, pc.b, nc, stream);
+        pg.sort_into_grid(gg, ng, stream);
+        pc.sort_into_grid(gc, nc, stream);
         if (accel) hipLaunchKernelGGL(eye_kernel<true>, dim3(eblocks), dim3(256), smem, stream, view, (const CamK*)d_cam.p, sk, (double*)d_gp.p, (int*)d_err.p);
         else hipLaunchKernelGGL(eye_kernel<false>, dim3(eblocks), dim3(256), 0, stream, view, (const CamK*)d_cam.p, sk, (double*)d_gp.p, (int*)d_err.p);
-        hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, stream, sk, (const double*)d_gp.p, gg.k, pg.b, gc.k, pc.b,
-                           (double*)d_stats.p, (int*)d_err.p);
+        const size_t pix_per_block = GATHER_BLOCK / 64;  // one wave per pixel
+        hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((npix + pix_per_block - 1) / pix_per_block)), dim3(GATHER_BLOCK), 0, stream, sk,
+                           (const double*)d_gp.p, gg.k, pg.s, gc.k, pc.s, (double*)d_stats.p, (int*)d_err.p);
         HIP_CHECK(hipGetLastError());
     }
     hipLaunchKernelGGL(estimate_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, stream, (const double*)d_stats.p, npix,
