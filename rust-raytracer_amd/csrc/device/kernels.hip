@@ -1254,10 +1254,18 @@ static CamK to_camk(const CameraDev& c) {
 
 struct DevBuf {
     void* p = nullptr;
-    ~DevBuf() {
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { reset(); }
+    void reset() {
         if (p) (void)hipFree(p);
+        p = nullptr;
     }
-    void alloc(size_t n) { HIP_CHECK(hipMalloc(&p, n ? n : 16)); }
+    void alloc(size_t n) {
+        reset();
+        HIP_CHECK(hipMalloc(&p, n ? n : 16));
+    }
 };
 struct Events {
     std::vector<hipEvent_t> ev;
@@ -1556,17 +1564,12 @@ void build_grid(Grid& g, const PhotonBuf& pb, unsigned int n, hipStream_t stream
     g.k.inv_cell = 1. / cell;
     const size_t n_scan = cells + 1;
     if (g.cap_cells < n_scan) {
-        g.cell_start = DevBuf();
-        g.cursor = DevBuf();
-        g.block_sums = DevBuf();
         g.cell_start.alloc(n_scan * 4);
         g.cursor.alloc(n_scan * 4);
         g.block_sums.alloc(((n_scan + 1023) / 1024 + 1) * 4);
         g.cap_cells = n_scan;
     }
     if (g.cap_photons < n) {
-        g.cell_of = DevBuf();
-        g.index = DevBuf();
         g.cell_of.alloc((size_t)n * 4);
         g.index.alloc((size_t)n * 4);
         g.cap_photons = n;
@@ -1591,8 +1594,6 @@ struct PhotonStore {
     PhotonBuf b{};
     PhotonSorted s{};
     void alloc(unsigned int cap) {
-        pos = DevBuf(); power = DevBuf(); norm = DevBuf();
-        spos = DevBuf(); spower = DevBuf(); snorm = DevBuf();
         pos.alloc((size_t)cap * 24);
         power.alloc((size_t)cap * 24);
         norm.alloc((size_t)cap * 24);
@@ -1628,6 +1629,12 @@ void render_sppm(const rt_scene& s, const CameraDev& cam, RenderPlan plan, const
     double cam_abs = std::fmax(std::fmax(std::fabs(cam.origin[0]), std::fabs(cam.origin[1])), std::fabs(cam.origin[2])) + std::fabs(cam.lens_radius);
     const bool accel = view.accel_ok && cam_abs <= view.origin_limit2 && std::isfinite(cam_abs) && (size_t)view.stack2 * 256 * 4 <= di.lds_max;
     const size_t smem = accel ? (size_t)view.stack2 * 256 * sizeof(uint32_t) : 0;
+    // photon pass: stage the accel's hot tables into LDS when at least two 256-thread blocks still fit on a CU
+    const size_t hot2 = (size_t)(view.stage2_end - view.stage2_begin);
+    const size_t smem_photon = hot2 + smem;
+    const bool photon_lds = accel && hot2 > 0 && 2 * smem_photon <= di.lds_max && !getenv("RTAMD_NO_LDS");
+    if (photon_lds && smem_photon > 48 * 1024)
+        HIP_CHECK(hipFuncSetAttribute((const void*)photon_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_photon));
 
     // AllLights::new (light.rs:202-217) + the fixed-point shift of the flux accumulators
     const int nl = (int)s.lights.size();
@@ -1654,7 +1661,8 @@ void render_sppm(const rt_scene& s, const CameraDev& cam, RenderPlan plan, const
         S = 40 - e;
         S = S < 0 ? 0 : (S > 60 ? 60 : S);
     }
-    DevBuf d_flux, d_scale, d_cum, d_cam, d_err, d_gp, d_stats, d_est;
+    DevBuf d_flux, d_scale, d_cum, d_cam, d_err, d_gp, d_stats, d_est, d_cursor;
+    d_cursor.alloc(4);
     d_flux.alloc(h_flux.size() * 8); d_scale.alloc(nl * 8); d_cum.alloc(nl * 8);
     HIP_CHECK(hipMemcpy(d_flux.p, h_flux.data(), h_flux.size() * 8, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(d_scale.p, h_scale.data(), nl * 8, hipMemcpyHostToDevice));
@@ -1671,12 +1679,28 @@ void render_sppm(const rt_scene& s, const CameraDev& cam, RenderPlan plan, const
     d_est.alloc(npix * 6 * 8);
     HIP_CHECK(hipMemset(d_stats.p, 0, npix * 10 * 8));
 
-    PhotonStore pg, pc;
+    // Two streams: the photon pass of iteration i+1 (stream P) runs beside the grid build + eye pass + gather of iteration i
+    // (the caller's stream), on double-buffered photon stores.  Both are latency-bound on their own (paths of 1..max_bounces
+    // segments; one wave per pixel), so together they fill the GPU.  Results do not depend on the overlap.
+    struct StreamP {
+        hipStream_t s = nullptr;
+        ~StreamP() {
+            if (s) (void)hipStreamDestroy(s);
+        }
+    } sp;
+    HIP_CHECK(hipStreamCreateWithFlags(&sp.s, hipStreamNonBlocking));
+    Events evs;
+    PhotonStore pg[2], pc[2];
     unsigned int cap_g = (unsigned int)std::min<uint64_t>((uint64_t)cfg.photons_per_iter * 8 + 1024, 0x7FFFFFFFu);
     unsigned int cap_c = (unsigned int)std::min<uint64_t>((uint64_t)cfg.photons_per_iter * 2 + 1024, 0x7FFFFFFFu);
     if (const char* e = getenv("RTAMD_SPPM_CAP")) cap_g = cap_c = (unsigned int)std::max(1, atoi(e));  // test knob: forces the grow-and-retry path
-    pg.alloc(cap_g);
-    pc.alloc(cap_c);
+    for (int j = 0; j < 2; j++) {
+        pg[j].alloc(cap_g);
+        pc[j].alloc(cap_c);
+    }
+    DevBuf d_err_p;  // error flags of the photon pass (its own word: the retry below clears it while the other stream runs)
+    d_err_p.alloc(4);
+    HIP_CHECK(hipMemset(d_err_p.p, 0, 4));
     Grid gg, gc;
     SppmK sk;
     sk.width = plan.width; sk.height = plan.height; sk.photons_per_iter = cfg.photons_per_iter;
@@ -1684,48 +1708,73 @@ void render_sppm(const rt_scene& s, const CameraDev& cam, RenderPlan plan, const
     sk.seed = plan.seed; sk.S = S; sk.iteration = 0;
     sk.knn_cand = KNN_CAND;
     if (const char* e = getenv("RTAMD_KNN_CAND")) sk.knn_cand = std::min(KNN_CAND, std::max(0, atoi(e)));  // test knob: forces the out-of-LDS selection
-    const int pblocks = std::min<int64_t>(((int64_t)cfg.photons_per_iter + 255) / 256, (int64_t)di.cus * 8);
+    // persistent photon waves: enough 256-thread blocks to fill every CU at 4 waves per SIMD, never more waves than chunks
+    const int pblocks = (int)std::max<int64_t>(1, std::min<int64_t>(((int64_t)cfg.photons_per_iter + 4 * PHOTON_CHUNK - 1) / (4 * PHOTON_CHUNK), (int64_t)di.cus * 4));
     const int eblocks = (int)std::min<size_t>((npix + 255) / 256, (size_t)di.cus * 8);
+    auto launch_photons = [&](int it) {  // on stream P, into store it % 2
+        PhotonStore &g = pg[it & 1], &c = pc[it & 1];
+        SppmK skp = sk;
+        skp.iteration = it;
+        HIP_CHECK(hipMemsetAsync(g.count.p, 0, 4, sp.s));
+        HIP_CHECK(hipMemsetAsync(c.count.p, 0, 4, sp.s));
+        HIP_CHECK(hipMemsetAsync(d_cursor.p, 0, 4, sp.s));
+        if (accel && photon_lds)
+            hipLaunchKernelGGL((photon_kernel<true, true>), dim3(pblocks), dim3(256), smem_photon, sp.s, view, skp, lk, g.b, c.b, (unsigned int*)d_cursor.p,
+                               (int*)d_err_p.p);
+        else if (accel)
+            hipLaunchKernelGGL((photon_kernel<true, false>), dim3(pblocks), dim3(256), smem, sp.s, view, skp, lk, g.b, c.b, (unsigned int*)d_cursor.p,
+                               (int*)d_err_p.p);
+        else
+            hipLaunchKernelGGL((photon_kernel<false, false>), dim3(pblocks), dim3(256), 0, sp.s, view, skp, lk, g.b, c.b, (unsigned int*)d_cursor.p,
+                               (int*)d_err_p.p);
+        HIP_CHECK(hipGetLastError());
+    };
     uint64_t tg = 0, tc = 0;
     auto t0 = std::chrono::steady_clock::now();
+    HIP_CHECK(hipStreamSynchronize(stream));  // the caller's earlier work on `stream` (uploads) precedes stream P
+    launch_photons(0);
+    hipEvent_t gather_done[2] = {nullptr, nullptr};  // gather of the iteration that last read store j
     for (int it = 0; it < cfg.iterations; it++) {
         sk.iteration = it;
+        PhotonStore &sg = pg[it & 1], &sc = pc[it & 1];
         unsigned int ng = 0, nc = 0;
-        for (;;) {  // photon pass; repeated with larger buffers if one overflowed (the pass is deterministic)
-            HIP_CHECK(hipMemsetAsync(pg.count.p, 0, 4, stream));
-            HIP_CHECK(hipMemsetAsync(pc.count.p, 0, 4, stream));
-            if (accel) hipLaunchKernelGGL(photon_kernel<true>, dim3(pblocks), dim3(256), smem, stream, view, sk, lk, pg.b, pc.b, (int*)d_err.p);
-            else hipLaunchKernelGGL(photon_kernel<false>, dim3(pblocks), dim3(256), 0, stream, view, sk, lk, pg.b, pc.b, (int*)d_err.p);
-            HIP_CHECK(hipGetLastError());
+        for (;;) {  // wait for the photon pass; it is repeated with larger buffers if one overflowed (the pass is deterministic)
             int h_err = 0;
-            HIP_CHECK(hipMemcpyAsync(&ng, pg.count.p, 4, hipMemcpyDeviceToHost, stream));
-            HIP_CHECK(hipMemcpyAsync(&nc, pc.count.p, 4, hipMemcpyDeviceToHost, stream));
-            HIP_CHECK(hipMemcpyAsync(&h_err, d_err.p, 4, hipMemcpyDeviceToHost, stream));
-            HIP_CHECK(hipStreamSynchronize(stream));
+            HIP_CHECK(hipMemcpyAsync(&ng, sg.count.p, 4, hipMemcpyDeviceToHost, sp.s));
+            HIP_CHECK(hipMemcpyAsync(&nc, sc.count.p, 4, hipMemcpyDeviceToHost, sp.s));
+            HIP_CHECK(hipMemcpyAsync(&h_err, d_err_p.p, 4, hipMemcpyDeviceToHost, sp.s));
+            HIP_CHECK(hipStreamSynchronize(sp.s));
             if (h_err & 1) throw RtError(RT_ERR_UNIT_ZERO, "unitizing zero vector (device, photon pass)");
             if (!(h_err & 2)) break;
-            HIP_CHECK(hipMemset(d_err.p, 0, 4));
-            if (ng > pg.b.cap) {
-                if (pg.b.cap >= 0x40000000u) throw RtError(RT_ERR_UNSUPPORTED, "photon map too large");
-                pg.alloc(std::max(ng + 1024u, pg.b.cap * 2u));
+            HIP_CHECK(hipMemsetAsync(d_err_p.p, 0, 4, sp.s));
+            if (ng > sg.b.cap) {
+                if (sg.b.cap >= 0x40000000u) throw RtError(RT_ERR_UNSUPPORTED, "photon map too large");
+                sg.alloc(std::max(ng + 1024u, sg.b.cap * 2u));
             }
-            if (nc > pc.b.cap) {
-                if (pc.b.cap >= 0x40000000u) throw RtError(RT_ERR_UNSUPPORTED, "photon map too large");
-                pc.alloc(std::max(nc + 1024u, pc.b.cap * 2u));
+            if (nc > sc.b.cap) {
+                if (sc.b.cap >= 0x40000000u) throw RtError(RT_ERR_UNSUPPORTED, "photon map too large");
+                sc.alloc(std::max(nc + 1024u, sc.b.cap * 2u));
             }
+            launch_photons(it);
         }
         tg += ng;
         tc += nc;
-        build_grid(gg, pg.b, ng, stream);
-        build_grid(gc, pc.b, nc, stream);
-        pg.sort_into_grid(gg, ng, stream);
-        pc.sort_into_grid(gc, nc, stream);
+        if (it + 1 < cfg.iterations) {  // next photon pass: its store was last read by the gather of iteration it - 1
+            if (gather_done[(it + 1) & 1]) HIP_CHECK(hipStreamWaitEvent(sp.s, gather_done[(it + 1) & 1], 0));
+            launch_photons(it + 1);
+        }
+        build_grid(gg, sg.b, ng, stream);
+        build_grid(gc, sc.b, nc, stream);
+        sg.sort_into_grid(gg, ng, stream);
+        sc.sort_into_grid(gc, nc, stream);
         if (accel) hipLaunchKernelGGL(eye_kernel<true>, dim3(eblocks), dim3(256), smem, stream, view, (const CamK*)d_cam.p, sk, (double*)d_gp.p, (int*)d_err.p);
         else hipLaunchKernelGGL(eye_kernel<false>, dim3(eblocks), dim3(256), 0, stream, view, (const CamK*)d_cam.p, sk, (double*)d_gp.p, (int*)d_err.p);
         const size_t pix_per_block = GATHER_BLOCK / 64;  // one wave per pixel
         hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((npix + pix_per_block - 1) / pix_per_block)), dim3(GATHER_BLOCK), 0, stream, sk,
-                           (const double*)d_gp.p, gg.k, pg.s, gc.k, pc.s, (double*)d_stats.p, (int*)d_err.p);
+                           (const double*)d_gp.p, gg.k, sg.s, gc.k, sc.s, (double*)d_stats.p, (int*)d_err.p);
         HIP_CHECK(hipGetLastError());
+        if (!gather_done[it & 1]) gather_done[it & 1] = evs.make();
+        HIP_CHECK(hipEventRecord(gather_done[it & 1], stream));
     }
     hipLaunchKernelGGL(estimate_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, stream, (const double*)d_stats.p, npix,
                        (double)cfg.iterations * (double)cfg.photons_per_iter, (double*)d_est.p);
