@@ -403,6 +403,28 @@ int rt_render_tiles_device(const rt_scene* s, const rt_camera* cam, const rt_par
     });
 }
 
+int rt_render_sppm_tiles_device(const rt_scene* s, const rt_camera* cam, const rt_params* p, const rt_sppm_config* cfg, double* d_tiles,
+                                void* hip_stream, rt_stats* stats) {
+    return guard([&] {
+        REQUIRE(s && cam && p && cfg && d_tiles, "null argument");
+        REQUIRE(p->spp > 0, "spp must be positive");
+        if (!s->committed) throw RtError(RT_ERR_NOT_COMMITTED, "rt_scene_commit has not been called");
+        if (device_count() < 1) throw RtError(RT_ERR_NO_DEVICE, "no HIP device: librtamd has no CPU fallback");
+        auto t0 = std::chrono::steady_clock::now();
+        rt_params q = *p;
+        q.integrator = 0;
+        RenderPlan pl = make_plan(&q);
+        CameraDev cd = make_camera(*cam);
+        rt_stats st{};
+        render_sppm(*s, cd, pl, *cfg, d_tiles, nullptr, hip_stream, &st, nullptr);
+        if (stats) {
+            *stats = st;
+            stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        }
+        return (int)RT_OK;
+    });
+}
+
 int rt_assemble_frame_device(const rt_params* p, const double* d_gathered, int64_t tiles_per_rank_stride, double* d_frame,
                              void* hip_stream) {
     return guard([&] {

@@ -74,7 +74,8 @@ static const uint32_t REF_RESTORE = 2u << 30;
 static const uint32_t REF_DONE = 0xFFFFFFFFu;
 static const uint32_t REF_LEAF_COUNT_SHIFT = 26;
 static const uint32_t REF_LEAF_FIRST_MASK = (1u << 26) - 1;
-static const int ACCEL_MAX_LEAF = 4;
+static const int ACCEL_MAX_LEAF = 8;      // limit of the 3-bit count field; the builder's default is ACCEL_DEFAULT_LEAF
+static const int ACCEL_DEFAULT_LEAF = 4;
 static const int ACCEL_MAX_STACK = 64;
 
 struct FlatView {  // by-value kernel argument

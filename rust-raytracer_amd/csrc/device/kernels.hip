@@ -1619,7 +1619,6 @@ void render_sppm(const rt_scene& s, const CameraDev& cam, RenderPlan plan, const
     if (s.lights.empty()) throw RtError(RT_ERR_ARG, "SPPM needs lights (rt_scene_set_lights)");
     if (cfg.iterations < 1 || cfg.photons_per_iter < 1 || cfg.k_global < 1 || cfg.k_caustic < 1 || cfg.max_bounces < 1 || !(cfg.alpha > 0.))
         throw RtError(RT_ERR_ARG, "bad rt_sppm_config");
-    if (plan.world != 1) throw RtError(RT_ERR_UNSUPPORTED, "rt_render_sppm renders the whole frame on one GPU");
     hipStream_t stream = (hipStream_t)stream_;
     int dev = 0;
     HIP_CHECK(hipGetDevice(&dev));

@@ -48,12 +48,20 @@ struct Ctx {
     double pad;
 };
 
-const double C_BOX = 1.0, C_PRIM = 2.0;  // relative costs of a child-box pair test and a primitive test
+const double C_PRIM = 2.0;  // relative costs of a child-box pair test (c_box()) and a primitive test
+double c_box() {  // RTAMD_C_BOX: tuning knob, read at commit time
+    static double v = [] {
+        const char* e = getenv("RTAMD_C_BOX");
+        double c = e ? atof(e) : 1.0;
+        return (c > 0. && c < 1e6) ? c : 1.0;
+    }();
+    return v;
+}
 const int BINS = 16;
 int max_leaf() {  // items per leaf, 1..ACCEL_MAX_LEAF (RTAMD_MAX_LEAF: tuning knob, read at commit time)
     static int v = [] {
         const char* e = getenv("RTAMD_MAX_LEAF");
-        int m = e ? atoi(e) : ACCEL_MAX_LEAF;
+        int m = e ? atoi(e) : ACCEL_DEFAULT_LEAF;
         return m < 1 ? 1 : (m > ACCEL_MAX_LEAF ? ACCEL_MAX_LEAF : m);
     }();
     return v;
@@ -131,7 +139,7 @@ uint32_t build(Ctx& c, int begin, int end, int depth) {
             acc = merge(acc, bb[b]);
             k += cnt[b];
             if (k == 0 || right_cnt[b + 1] == 0) continue;
-            double cost = C_BOX + C_PRIM * (area(acc) * k + right_area[b + 1] * right_cnt[b + 1]) / parent_area;
+            double cost = c_box() + C_PRIM * (area(acc) * k + right_area[b + 1] * right_cnt[b + 1]) / parent_area;
             if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = b; }
         }
     }

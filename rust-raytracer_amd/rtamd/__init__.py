@@ -110,6 +110,8 @@ _SIGS = [
                                  C.POINTER(C.c_uint64), C.POINTER(rt_stats)]),
     ("rt_render_tiles_device", C.c_int, [C.c_void_p, C.POINTER(rt_camera), C.POINTER(rt_params), C.c_void_p, C.c_void_p,
                                          C.POINTER(rt_stats)]),
+    ("rt_render_sppm_tiles_device", C.c_int, [C.c_void_p, C.POINTER(rt_camera), C.POINTER(rt_params), C.POINTER(rt_sppm_config), C.c_void_p,
+                                              C.c_void_p, C.POINTER(rt_stats)]),
     ("rt_tiles_total", C.c_int64, [C.POINTER(rt_params)]),
     ("rt_tiles_owned", C.c_int64, [C.POINTER(rt_params)]),
     ("rt_assemble_frame_device", C.c_int, [C.POINTER(rt_params), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
@@ -372,6 +374,22 @@ class World:
         _chk(self.L.rt_render_tiles_device(self.h, C.byref(camera.c), C.byref(params), C.c_void_p(d_tiles_ptr),
                                            C.c_void_p(stream_ptr or 0), C.byref(st)))
         return st.as_dict()
+
+    def render_sppm_tiles_device(self, camera, params, d_tiles_ptr, stream_ptr=None, **sppm):
+        """rt_render_sppm_tiles_device: the (replicated, deterministic) SPPM pre-pass, then this rank's tiles of the final pass.
+        sppm: iterations, photons_per_iter, alpha, k_global, k_caustic, max_bounces (defaults = the reference's constants)."""
+        cfg = rt_sppm_config()
+        self.L.rt_default_sppm_config(C.byref(cfg))
+        for k, v in sppm.items():
+            if not hasattr(cfg, k):
+                raise TypeError("unknown SPPM setting %r" % k)
+            setattr(cfg, k, v)
+        st = rt_stats()
+        _chk(self.L.rt_render_sppm_tiles_device(self.h, C.byref(camera.c), C.byref(params), C.byref(cfg), C.c_void_p(d_tiles_ptr),
+                                                C.c_void_p(stream_ptr or 0), C.byref(st)))
+        d = st.as_dict()
+        d["prepass_seconds"] = st.reserved[0] * 1e-6
+        return d
 
     def debug_hit(self, rays, t_min=1e-3, t_max=float("inf"), kernel=1):
         r = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)

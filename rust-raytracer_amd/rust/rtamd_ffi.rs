@@ -112,6 +112,8 @@ extern "C" {
     pub fn rt_default_sppm_config(c: *mut rt_sppm_config);
     pub fn rt_render_sppm(s: *const rt_scene, cam: *const rt_camera, p: *const rt_params, cfg: *const rt_sppm_config, out_rgb: *mut c_double,
                           stats_out: *mut c_double, photons_stored: *mut u64, stats: *mut rt_stats) -> c_int;
+    pub fn rt_render_sppm_tiles_device(s: *const rt_scene, cam: *const rt_camera, p: *const rt_params, cfg: *const rt_sppm_config,
+                                       d_tiles: *mut c_double, hip_stream: *mut c_void, stats: *mut rt_stats) -> c_int;
     pub fn rt_tonemap_u8(rgb: *const c_double, n: usize, out: *mut u8) -> c_int;
     pub fn rt_write_png(path: *const c_char, w: c_int, h: c_int, rgb: *const u8) -> c_int;
 }

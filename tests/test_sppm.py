@@ -138,3 +138,26 @@ def test_hip_sppm_knn_selection_outside_lds_is_identical(monkeypatch):
     assert a[2] == b[2] and np.array_equal(a[1], b[1]) and np.array_equal(a[0], b[0], equal_nan=True)
     eimg, est, etot = o.render_sppm(16, 16, 1, seed=3, **CFG)
     assert etot == b[2] and np.array_equal(b[1], est)
+
+
+@pytest.mark.gpu
+def test_hip_sppm_tiles_over_ranks_stitch_to_the_single_gpu_frame():
+    """rt_render_sppm_tiles_device: every rank repeats the deterministic pre-pass and renders its own tiles; the stitched
+    frame of a 3-rank partition equals rt_render_sppm's (and therefore the oracle's) bit for bit."""
+    import torch
+    import rtamd
+    from rtamd.distributed import TileLayout, stitch_host
+    w, cam = rtamd.select_scene(scene_path("cube.obj"), 1.0, 1)
+    W, H, spp = 24, 20, 2
+    full, _, _, _ = w.render_sppm(cam, width=W, height=H, spp=spp, seed=1, **CFG)
+    world_size = 3
+    lay = TileLayout(W, H, world_size)
+    parts = []
+    for r in range(world_size):
+        p = rtamd.default_params(width=W, height=H, spp=spp, seed=1, rank=r, world=world_size)
+        buf = torch.zeros(lay.stride * 64 * 3, dtype=torch.float64, device="cuda:0")
+        info = w.render_sppm_tiles_device(cam, p, buf.data_ptr(), **CFG)
+        assert info["prepass_seconds"] > 0
+        parts.append(buf.cpu())
+    frame = stitch_host(torch.cat(parts).numpy(), lay)
+    assert np.array_equal(frame, full, equal_nan=True)
