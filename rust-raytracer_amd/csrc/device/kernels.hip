@@ -616,37 +616,40 @@ DEV Rec materialize(const Acc& A, const Hit& h, D3 wo, D3 wd, int* err) {
 }
 
 // Material::emitted + Material::scatter, material.rs:88-212.  Returns false on Absorb.
+// The material types run as divergent branches of one wave, so what they have in common is done ONCE, before the
+// branches: the texture lookup (every type reads its texture exactly once), the unit-sphere sample that Lambertian,
+// DiffuseLight and Metal all draw first, and the one normalisation each type performs (of that sample for the diffuse
+// types, of the incoming direction for Metal and Dielectric).  Per lane the operations and their order are unchanged.
 DEV bool shade(const Acc& A, const Rec& rec, D3 rdir, Rng& rng, D3& emitted, D3& att, D3& out_dir, bool& diffuse, int* err) {
     const MatDev mt = A.mats[rec.mat];
-    emitted = mk(0., 0., 0.);
-    diffuse = (mt.type == 0 || mt.type == 3);  // Interaction::Diffuse (material.rs:111,207)
-    if (mt.type == 0 || mt.type == 3) {  // Lambertian / DiffuseLight: scattered_direction, material.rs:92-98
-        D3 dir = add(rec.normal, unit(random_in_unit_sphere(rng), err));
+    const int type = mt.type;
+    const bool lamb = (type == 0 || type == 3);  // Lambertian / DiffuseLight: Interaction::Diffuse (material.rs:111,207)
+    diffuse = lamb;
+    const D3 tc = tex_color(A, mt.tex, rec);
+    const double FRAC_1_PI = 0.318309886183790671537767526745028724;
+    emitted = (type == 3) ? tc : mk(0., 0., 0.);                                         // material.rs:209-211 (no face test)
+    att = (type == 3) ? mk(1. * FRAC_1_PI, 1. * FRAC_1_PI, 1. * FRAC_1_PI) : tc;         // material.rs:201-203
+    D3 rs = mk(0., 0., 0.);
+    if (type != 2) rs = random_in_unit_sphere(rng);  // Metal draws its fuzz sample even when fuzz == 0 (Q4)
+    const D3 u = unit(lamb ? rs : rdir, err);
+    if (lamb) {  // scattered_direction, material.rs:92-98
+        D3 dir = add(rec.normal, u);
         if (near_zero(dir)) dir = rec.normal;
         out_dir = dir;
-        if (mt.type == 0) {
-            att = tex_color(A, mt.tex, rec);
-        } else {
-            const double FRAC_1_PI = 0.318309886183790671537767526745028724;
-            att = mk(1. * FRAC_1_PI, 1. * FRAC_1_PI, 1. * FRAC_1_PI);  // material.rs:201-203
-            emitted = tex_color(A, mt.tex, rec);                         // material.rs:209-211 (no face test)
-        }
         return true;
     }
-    if (mt.type == 1) {  // Metal, material.rs:126-139 ; fuzz sample drawn even when fuzz == 0 (Q4)
-        D3 reflected = reflect(unit(rdir, err), rec.normal);
-        D3 dir = add(reflected, muls(random_in_unit_sphere(rng), mt.param));
+    if (type == 1) {  // Metal, material.rs:126-139
+        D3 reflected = reflect(u, rec.normal);
+        D3 dir = add(reflected, muls(rs, mt.param));
         if (dot(dir, rec.normal) > 0.) {
             out_dir = dir;
-            att = tex_color(A, mt.tex, rec);
             return true;
         }
         return false;  // Absorb (Q15)
     }
     // Dielectric, material.rs:157-188
-    att = tex_color(A, mt.tex, rec);
     double ratio = rec.front_face ? (1.0 / mt.param) : mt.param;
-    D3 ud = unit(rdir, err);
+    const D3 ud = u;
     double cos_theta = fmin(dot(neg(ud), rec.normal), 1.0);
     double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
     bool cannot_refract = ratio * sin_theta > 1.0;
