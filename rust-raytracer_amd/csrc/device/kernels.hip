@@ -770,31 +770,42 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
     const int lane = threadIdx.x & 63;
     const uint64_t lanemask_lt = (1ull << lane) - 1ull;
 
-    for (;;) {
-        unsigned int unit = 0;
-        if (lane == 0) unit = atomicAdd(counter, 1u);
-        unit = __builtin_amdgcn_readfirstlane(unit);
-        if (unit >= (unsigned)rk.n_units) break;  // every wave reaches this: the counter only grows
-        const int lt = (int)(unit / (unsigned)rk.subs_per_tile);
-        const int sub_i = (int)(unit - (unsigned)lt * (unsigned)rk.subs_per_tile);
-        const int tile = lt * rk.world + rk.rank;
-        const int tx = tile % rk.tiles_x, ty = tile / rk.tiles_x;
-        const int s0 = rk.s_begin + sub_i * rk.sub_spp;
-        const int s1 = min(s0 + rk.sub_spp, rk.s_end);
-        const int pool = (s1 - s0) * TILE_PIX;
-        int next = 0;  // wave-uniform
+    // current work unit (wave-uniform); `pool` paths, of which `next` have been handed out.  A wave does not drain a unit
+    // before it takes the next one: as soon as the pool is empty and a lane is free the next unit is fetched, so the lanes
+    // still finishing long paths of the old unit run beside fresh paths of the new one (a finished path knows where its
+    // sample goes: out_idx is per lane).  Only the end of the launch has a tail.
+    int lt = 0, tx = 0, ty = 0, s0 = 0, pool = 0, next = 0;
+    bool more_units = true;
 
-        bool alive = false;
-        D3 o = mk(0, 0, 0), d = mk(0, 0, 1), beta = mk(1, 1, 1), L = mk(0, 0, 0);
-        int depth = 0;
-        int pix_id = 0;
-        size_t out_idx = 0;
-        Rng rng;
-        rng.s = 0;
-
+    bool alive = false;
+    D3 o = mk(0, 0, 0), d = mk(0, 0, 1), beta = mk(1, 1, 1), L = mk(0, 0, 0);
+    int depth = 0;
+    int pix_id = 0;
+    size_t out_idx = 0;
+    Rng rng;
+    rng.s = 0;
+    {
         for (;;) {
             // ---- regeneration: dead lanes pull the next (pixel, sample) of the pool ----
             uint64_t dead = __ballot(!alive);
+            if (dead != 0ull && next >= pool && more_units) {
+                unsigned int unit = 0;
+                if (lane == 0) unit = atomicAdd(counter, 1u);
+                unit = __builtin_amdgcn_readfirstlane(unit);
+                if (unit >= (unsigned)rk.n_units) {
+                    more_units = false;  // every wave gets here: the counter only grows
+                } else {
+                    lt = (int)(unit / (unsigned)rk.subs_per_tile);
+                    const int sub_i = (int)(unit - (unsigned)lt * (unsigned)rk.subs_per_tile);
+                    const int tile = lt * rk.world + rk.rank;
+                    tx = tile % rk.tiles_x;
+                    ty = tile / rk.tiles_x;
+                    s0 = rk.s_begin + sub_i * rk.sub_spp;
+                    const int s1 = min(s0 + rk.sub_spp, rk.s_end);
+                    pool = (s1 - s0) * TILE_PIX;
+                    next = 0;
+                }
+            }
             if (dead != 0ull && next < pool) {
                 int k = next + __popcll(dead & lanemask_lt);
                 next = min(next + (int)__popcll(dead), pool);
@@ -821,7 +832,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
                 }
             }
             if (__ballot(alive) == 0ull) {
-                if (next >= pool) break;
+                if (next >= pool && !more_units) break;
                 continue;
             }
             // ---- one path segment: sample_ray's loop body, photon_mapper.rs:335-362 ----
