@@ -356,12 +356,13 @@ static RenderPlan make_plan(const rt_params* p) {
     }
     if (chunk > p->spp) chunk = p->spp;
     pl.spp_chunk = chunk;
-    // one work unit = 64 pixels x sub_spp samples (a wave drains it with in-wave regeneration).  Large pools amortise
-    // the drain tail; many units balance the 4096 resident waves: aim at >= ~12 units per wave, 4 <= sub_spp <= 16.
+    // one work unit = 64 pixels x sub_spp samples (a wave works through it with in-wave regeneration and fetches the next
+    // one as soon as its pool is empty).  Many units balance the 4096 resident waves at the end of a launch: aim at
+    // >= ~12 units per wave, 4 <= sub_spp <= 8 (measured on the headline workload: 4: 2144, 8: 2166, 16: 2104 Msamples/s).
     int64_t want_units = 12 * 4096;
     int64_t subs = std::max<int64_t>(1, want_units / std::max<int64_t>(1, pl.tiles_owned));
     int sub = (int)((chunk + subs - 1) / subs);
-    pl.sub_spp = std::max(std::min(chunk, 4), std::min(sub, 16));
+    pl.sub_spp = std::max(std::min(chunk, 4), std::min(sub, 8));
     if (const char* e = getenv("RTAMD_SUB_SPP")) pl.sub_spp = std::max(1, std::min(chunk, atoi(e)));  // tuning knob (A/B runs)
     return pl;
 }
