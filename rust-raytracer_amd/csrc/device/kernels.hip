@@ -737,6 +737,7 @@ DEV bool mixture_step(const Acc& A, const Rec& rec, Rng& rng, D3 att, D3& beta, 
 // ------------------------------------------------------------ pt_kernel ---
 // INTEG: 0 = sample_ray with BSDF sampling; 1 = light/cosine mixture pdf; 2 = the reference's literal SPPM sample_ray:
 // the first Diffuse hit adds the pixel's pre-computed photon estimates and ends the path (photon_mapper.rs:345-352)
+static const int REGEN_MIN = 8;
 template <bool LDS, bool GENERAL, int ACCEL, int INTEG>
 __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, RenderK rk, double* __restrict__ samples,
                                                       unsigned int* __restrict__ counter, int* __restrict__ err) {
@@ -788,6 +789,9 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
         for (;;) {
             // ---- regeneration: dead lanes pull the next (pixel, sample) of the pool ----
             uint64_t dead = __ballot(!alive);
+            // the regeneration code runs for the whole wave however few lanes need it: wait until REGEN_MIN lanes are free
+            // (measured: 1 -> 2142, 4 -> 2174, 8 -> 2228, 12 -> 2210, 16 -> 2189, 24 -> 2094 Msamples/s)
+            if ((int)__popcll(dead) < REGEN_MIN && dead != ~0ull) dead = 0ull;
             if (dead != 0ull && next >= pool && more_units) {
                 unsigned int unit = 0;
                 if (lane == 0) unit = atomicAdd(counter, 1u);

@@ -64,21 +64,16 @@ rep("""        if (sp > 0) {
     return h;""")
 rep("DEV bool shade(const Acc& A, const Rec& rec, D3 rdir, Rng& rng, D3& emitted, D3& att, D3& out_dir, bool& diffuse, int* err) {",
     "DEV bool shade(const Acc& A, const Rec& rec, D3 rdir, Rng& rng, D3& emitted, D3& att, D3& out_dir, bool& diffuse, int* err, unsigned long long* ph = nullptr) {")
-rep("        D3 dir = add(rec.normal, unit(random_in_unit_sphere(rng), err));",
-    "        if (ph) cntev(ph, 10);\n        D3 dir = add(rec.normal, unit(random_in_unit_sphere(rng, ph ? ph + 9 : nullptr), err));")
-rep("        D3 dir = add(reflected, muls(random_in_unit_sphere(rng), mt.param));",
-    "        if (ph) cntev(ph, 11);\n        D3 dir = add(reflected, muls(random_in_unit_sphere(rng, ph ? ph + 9 : nullptr), mt.param));")
-rep("    // Dielectric, material.rs:157-188\n", "    // Dielectric, material.rs:157-188\n    if (ph) cntev(ph, 12);\n")
+rep("    if (type != 2) rs = random_in_unit_sphere(rng);",
+    "    if (ph && lamb) cntev(ph, 10);\n    if (ph && type == 1) cntev(ph, 11);\n    if (ph && type == 2) cntev(ph, 12);\n    if (type != 2) rs = random_in_unit_sphere(rng, ph ? ph + 9 : nullptr);")
 # pt_kernel (first occurrence of each pattern = pt_kernel, not the diagnostic kernel 3)
-rep("""    const uint64_t lanemask_lt = (1ull << lane) - 1ull;
-
-    for (;;) {
-        unsigned int unit = 0;""", """    const uint64_t lanemask_lt = (1ull << lane) - 1ull;
+rep("""    int lt = 0, tx = 0, ty = 0, s0 = 0, pool = 0, next = 0;
+    bool more_units = true;
+""", """    int lt = 0, tx = 0, ty = 0, s0 = 0, pool = 0, next = 0;
+    bool more_units = true;
     unsigned long long ph[32];
     for (int i = 0; i < 32; i++) ph[i] = 0;
-
-    for (;;) {
-        unsigned int unit = 0;""")
+""")
 rep("""        for (;;) {
             // ---- regeneration: dead lanes pull the next (pixel, sample) of the pool ----
             uint64_t dead = __ballot(!alive);""", """        for (;;) {
@@ -89,7 +84,8 @@ rep("                if (!alive && k < pool) {\n                    int pix = k 
     "                cntev(ph, 8);\n                if (!alive && k < pool) {\n                    int pix = k & (TILE_PIX - 1), s = s0 + (k >> 6);")
 rep("                        D3 rd = muls(random_in_unit_disk(rng), cam.lens_radius);  // drawn even for aperture 0 (Q4)",
     "                        D3 rd = muls(random_in_unit_disk(rng, ph + 13), cam.lens_radius);")
-rep("""            if (alive) {
+rep("""            // ---- one path segment: sample_ray's loop body, photon_mapper.rs:335-362 ----
+            if (alive) {
                 Hit h = (ACCEL == 2) ? traverse2<GENERAL>(A, stk, stk_stride, o, d, rk.t_min, INFINITY)
                                      : traverse<GENERAL>(A, o, d, rk.t_min, INFINITY);
                 bool done = true;""", """            unsigned long long t1 = PH_NOW();
