@@ -361,6 +361,11 @@ static RenderPlan make_plan(const rt_params* p) {
         chunk = (int)((std::max(1, p->spp) + launches - 1) / launches);
     }
     if (chunk > p->spp) chunk = p->spp;
+    {   // the kernels address a sample by a 32-bit slot index: tiles * chunk * 64 slots per launch
+        const int64_t max_chunk = (int64_t(1) << 32) / (std::max<int64_t>(1, pl.tiles_owned) * TILE_PIX) - 1;
+        if (max_chunk < 1) throw RtError(RT_ERR_UNSUPPORTED, "image too large for one rank: more than 2^32 pixel slots");
+        if (chunk > max_chunk) chunk = (int)max_chunk;
+    }
     pl.spp_chunk = chunk;
     // one work unit = 64 pixels x sub_spp samples (a wave works through it with in-wave regeneration and fetches the next
     // one as soon as its pool is empty).  Many units balance the 4096 resident waves at the end of a launch: aim at

@@ -774,7 +774,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
     // current work unit (wave-uniform); `pool` paths, of which `next` have been handed out.  A wave does not drain a unit
     // before it takes the next one: as soon as the pool is empty and a lane is free the next unit is fetched, so the lanes
     // still finishing long paths of the old unit run beside fresh paths of the new one (a finished path knows where its
-    // sample goes: out_idx is per lane).  Only the end of the launch has a tail.
+    // sample goes: out_slot is per lane).  Only the end of the launch has a tail.
     int lt = 0, tx = 0, ty = 0, s0 = 0, pool = 0, next = 0;
     bool more_units = true;
 
@@ -782,7 +782,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
     D3 o = mk(0, 0, 0), d = mk(0, 0, 1), beta = mk(1, 1, 1), L = mk(0, 0, 0);
     int depth = 0;
     int pix_id = 0;
-    size_t out_idx = 0;
+    uint32_t out_slot = 0;  // index of this path's sample in the launch's sample buffer (make_plan keeps it below 2^32)
     Rng rng;
     rng.s = 0;
     {
@@ -830,7 +830,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
                         L = mk(0., 0., 0.);
                         depth = rk.max_depth;
                         pix_id = y * rk.width + x;
-                        out_idx = ((size_t)((size_t)lt * rk.chunk_spp + (s - rk.s_begin)) * TILE_PIX + pix) * 3;
+                        out_slot = ((uint32_t)lt * (uint32_t)rk.chunk_spp + (uint32_t)(s - rk.s_begin)) * (uint32_t)TILE_PIX + (uint32_t)pix;
                         alive = true;
                     }
                 }
@@ -871,9 +871,10 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
                     }
                 }
                 if (done) {
-                    samples[out_idx] = L.x;
-                    samples[out_idx + 1] = L.y;
-                    samples[out_idx + 2] = L.z;
+                    double* dst = samples + 3 * (size_t)out_slot;
+                    dst[0] = L.x;
+                    dst[1] = L.y;
+                    dst[2] = L.z;
                     alive = false;
                 }
             }
