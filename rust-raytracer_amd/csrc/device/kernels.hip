@@ -26,6 +26,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <vector>
 
@@ -1348,6 +1349,8 @@ struct WorkspaceLease {
         }
         try {
             if (!w->small) HIP_CHECK(hipMalloc(&w->small, WS_SMALL));
+            if (const char* e = getenv("RTAMD_WS_LIMIT_MB"))  // test knob: pretend the device cannot spare a sample buffer this large
+                if (need_samples > ((size_t)std::max(1, atoi(e)) << 20)) throw RtError(RT_ERR_HIP, "sample buffer over RTAMD_WS_LIMIT_MB");
             if (w->samples_bytes < need_samples) {
                 if (w->samples) (void)hipFree(w->samples);
                 w->samples = nullptr;
@@ -1377,8 +1380,9 @@ struct WorkspaceLease {
 typedef void (*pt_fn)(FlatView, CamK, RenderK, double*, unsigned int*, int*);
 typedef void (*pt_sm_fn)(FlatView, const CamK*, RenderK, double*, unsigned int*, int*, unsigned long long*);
 
-void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& plan, double* d_tiles, void* stream_, rt_stats* st) {
+void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& plan_in, double* d_tiles, void* stream_, rt_stats* st) {
     if (!s.committed) throw RtError(RT_ERR_NOT_COMMITTED, "scene not committed");
+    RenderPlan plan = plan_in;  // the launch size may shrink below if the sample buffer cannot be allocated
     hipStream_t stream = (hipStream_t)stream_;
     int dev = 0;
     HIP_CHECK(hipGetDevice(&dev));
@@ -1438,8 +1442,21 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
     const int grid = di.cus * blocks_per_cu;
 
     const int64_t n_pix = plan.tiles_owned * TILE_PIX;
-    WorkspaceLease lease(dev, std::max<size_t>(16, (size_t)n_pix * plan.spp_chunk * 3 * sizeof(double)),
-                         std::max<size_t>(16, (size_t)n_pix * 3 * sizeof(double)));
+    // the sample buffer of one launch (make_plan budgets up to 12 GiB): on a GPU that cannot spare it, halve the launch
+    std::unique_ptr<WorkspaceLease> lease_p;
+    for (;;) {
+        try {
+            lease_p.reset(new WorkspaceLease(dev, std::max<size_t>(16, (size_t)n_pix * plan.spp_chunk * 3 * sizeof(double)),
+                                             std::max<size_t>(16, (size_t)n_pix * 3 * sizeof(double))));
+            break;
+        } catch (const RtError&) {
+            (void)hipGetLastError();
+            if (plan.spp_chunk <= 1) throw;
+            plan.spp_chunk = (plan.spp_chunk + 1) / 2;
+            plan.sub_spp = std::min(plan.sub_spp, plan.spp_chunk);
+        }
+    }
+    WorkspaceLease& lease = *lease_p;
     struct Ptr {
         void* p;
     };

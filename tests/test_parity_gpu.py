@@ -352,3 +352,16 @@ def test_degenerate_image_sizes_match_the_oracle(w, h):
     for kernel in (1, 2):
         img, _ = world.render(cam, width=w, height=h, spp=3, seed=1, kernel=kernel)
         assert np.array_equal(img, exp, equal_nan=True), (kernel, img, exp)
+
+
+def test_launches_shrink_when_the_sample_buffer_cannot_be_allocated(monkeypatch):
+    """make_plan budgets up to 12 GiB for the per-launch sample buffer; a device that cannot spare it gets smaller launches
+    (halved until the buffer fits) and, since samples are reduced in sample order, the same image."""
+    world, cam, _ = _pair("scene_500.json")
+    w, h, spp = 256, 192, 40          # 40 spp x 48 Ki pixels x 24 B = 45 MiB in one launch
+    full, st = world.render(cam, width=w, height=h, spp=spp, seed=5)
+    assert st["launches"] == 1 and st["spp_chunk"] == spp
+    monkeypatch.setenv("RTAMD_WS_LIMIT_MB", "8")
+    small, st2 = world.render(cam, width=w, height=h, spp=spp, seed=5)
+    assert st2["spp_chunk"] == 5 and st2["launches"] == 8           # 40 -> 20 -> 10 -> 5 sample indices per launch
+    assert np.array_equal(small, full)
