@@ -5,7 +5,8 @@ sys.path.insert(0, os.path.join(ROOT, "rust-raytracer_amd"))
 import rtamd
 from rtamd import shapes
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-P, N, I = shapes.torus(160, 320)
+nu, nv = [int(x) for x in os.environ.get("C4_TORUS", "160x320").split("x")]  # C4_TORUS=40x80: smaller meshes
+P, N, I = shapes.torus(nu, nv)
 w = rtamd.World(); w.new(shapes.cornell_with_mesh(w, P, N, I), bvh_seed=1)
 cam = rtamd.Camera(((278, 278, -800), (278, 278, 278)), (0, 1, 0), 50, 1.0, 0.0, 10.0)
 w.render(cam, width=1200, height=1200, spp=2, seed=1)
