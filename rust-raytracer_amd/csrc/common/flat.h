@@ -34,6 +34,10 @@ struct MatDev {   // material.rs:88-212
     int32_t type;  // 0 Lambertian, 1 Metal, 2 Dielectric, 3 DiffuseLight
     int32_t tex;   // albedo / emit texture
     double param;  // Metal.fuzz | Dielectric.ir
+    // Dielectric only, computed on the host with the reference's operations (the same IEEE results, once instead of per hit):
+    double inv_ir;      // 1.0 / ir                                   material.rs:161 (front face)
+    double r0_front;    // ((1 - 1/ir) / (1 + 1/ir))^2                reflectance, material.rs:150-153
+    double r0_back;     // ((1 - ir) / (1 + ir))^2
 };
 struct TexDev {   // material.rs:48-84
     int32_t type;  // 0 Constant, 1 Checker, 2 Image

@@ -649,15 +649,14 @@ DEV bool shade(const Acc& A, const Rec& rec, D3 rdir, Rng& rng, D3& emitted, D3&
         return false;  // Absorb (Q15)
     }
     // Dielectric, material.rs:157-188
-    double ratio = rec.front_face ? (1.0 / mt.param) : mt.param;
+    double ratio = rec.front_face ? mt.inv_ir : mt.param;  // 1.0 / ir, from the host
     const D3 ud = u;
     double cos_theta = fmin(dot(neg(ud), rec.normal), 1.0);
     double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
     bool cannot_refract = ratio * sin_theta > 1.0;
     bool do_reflect = cannot_refract;
     if (!do_reflect) {  // the random number is consumed only when refraction is possible (Q16)
-        double q = (1. - ratio) / (1. + ratio);  // reflectance, material.rs:150-154
-        double r0 = q * q;
+        double r0 = rec.front_face ? mt.r0_front : mt.r0_back;  // ((1 - ratio) / (1 + ratio))^2, from the host (material.rs:150-153)
         double b = 1. - cos_theta;
         double b2 = b * b;
         double b4 = b2 * b2;

@@ -230,7 +230,16 @@ void flatten(rt_scene& s) {
     }
 
     std::vector<MatDev> mats;
-    for (auto& m : s.materials) mats.push_back(MatDev{m.type, m.tex, m.param});
+    for (auto& m : s.materials) {
+        MatDev md{m.type, m.tex, m.param, 0., 0., 0.};
+        if (m.type == MAT_DIELECTRIC) {
+            md.inv_ir = 1.0 / m.param;
+            const double qf = (1. - md.inv_ir) / (1. + md.inv_ir), qb = (1. - m.param) / (1. + m.param);
+            md.r0_front = qf * qf;
+            md.r0_back = qb * qb;
+        }
+        mats.push_back(md);
+    }
     std::vector<TexDev> texs;
     std::vector<uint8_t> texels;
     for (auto& t : s.textures) {
