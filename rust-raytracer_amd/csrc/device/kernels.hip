@@ -521,6 +521,12 @@ DEV int sin_sign_fast(double a) {
     if (!(fabs(r) < 262144.0) || f < 1e-9 || f > 1.0 - 1e-9) return 2;
     return ((int)kf) & 1;
 }
+// Cold paths are kept OUT OF LINE: the hot loop is bound by instruction issue/fetch, and three inlined sin() argument
+// reductions (or acos + atan2) in the middle of it cost ~1 % although they almost never run.
+__device__ __attribute__((noinline)) bool checker_sines_negative(D3 p) {  // the literal test of CheckerTexture, material.rs:62-69
+    double sines = sin(10. * p.x) * sin(10. * p.y) * sin(10. * p.z);
+    return sines < 0.;
+}
 DEV D3 tex_color(const Acc& A, int tex, const Rec& rec) {  // material.rs:52-84
     const TexDev* t = &A.texs[tex];
     int type = t->type;
@@ -529,8 +535,7 @@ DEV D3 tex_color(const Acc& A, int tex, const Rec& rec) {  // material.rs:52-84
         int s0 = sin_sign_fast(10. * p.x), s1 = sin_sign_fast(10. * p.y), s2 = sin_sign_fast(10. * p.z);
         bool negative;
         if ((s0 | s1 | s2) & 2) {  // within 1e-9 of a zero of some factor (or huge argument): evaluate literally
-            double sines = sin(10. * p.x) * sin(10. * p.y) * sin(10. * p.z);
-            negative = sines < 0.;
+            negative = checker_sines_negative(p);
         } else {
             negative = ((s0 ^ s1 ^ s2) & 1) != 0;  // |factors| > 3e-9, so the product cannot underflow to zero
         }
@@ -547,6 +552,13 @@ DEV D3 tex_color(const Acc& A, int tex, const Rec& rec) {  // material.rs:52-84
     return mk(px[0] / 255., px[1] / 255., px[2] / 255.);
 }
 
+__device__ __attribute__((noinline)) void sphere_uv(D3 outward, double& u, double& v) {  // get_uv, sphere.rs:16-20
+    const double PI = 3.14159265358979323846264338327950288, FRAC_1_PI = 0.318309886183790671537767526745028724;
+    double theta = acos(-outward.y);
+    double phi = atan2(-outward.z, outward.x) + PI;
+    u = phi * FRAC_1_PI * 0.5;
+    v = theta * FRAC_1_PI;
+}
 // Build the HitRecord of the winning leaf only (the reference builds one per candidate).
 template <bool GENERAL>
 DEV Rec materialize(const Acc& A, const Hit& h, D3 wo, D3 wd, int* err) {
@@ -568,13 +580,7 @@ DEV Rec materialize(const Acc& A, const Hit& h, D3 wo, D3 wd, int* err) {
         D3 p = add(o, muls(d, h.t));
         outward = divs(sub(p, mk(c0.x, c0.y, c1.x)), c1.y);
         want_uv = A.texs[A.mats[rec.mat].tex].type == 2;
-        if (want_uv) {  // get_uv, sphere.rs:16-20 (only an ImageTexture reads it)
-            const double PI = 3.14159265358979323846264338327950288, FRAC_1_PI = 0.318309886183790671537767526745028724;
-            double theta = acos(-outward.y);
-            double phi = atan2(-outward.z, outward.x) + PI;
-            rec.u = phi * FRAC_1_PI * 0.5;
-            rec.v = theta * FRAC_1_PI;
-        }
+        if (want_uv) sphere_uv(outward, rec.u, rec.v);  // get_uv, sphere.rs:16-20 (only an ImageTexture reads it)
     } else if (GENERAL && kind != NK_TRI) {  // rectangles
         int axis = (int)kind - (int)NK_RECT_YZ;
         double2 r0 = A.rects[3 * pl], r1 = A.rects[3 * pl + 1];
