@@ -521,8 +521,8 @@ DEV int sin_sign_fast(double a) {
     if (!(fabs(r) < 262144.0) || f < 1e-9 || f > 1.0 - 1e-9) return 2;
     return ((int)kf) & 1;
 }
-// Cold paths are kept OUT OF LINE: the hot loop is bound by instruction issue/fetch, and three inlined sin() argument
-// reductions (or acos + atan2) in the middle of it cost ~1 % although they almost never run.
+// This cold path is kept OUT OF LINE: the hot loop is bound by instruction issue/fetch, and three inlined sin() argument
+// reductions in the middle of it cost ~1 % although they almost never run.
 __device__ __attribute__((noinline)) bool checker_sines_negative(D3 p) {  // the literal test of CheckerTexture, material.rs:62-69
     double sines = sin(10. * p.x) * sin(10. * p.y) * sin(10. * p.z);
     return sines < 0.;
@@ -552,7 +552,7 @@ DEV D3 tex_color(const Acc& A, int tex, const Rec& rec) {  // material.rs:52-84
     return mk(px[0] / 255., px[1] / 255., px[2] / 255.);
 }
 
-__device__ __attribute__((noinline)) void sphere_uv(D3 outward, double& u, double& v) {  // get_uv, sphere.rs:16-20
+DEV void sphere_uv(D3 outward, double& u, double& v) {  // get_uv, sphere.rs:16-20 (inline: a call here costs Cornell 4 %)
     const double PI = 3.14159265358979323846264338327950288, FRAC_1_PI = 0.318309886183790671537767526745028724;
     double theta = acos(-outward.y);
     double phi = atan2(-outward.z, outward.x) + PI;
