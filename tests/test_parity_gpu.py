@@ -365,3 +365,15 @@ def test_launches_shrink_when_the_sample_buffer_cannot_be_allocated(monkeypatch)
     small, st2 = world.render(cam, width=w, height=h, spp=spp, seed=5)
     assert st2["spp_chunk"] == 5 and st2["launches"] == 8           # 40 -> 20 -> 10 -> 5 sample indices per launch
     assert np.array_equal(small, full)
+
+
+def test_image_does_not_depend_on_the_work_partition_knobs(monkeypatch):
+    """work-unit size and launch size only change the schedule (which wave traces which path, in how many launches)."""
+    world, cam, _ = _pair("scene_500.json")
+    w, h, spp = 96, 72, 24
+    full, st = world.render(cam, width=w, height=h, spp=spp, seed=9)
+    monkeypatch.setenv("RTAMD_SUB_SPP", "3")
+    monkeypatch.setenv("RTAMD_SAMPLE_BUDGET_MB", "1")           # 1 MiB: a few sample indices per launch
+    other, st2 = world.render(cam, width=w, height=h, spp=spp, seed=9)
+    assert st2["launches"] > st["launches"]
+    assert np.array_equal(other, full)
