@@ -377,3 +377,17 @@ def test_image_does_not_depend_on_the_work_partition_knobs(monkeypatch):
     other, st2 = world.render(cam, width=w, height=h, spp=spp, seed=9)
     assert st2["launches"] > st["launches"]
     assert np.array_equal(other, full)
+
+
+def test_negative_t_min_goes_through_the_reference_order_kernel():
+    """box32's conservativeness proof needs t_min >= 0: with a negative t_min (hits behind the origin count, as in the
+    reference's World::hit for such a range) kernel 0 resolves to kernel 1 and kernel 2 is refused."""
+    import rtamd
+    world, cam, ref = _pair("scene_10.json")
+    img, st = world.render(cam, width=40, height=24, spp=3, seed=2, t_min=-0.25)
+    assert st["kernel_used"] == 1
+    exp, _ = ref.render(40, 24, 3, seed=2, t_min=-0.25)
+    _assert_same(img, exp, "t_min = -0.25")
+    with pytest.raises(rtamd.RtError) as e:
+        world.render(cam, width=8, height=8, spp=1, t_min=-0.25, kernel=2)
+    assert e.value.code == -10   # RT_ERR_UNSUPPORTED
