@@ -391,3 +391,29 @@ def test_negative_t_min_goes_through_the_reference_order_kernel():
     with pytest.raises(rtamd.RtError) as e:
         world.render(cam, width=8, height=8, spp=1, t_min=-0.25, kernel=2)
     assert e.value.code == -10   # RT_ERR_UNSUPPORTED
+
+
+def test_coordinates_beyond_2_pow_36_use_the_reference_order_kernel():
+    """box32 keeps lo*iv and of*iv finite for coordinates below 2^36; larger scenes get no accel (flatten.cpp) and render
+    through kernel 1, still bit-exact."""
+    import oracle
+    import rtamd
+    S = 3.0e11                                                      # > 2^36 / 64 (origin_limit = 64 x extent)
+    w, o = rtamd.World(), oracle.Scene()
+    ids = []
+    for sc in (w, o):
+        m = sc.Lambertian(sc.ConstantTexture((0.7, 0.6, 0.5)))
+        e = sc.DiffuseLight(sc.ConstantTexture((4.0, 4.0, 4.0)))
+        items = [sc.Sphere((0.0, -1000.0 * S, 0.0), 1000.0 * S, m), sc.Sphere((0.0, 1.0 * S, 0.0), 1.0 * S, m),
+                 sc.Sphere((2.5 * S, 3.0 * S, 1.0 * S), 1.0 * S, e)]
+        ids.append(items)
+    w.new(ids[0], bvh_seed=1)
+    o.World(ids[1], 1)
+    assert w.info()["accel_ok"] == 0
+    cam = rtamd.Camera(((0, 2 * S, -8 * S), (0, 1 * S, 0)), (0, 1, 0), 40, 1.5, 0.0, 8 * S)
+    o.Camera((0, 2 * S, -8 * S), (0, 1 * S, 0), (0, 1, 0), 40, 1.5, 0.0, 8 * S)
+    img, st = w.render(cam, width=48, height=32, spp=4, seed=1)
+    assert st["kernel_used"] == 1
+    exp, _ = o.render(48, 32, 4, seed=1)
+    _assert_same(img, exp, "huge coordinates")
+    assert img.max() > 0
