@@ -259,9 +259,11 @@ def test_accel_is_conservative_fuzz(scale):
         w = rtamd.World()
         m = [w.Lambertian(w.ConstantTexture(tuple(rng.random(3)))) for _ in range(3)]
         items = []
+        spheres = []
         for _ in range(60):
             c = (rng.random(3) - 0.5) * 20.0 * scale
-            items.append(w.Sphere(tuple(c), float(rng.uniform(0.05, 1.5) * scale), m[rng.integers(3)]))
+            spheres.append((tuple(c), float(rng.uniform(0.05, 1.5) * scale)))
+            items.append(w.Sphere(spheres[-1][0], spheres[-1][1], m[rng.integers(3)]))
         for _ in range(12):
             a0, b0 = (rng.random(2) - 0.5) * 20.0 * scale
             a1, b1 = a0 + rng.uniform(0.5, 6.0) * scale, b0 + rng.uniform(0.5, 6.0) * scale
@@ -290,6 +292,25 @@ def test_accel_is_conservative_fuzz(scale):
         bad = np.argwhere((a != b).any(axis=1))
         assert len(bad) == 0, "trial %d: %d rays differ, first %s:\n k1 %s\n k2 %s" % (trial, len(bad), rays[bad[0, 0]], a[bad[0, 0]], b[bad[0, 0]])
         assert a[:, 0].sum() > n // 20
+        # grazing rays from FAR origins (up to the 64 x extent the boxes are padded for): aimed at the silhouette of every
+        # sphere, just inside and just outside; of = fl32(o) and c = fl32(of * iv) are at their coarsest here
+        far, tgt = [], []
+        for (c, r) in spheres:
+            for eps in (1e-3, 1e-6, 1e-9, -1e-9, -1e-6, -1e-3):
+                u = rng.normal(size=3)
+                u /= np.linalg.norm(u)
+                org = np.asarray(c) + u * rng.uniform(100.0, 600.0) * scale
+                p = np.cross(u, rng.normal(size=3))
+                p /= np.linalg.norm(p)
+                far.append(org)
+                tgt.append(np.asarray(c) + p * r * (1.0 - eps))
+        far, tgt = np.array(far), np.array(tgt)
+        rays = np.concatenate([far, tgt - far], axis=1)
+        a = w.debug_hit(rays, t_min=1e-3, kernel=1)
+        b = w.debug_hit(rays, t_min=1e-3, kernel=2)
+        bad = np.argwhere((a != b).any(axis=1))
+        assert len(bad) == 0, "trial %d (grazing): %d rays differ, first %s:\n k1 %s\n k2 %s" % (trial, len(bad), rays[bad[0, 0]], a[bad[0, 0]], b[bad[0, 0]])
+        assert 0.25 < a[:, 0].mean() < 0.95
 
 
 @pytest.mark.parametrize("kernel", [1, 2])
