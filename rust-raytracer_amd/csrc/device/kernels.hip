@@ -1,14 +1,14 @@
 // HIP kernels of the radiance path for gfx950 (MI355X, wave64).
 //
-// pt_kernel  -- persistent path tracer.  One wave owns a work unit = (8x8 pixel
-//   tile, sub-range of sample indices) and drains its pool of 64*sub_spp paths
-//   with in-wave path regeneration: a lane whose path ended immediately pulls the
-//   next (pixel, sample) of the pool (wave64 ballot + prefix popcount), so lanes
-//   stay busy although path lengths vary from 1 to 50 segments.  The flattened
-//   scene (common/flat.h) is staged once per workgroup into LDS when it fits
-//   (its traversal tables; scene_500: 96 KB of the CU's 160 KB), otherwise read through L2.
-//   Each finished path stores its radiance to the per-sample buffer; nothing is
-//   accumulated out of order.
+// pt_kernel  -- persistent path tracer.  256 workgroups x 1024 threads (4 waves per SIMD) stay resident for the whole
+//   launch; a wave takes work units = (8x8 pixel tile, <= 8 sample indices) from a global counter and keeps its lanes
+//   busy with in-wave path regeneration: lanes whose paths ended (once 8 of them are free) pull the next (pixel, sample)
+//   of the unit's pool (wave64 ballot + prefix popcount), and the next unit is fetched as soon as the pool is empty, so
+//   path lengths of 1 to 50 segments never drain a wave.  Per segment: closest hit (kernel 2: SAH BVH2 with conservative
+//   f32 boxes, per-lane stack in LDS; kernel 1: the reference-order program), hit record, emission + scatter.
+//   The flattened scene (common/flat.h) is staged once per workgroup into LDS when it fits (its traversal tables;
+//   scene_500: 72 KB + 56 KB of stacks of the CU's 160 KB), otherwise read through L2 with the top of the BVHs cached.
+//   Each finished path stores its radiance to the per-sample buffer; nothing is accumulated out of order.
 // reduce_kernel -- per pixel, adds the launch's samples IN SAMPLE ORDER into the
 //   f64 accumulator: the reference's `pixel_color += sample` loop (camera.rs:96-101),
 //   which makes the image independent of how work was scheduled.
