@@ -9,20 +9,29 @@ pixel-samples through the HIP path: rt_render_tiles_device on every rank's tiles
 framebuffer gather to rank 0 (RCCL) and the stitch.  The scene, camera and all buffers are
 resident in HBM before the timed region.  value = W*H*spp*K / max-over-ranks wall time.
 
-N > 1: launched by torch.distributed.run, one rank per GPU; the frame is dealt to ranks by
-8x8 tile (tile t -> rank t % N), total work fixed => "scaling": "strong".
+N > 1: one rank per GPU; the frame is dealt to ranks by 8x8 tile (tile t -> rank t % N), total work
+fixed => "scaling": "strong".  Started either by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE
+in the environment) or directly: `python bench.py --gpus N` starts the N ranks itself, as child
+processes, BEFORE anything in this process has touched the GPU, and exits with their status.  Fewer
+than N visible devices, or a WORLD_SIZE that contradicts --gpus, is an error -- never a silent
+single-GPU run.
 
-Extra objects on the JSON line:
-  roofline     -- SURVEY s8d contract: algorithmic bytes per sample (reference-order AABB/sphere
-                  test counts x reference payload sizes, tests/golden/alg_bytes_scene_500.json)
-                  x samples per launch / mean path-trace kernel duration (HIP events recorded by
-                  the library on its launch stream), against the 8 TB/s HBM peak.
-  cpu_baseline -- the oracle (a C++ port of the reference's CPU path; the Rust binary cannot be
-                  built here) on this box's host cores, bounded sample, rank 0 at N=1 only.
+Extra objects on the JSON line (definitions and formulas: DESIGN.md s5):
+  roofline          -- the bound that binds pt_kernel: VALU issue.  achieved = VALU wave-instructions/s,
+                       peak = SIMDs x clock / mean issue cycles per VALU instruction; lane_utilisation beside it.
+                       Per-sample instruction counts come from the PMC passes committed under profiles/ (model
+                       file named in `source`); the kernel time is measured live (HIP events on the launch stream).
+  roofline_contract -- SURVEY s8d: algorithmic bytes per sample in the REFERENCE's traversal order / kernel time
+                       against the 8 TB/s HBM peak.  The scene is LDS-resident, so this is not a physical fraction.
+  roofline_hbm      -- physical HBM traffic (PMC, carried over) / kernel time against the HBM peak.
+  cpu_baseline      -- the oracle (a C++ port of the reference's CPU path; the Rust binary cannot be
+                       built here) on this box's host cores, bounded sample, rank 0 at N=1 only.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,8 +40,9 @@ sys.path.insert(0, os.path.join(ROOT, "rust-raytracer_amd"))
 
 SCENE = os.path.join(ROOT, "tests", "golden", "scenes", "scene_500.json")
 ALG_BYTES = os.path.join(ROOT, "tests", "golden", "alg_bytes_scene_500.json")
-TRAFFIC = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+MODEL = os.path.join(ROOT, "profiles", "pt_kernel_model.json")
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+N_SIMDS = 256 * 4      # 256 CUs x 4 SIMDs
 CPU_BASELINE_THREADS = 16
 
 
@@ -54,6 +64,82 @@ def cpu_baseline(width, height, spp_cpu, seed):
     }
 
 
+def visible_devices():
+    """HIP devices visible to librtamd, counted in a CHILD process: the launcher itself must never initialise the GPU."""
+    code = "import sys; sys.path.insert(0, %r); import rtamd; print(rtamd.device_count())" % os.path.join(ROOT, "rust-raytracer_amd")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise SystemExit("bench.py: cannot load librtamd.so to count devices:\n" + r.stderr[-2000:])
+    return int(r.stdout.strip().splitlines()[-1])
+
+
+def rank_command(n_ranks, argv, port):
+    """The command the driver uses for N > 1 (one rank per GPU over torch.distributed.run)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n_ranks, "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` with no rank environment: start the N ranks as children and return their status.
+    Nothing here initialises the GPU runtime (no framework import, no HIP call), and no process image is replaced."""
+    n_dev = visible_devices()
+    rehearse = os.environ.get("RTAMD_BENCH_REHEARSE") == "1"
+    if n_dev < 1:
+        raise SystemExit("bench.py needs a HIP device: the product has no CPU fallback (0 devices visible, --gpus %d)" % args.gpus)
+    if n_dev < args.gpus and not rehearse:
+        raise SystemExit("bench.py: --gpus %d but only %d HIP device(s) visible; refusing to render on fewer GPUs than asked "
+                         "(RTAMD_BENCH_REHEARSE=1 rehearses the N-rank path on one device over gloo)" % (args.gpus, n_dev))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["MASTER_ADDR"] = "127.0.0.1"
+    return subprocess.call(rank_command(args.gpus, argv, port), env=env)
+
+
+def roofline_objects(stats_acc, dt_kernel_s, clock_note=None):
+    """roofline / roofline_contract / roofline_hbm for pt_kernel (see the module docstring and DESIGN.md s5)."""
+    launches = max(1, stats_acc["launches"])
+    samples_per_launch = stats_acc["samples"] / launches
+    ms_per_launch = stats_acc["kernel_ms"] / launches
+    sps = stats_acc["samples"] / (stats_acc["kernel_ms"] * 1e-3) if stats_acc["kernel_ms"] > 0 else 0.0  # samples/s inside pt_kernel
+    with open(ALG_BYTES) as f:
+        b_alg = json.load(f)["bytes_per_sample"]
+    contract = {"bound": "hbm", "achieved": sps * b_alg / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sps * b_alg / 1e9 / HBM_PEAK_GBS,
+                "alg_bytes_per_sample": b_alg,
+                "note": "SURVEY s8d contract figure: bytes the REFERENCE's traversal order would touch; served from LDS here and mostly "
+                        "never touched (near-first SAH traversal), so frac > 1 is expected and is not a physical utilisation"}
+    model = None
+    if os.path.exists(MODEL):
+        with open(MODEL) as f:
+            model = json.load(f)
+    roof = {"bound": "valu_issue", "achieved": None, "peak": None, "unit": "G wave-instructions/s", "frac": None, "traffic": None,
+            "kernel": "pt_kernel", "samples_per_launch": samples_per_launch, "ms_per_launch": ms_per_launch}
+    hbm = None
+    if model:
+        ipc = model["valu_insts_per_sample"]            # VALU wave-instructions per sample (SQ_INSTS_VALU / samples)
+        cyc = model["valu_issue_cycles_per_inst"]       # SQ_ACTIVE_INST_VALU * 4 / SQ_INSTS_VALU (f64 and 64-bit integer ops issue slower than f32)
+        clk = model["clock_ghz"]                        # GRBM_GUI_ACTIVE / 8 / kernel time of the PMC pass
+        achieved = sps * ipc / 1e9
+        peak = N_SIMDS * clk / cyc
+        frac = achieved / peak if peak > 0 else None
+        roof.update({"achieved": achieved, "peak": peak, "frac": frac, "lane_utilisation": model["lane_utilisation"],
+                     "useful_frac": frac * model["lane_utilisation"] if frac else None,
+                     "valu_insts_per_sample": ipc, "valu_issue_cycles_per_inst": cyc, "clock_ghz": clk,
+                     "source": "per-sample counts carried over from %s; kernel time measured in this run" % model.get("source", "profiles/")})
+        if frac is not None and not (0.0 < frac <= 1.05):
+            roof.update({"frac": None, "useful_frac": None,
+                         "note": "live kernel rate and the PMC model disagree (frac %.3f): the model file is stale for this build" % frac})
+        bps = model.get("hbm_bytes_per_sample")
+        if bps is not None:
+            roof["traffic"] = bps * samples_per_launch  # bytes per launch, PMC (FETCH_SIZE x2 on gfx950 + WRITE_SIZE), carried over
+            hbm = {"bound": "hbm", "achieved": sps * bps / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sps * bps / 1e9 / HBM_PEAK_GBS,
+                   "hbm_bytes_per_sample": bps, "source": "carried over from %s" % model.get("source", "profiles/")}
+    return roof, contract, hbm
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -63,37 +149,53 @@ def main():
     ap.add_argument("--height", type=int, default=1200)
     ap.add_argument("--spp", type=int, default=1000)
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--kernel", type=int, default=0, help="0 = library default; 1/2/3 force a path-trace kernel (A/B runs only)")
+    ap.add_argument("--kernel", type=int, default=0, help="0 = library default; 1/2/4 force a traversal (A/B runs only)")
     ap.add_argument("--cpu-spp", type=int, default=32, help="spp of the bounded CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+
+    ws_env = os.environ.get("WORLD_SIZE")
+    if ws_env is None:
+        if args.gpus > 1:
+            sys.exit(launch_ranks(args, sys.argv[1:]))
+        world_size = 1
+    else:
+        world_size = int(ws_env)
+        if world_size != args.gpus:
+            raise SystemExit("bench.py: --gpus %d contradicts WORLD_SIZE=%d" % (args.gpus, world_size))
 
     import torch
     import rtamd
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world_size = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available() or rtamd.device_count() < 1:
+    rehearse = os.environ.get("RTAMD_BENCH_REHEARSE") == "1"  # all ranks on device 0, gather over gloo through host memory
+    n_dev = rtamd.device_count()
+    if not torch.cuda.is_available() or n_dev < 1:
         raise SystemExit("bench.py needs a HIP device: the product has no CPU fallback")
-    dev_index = int(os.environ.get("RTAMD_BENCH_DEVICE", local_rank))  # override only to rehearse N>1 on a 1-GPU box
+    if n_dev < world_size and not rehearse:
+        raise SystemExit("bench.py: %d ranks but only %d HIP device(s) visible" % (world_size, n_dev))
+    dev_index = 0 if rehearse else local_rank
     torch.cuda.set_device(dev_index)  # before the process group: RCCL binds the communicator to the current device
     dev = torch.device("cuda", dev_index)
     dist = None
     if world_size > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world_size)
+        dist.init_process_group(backend="gloo" if rehearse else "nccl", rank=rank, world_size=world_size)
 
     world, cam = rtamd.load_scene_file(SCENE)
     params = rtamd.default_params(width=args.width, height=args.height, spp=args.spp, max_depth=50, t_min=1e-3, seed=args.seed,
                                   rank=rank, world=world_size, kernel=args.kernel)
-    from rtamd.distributed import TileLayout, gather_tiles
+    from rtamd.distributed import TileLayout, TileGather
     layout = TileLayout(args.width, args.height, world_size)
     p0 = rtamd.default_params(width=args.width, height=args.height, spp=args.spp, rank=0, world=world_size)
     stride = layout.stride  # rank 0 owns the most tiles; every rank pads to it for the gather
     assert stride == rtamd.tiles_owned(p0)
     d_tiles = torch.zeros(stride * 64 * 3, dtype=torch.float64, device=dev)
     frame = torch.zeros(args.height * args.width * 3, dtype=torch.float64, device=dev) if rank == 0 else None
+    gather = TileGather(layout, rank, dist, d_tiles, dst=0, host_staged=rehearse)  # receive buffer allocated once, outside the loop
     stream = torch.cuda.current_stream().cuda_stream
 
     stats_acc = {"kernel_ms": 0.0, "launches": 0, "samples": 0}
@@ -102,7 +204,7 @@ def main():
     def step(timed):
         st = world.render_tiles_device(cam, params, d_tiles.data_ptr(), stream)
         # the stitch of camera.rs:115-123 across GPUs: ONE framebuffer gather to rank 0 over RCCL/xGMI
-        src = gather_tiles(d_tiles, layout, rank, dist, dst=0)
+        src = gather(d_tiles)
         if rank == 0:
             rtamd.assemble_frame_device(p0, src.data_ptr(), stride, frame.data_ptr(), stream)
         if timed:
@@ -126,27 +228,16 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
     if rank == 0:
         total = args.width * args.height * args.spp * args.steps
         value = total / dt / 1e6
-        with open(ALG_BYTES) as f:
-            alg = json.load(f)
-        b_alg = alg["bytes_per_sample"]
-        # dominant kernel = pt_kernel; per launch: samples/launch * B_alg / mean launch duration (this rank)
-        launches = max(1, stats_acc["launches"])
-        samples_per_launch = stats_acc["samples"] / launches
-        ms_per_launch = stats_acc["kernel_ms"] / launches
-        achieved = (samples_per_launch * b_alg) / (ms_per_launch * 1e-3) / 1e9 if ms_per_launch > 0 else 0.0
-        traffic = None
-        if os.path.exists(TRAFFIC):
-            with open(TRAFFIC) as f:
-                per_sample = json.load(f).get("hbm_bytes_per_sample")
-                if per_sample is not None:  # PMC-measured (profiles/), scaled to this run's launch size
-                    traffic = per_sample * samples_per_launch
+        roof, contract, hbm = roofline_objects(stats_acc, dt)
+        kernel_names = {1: "reference-order stackless", 2: "SAH-BVH2 accel, f32 conservative boxes",
+                        4: "8-wide quantised BVH accel, f32 conservative boxes"}
         out = {
             "metric": "Msamples/sec (px*spp), scene_500 %dx%d %dspp" % (args.width, args.height, args.spp),
             "value": value, "unit": "Msamples/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
@@ -155,18 +246,17 @@ def main():
             "config": {"workload": "tests/golden/scenes/scene_500.json (data/scene_500.json of the reference, minified): 1005 spheres, "
                                    "999-node file BVH, %dx%d, %d spp, depth 50, seed %d" % (args.width, args.height, args.spp, args.seed),
                        "parallelism": "image tiles 8x8 dealt round-robin to %d GPU(s), RCCL framebuffer gather" % world_size,
-                       "kernel": "pt_kernel<%s>(f64 primitives, scene %s)" % ({1: "reference-order stackless", 2: "SAH-BVH2 accel, f32 conservative boxes", 3: "SAH-BVH2 accel, early-restart schedule"}.get(last.get("kernel_used"), "?"),
+                       "kernel": "pt_kernel<%s>(f64 primitives, scene %s)" % (kernel_names.get(last.get("kernel_used"), "?"),
                                                                               "in LDS" if last.get("scene_in_lds") else "in L2/HBM"),
                        "block_threads": last.get("block_threads"), "grid_blocks": last.get("grid_blocks"),
                        "spp_chunk": last.get("spp_chunk")},
             "wall_s": dt,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "pt_kernel", "alg_bytes_per_sample": b_alg, "samples_per_launch": samples_per_launch,
-                         "ms_per_launch": ms_per_launch,
-                         "note": "algorithmic bytes in the REFERENCE's traversal order (SURVEY s8d); the scene's traversal tables are "
-                                 "LDS-resident, so physical HBM traffic is far below this figure"},
+            "roofline": roof, "roofline_contract": contract,
         }
+        if hbm is not None:
+            out["roofline_hbm"] = hbm
+        if rehearse:
+            out["rehearsal"] = "all %d ranks share HIP device 0, gather over gloo through host memory: NOT a scaling measurement" % world_size
         if world_size == 1 and args.cpu_spp > 0:
             out["cpu_baseline"] = cpu_baseline(args.width, args.height, args.cpu_spp, args.seed)
         print(json.dumps(out))

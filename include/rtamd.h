@@ -150,6 +150,27 @@ int rt_object_bvh_build(rt_scene* s, int n, const int* objects, uint64_t bvh_see
 /* Hitable::bounding_box (objects/hit.rs:53): out = min[3], max[3]; RT_ERR_NO_BBOX for None */
 int rt_object_bounding_box(const rt_scene* s, int object, double out_min_max[6]);
 
+/* Introspection of the host-side object graph (the walk a `Describe` visitor of the reference's trait objects does the
+ * other way round): what an object id stands for, its parameters and its children.
+ *   sphere:    v = {center[3], radius}                      (objects/sphere.rs:9-13)
+ *   rect:      v = {a0, b0, a1, b1, k}, axis = constant axis (0: YZRectangle x=k, 1: XZRectangle y=k, 2: XYRectangle z=k)
+ *   triangle:  v = {ia, ib, ic} vertex indices of its mesh  (objects/mesh.rs:8-14)
+ *   cube / list / mesh / transform / bvh: children only (cube: its 6 sides; mesh: its inner BVHNode; bvh: {left, right}) */
+typedef enum rt_object_type {
+    RT_OBJ_SPHERE = 0, RT_OBJ_RECT = 1, RT_OBJ_CUBE = 2, RT_OBJ_TRIANGLE = 3, RT_OBJ_MESH = 4, RT_OBJ_TRANSFORM = 5,
+    RT_OBJ_LIST = 6, RT_OBJ_BVH = 7
+} rt_object_type;
+typedef struct rt_object_desc {
+    int32_t type;        /* rt_object_type */
+    int32_t material;    /* material id, -1 for containers */
+    int32_t n_children;
+    int32_t axis;        /* rect only */
+    double v[8];
+} rt_object_desc;
+int rt_scene_root(const rt_scene* s);            /* object id of the root (World.bvh / the file's top-level list), RT_ERR_ARG if unset */
+int rt_object_describe(const rt_scene* s, int object, rt_object_desc* out);
+int rt_object_children(const rt_scene* s, int object, int capacity, int* out);  /* writes min(capacity, n) ids, returns n */
+
 /* World::new(hitable_list, cam, lights) (world.rs:15-25): root = BVHNode::new(list) */
 int rt_world_new(rt_scene* s, int n, const int* objects, uint64_t bvh_seed);
 /* World::new's `lights: Vec<Arc<dyn Light>>` (world.rs:18; scene.rs:110 passes the XZRectLight): the objects that the
@@ -185,7 +206,8 @@ int rt_render(const rt_scene* s, const rt_camera* cam, const rt_params* p, doubl
 /* The reference's main.rs:52-54 as it really is: SPPMIntegrator::new(world) (photon_mapper.rs:139-233: `iterations` x
  * {photons_per_iter photon paths -> global + caustic photon maps; one eye ray per pixel; progressive radius update}) followed
  * by capture_image with SPPMIntegrator::sample_ray (photon_mapper.rs:327-365: the first Diffuse hit adds the pixel's estimates
- * and ends the path).  Needs rt_scene_set_lights with lights made by rt_object_*_light.  One GPU, whole frame.
+ * and ends the path).  Needs rt_scene_set_lights with lights made by rt_object_*_light.  One GPU, whole frame:
+ * p->world != 1 is RT_ERR_ARG.
  * stats_out (optional, HOST, height*width*10 f64): per pixel {global: flux[3], radius2, photons; caustic: flux[3], radius2, photons}.
  * spp == 0 runs the pre-pass only (out_rgb may be NULL).  rt_stats.reserved[0] = pre-pass time in microseconds. */
 typedef struct rt_sppm_config {
@@ -208,7 +230,7 @@ int rt_render_tiles_device(const rt_scene* s, const rt_camera* cam, const rt_par
                            rt_stats* stats);
 /* SPPM across GPUs: every rank runs the same deterministic pre-pass (photon maps + per-pixel statistics of the WHOLE
  * frame: ~0.13 s for the reference's 50 x 500 000 photons) and renders only its own tiles; the buffers are gathered and
- * stitched exactly like rt_render_tiles_device's.  d_stats (DEVICE, W*H*10 f64) may be NULL. */
+ * stitched exactly like rt_render_tiles_device's.  (The per-pixel pre-pass statistics are only returned by rt_render_sppm.) */
 int rt_render_sppm_tiles_device(const rt_scene* s, const rt_camera* cam, const rt_params* p, const rt_sppm_config* cfg, double* d_tiles,
                                 void* hip_stream, rt_stats* stats);
 int64_t rt_tiles_total(const rt_params* p);   /* ceil(W/8)*ceil(H/8) */

@@ -230,6 +230,45 @@ int rt_object_bounding_box(const rt_scene* s, int object, double out_min_max[6])
         return (int)RT_OK;
     });
 }
+int rt_scene_root(const rt_scene* s) {
+    return guard([&] {
+        REQUIRE(s, "null scene");
+        REQUIRE(s->root >= 0, "scene has no root");
+        return s->root;
+    });
+}
+int rt_object_describe(const rt_scene* s, int object, rt_object_desc* out) {
+    return guard([&] {
+        REQUIRE(s && out, "null argument");
+        check_obj(*s, object);
+        const ObjectRec& o = s->objects[object];
+        static_assert((int)OBJ_SPHERE == RT_OBJ_SPHERE && (int)OBJ_RECT == RT_OBJ_RECT && (int)OBJ_CUBE == RT_OBJ_CUBE &&
+                      (int)OBJ_TRIANGLE == RT_OBJ_TRIANGLE && (int)OBJ_MESH == RT_OBJ_MESH && (int)OBJ_TRANSFORM == RT_OBJ_TRANSFORM &&
+                      (int)OBJ_LIST == RT_OBJ_LIST && (int)OBJ_BVH == RT_OBJ_BVH, "rt_object_type mirrors ObjType");
+        std::memset(out, 0, sizeof(*out));
+        out->type = o.type;
+        out->material = (o.type == OBJ_SPHERE || o.type == OBJ_RECT || o.type == OBJ_TRIANGLE) ? o.material : -1;
+        out->n_children = (int32_t)o.children.size();
+        if (o.type == OBJ_SPHERE) {
+            out->v[0] = o.c[0]; out->v[1] = o.c[1]; out->v[2] = o.c[2]; out->v[3] = o.r;
+        } else if (o.type == OBJ_RECT) {
+            out->axis = o.axis;
+            out->v[0] = o.a0; out->v[1] = o.b0; out->v[2] = o.a1; out->v[3] = o.b1; out->v[4] = o.k;
+        } else if (o.type == OBJ_TRIANGLE) {
+            out->v[0] = (double)o.ia; out->v[1] = (double)o.ib; out->v[2] = (double)o.ic;
+        }
+        return (int)RT_OK;
+    });
+}
+int rt_object_children(const rt_scene* s, int object, int capacity, int* out) {
+    return guard([&] {
+        REQUIRE(s && (out || capacity <= 0), "null argument");
+        check_obj(*s, object);
+        const ObjectRec& o = s->objects[object];
+        for (int i = 0; i < capacity && i < (int)o.children.size(); i++) out[i] = o.children[i];
+        return (int)o.children.size();
+    });
+}
 int rt_world_new(rt_scene* s, int n, const int* objects, uint64_t bvh_seed) {
     return guard([&] {
         not_committed_only(s);
@@ -517,6 +556,8 @@ int rt_render_sppm(const rt_scene* s, const rt_camera* cam, const rt_params* p, 
     return guard([&] {
         REQUIRE(s && cam && p && cfg, "null argument");
         REQUIRE(p->spp == 0 || out_rgb, "null output buffer");
+        REQUIRE(p->world == 1 && p->rank == 0, "rt_render_sppm renders the whole frame on one GPU (world must be 1); "
+                                               "the tile-partitioned form is rt_render_sppm_tiles_device");
         if (!s->committed) throw RtError(RT_ERR_NOT_COMMITTED, "rt_scene_commit has not been called");
         if (device_count() < 1) throw RtError(RT_ERR_NO_DEVICE, "no HIP device: librtamd has no CPU fallback");
         auto t0 = std::chrono::steady_clock::now();

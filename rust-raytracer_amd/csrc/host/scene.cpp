@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <string>
 
 #include "../common/rng.h"
 
@@ -63,6 +64,12 @@ int add_material(rt_scene& s, int type, int tex, double param) {
     return (int)s.materials.size() - 1;
 }
 
+// Geometry must be finite: the reference would sort NaN box corners with an inconsistent comparator (bvh.rs:34-44) and
+// feed NaN slabs to every ray; here it is an argument error at the boundary.
+static void require_finite(const double* v, size_t n, const char* what) {
+    for (size_t i = 0; i < n; i++)
+        if (!std::isfinite(v[i])) throw RtError(RT_ERR_ARG, std::string(what) + " must be finite");
+}
 static int push(rt_scene& s, ObjectRec&& o) {
     s.objects.push_back(std::move(o));
     return (int)s.objects.size() - 1;
@@ -71,6 +78,8 @@ static int push(rt_scene& s, ObjectRec&& o) {
 // sphere.rs:56-61
 int add_sphere(rt_scene& s, const double c[3], double r, int mat) {
     check_mat(s, mat);
+    require_finite(c, 3, "sphere center");
+    require_finite(&r, 1, "sphere radius");
     ObjectRec o;
     o.type = OBJ_SPHERE;
     o.material = mat;
@@ -87,6 +96,10 @@ int add_sphere(rt_scene& s, const double c[3], double r, int mat) {
 int add_rect(rt_scene& s, int axis, double a0, double b0, double a1, double b1, double k, int mat) {
     check_mat(s, mat);
     if (axis < 0 || axis > 2) throw RtError(RT_ERR_ARG, "rect axis must be 0..2");
+    {
+        const double v[5] = {a0, b0, a1, b1, k};
+        require_finite(v, 5, "rectangle coordinates");
+    }
     ObjectRec o;
     o.type = OBJ_RECT;
     o.material = mat;
@@ -234,6 +247,8 @@ int add_mesh(rt_scene& s, int n_vert, const double* pos, const double* nrm, int 
              bool synth_normals, uint64_t bvh_seed) {
     check_mat(s, mat);
     if (n_vert <= 0 || n_tri <= 0 || !pos || !idx) throw RtError(RT_ERR_ARG, "empty mesh");
+    require_finite(pos, (size_t)n_vert * 3, "mesh positions");
+    if (nrm) require_finite(nrm, (size_t)n_vert * 3, "mesh normals");
     for (int i = 0; i < 3 * n_tri; i++)
         if (idx[i] >= (uint32_t)n_vert) throw RtError(RT_ERR_ARG, "triangle index out of range");
     auto md = std::make_unique<MeshData>();
@@ -319,6 +334,9 @@ static void xf_point(const double* t, const double* p, double* o) {  // vec3.rs:
 // Transform::new, transform.rs:17-148 : M = T*S*Rx*Ry*Rz ; box = 8 transformed corners
 int add_transform(rt_scene& s, const double rot_deg[3], const double scale[3], const double translate[3], int obj) {
     check_obj(s, obj);
+    require_finite(rot_deg, 3, "transform rotation");
+    require_finite(scale, 3, "transform scale");
+    require_finite(translate, 3, "transform translation");
     double rx = rot_deg[0] * PI / 180., ry = rot_deg[1] * PI / 180., rz = rot_deg[2] * PI / 180.;
     const double T[16] = {1., 0., 0., translate[0], 0., 1., 0., translate[1], 0., 0., 1., translate[2], 0., 0., 0., 1.};
     const double S[16] = {scale[0], 0., 0., 0., 0., scale[1], 0., 0., 0., 0., scale[2], 0., 0., 0., 0., 1.};

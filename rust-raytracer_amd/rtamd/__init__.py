@@ -55,6 +55,13 @@ class rt_sppm_config(C.Structure):
                 ("max_bounces", C.c_int32), ("reserved", C.c_int32), ("alpha", C.c_double)]
 
 
+class rt_object_desc(C.Structure):
+    _fields_ = [("type", C.c_int32), ("material", C.c_int32), ("n_children", C.c_int32), ("axis", C.c_int32), ("v", C.c_double * 8)]
+
+
+OBJECT_TYPES = ("Sphere", "Rect", "Cube", "Triangle", "Mesh", "Transform", "HitableList", "BVHNode")
+
+
 class rt_scene_info(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("n_nodes", "n_boxes", "n_spheres", "n_rects", "n_tris", "n_xforms", "n_materials",
                                          "n_textures", "n_verts", "max_depth", "committed", "reserved")] + [("bytes", C.c_uint64)] + \
@@ -97,6 +104,9 @@ _SIGS = [
     ("rt_object_bvh_node", C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     ("rt_object_bvh_build", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_uint64]),
     ("rt_object_bounding_box", C.c_int, [C.c_void_p, C.c_int, C.c_double * 6]),
+    ("rt_scene_root", C.c_int, [C.c_void_p]),
+    ("rt_object_describe", C.c_int, [C.c_void_p, C.c_int, C.POINTER(rt_object_desc)]),
+    ("rt_object_children", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     ("rt_world_new", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_uint64]),
     ("rt_scene_set_root", C.c_int, [C.c_void_p, C.c_int]),
     ("rt_scene_set_lights", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
@@ -311,6 +321,18 @@ class World:
         out = (C.c_double * 6)()
         _chk(self.L.rt_object_bounding_box(self.h, obj, out))
         return np.array(out[:])
+
+    # --- graph introspection ---
+    def root(self):
+        return _chk(self.L.rt_scene_root(self.h))
+
+    def describe(self, obj):
+        """(type name, dict) of an object id: material, axis, parameters v, children ids."""
+        d = rt_object_desc()
+        _chk(self.L.rt_object_describe(self.h, obj, C.byref(d)))
+        kids = (C.c_int * max(1, d.n_children))()
+        _chk(self.L.rt_object_children(self.h, obj, d.n_children, kids))
+        return OBJECT_TYPES[d.type], {"material": d.material, "axis": d.axis, "v": list(d.v), "children": list(kids[:d.n_children])}
 
     # --- World::new / commit ---
     def new(self, hitable_list, lights=(), bvh_seed=1):

@@ -51,16 +51,48 @@ def stitch_host(gathered_pixels, layout):
     return g[layout.gather_index_map()]
 
 
+class TileGather:
+    """The one exchange step (the mpsc channel of camera.rs:77,108,115): every rank's padded tile buffer -> rank dst.
+
+    The receive side is ONE rank-major buffer [world, stride*192] allocated once; `dist.gather` writes straight into its
+    rows and `gathered` is handed to the stitch as it is (no per-frame allocation, no torch.cat copy).
+    host_staged=True moves the payload through host memory -- only for rehearsing world > 1 on a box whose ranks share
+    one GPU (RCCL refuses two ranks on one device, so the rehearsal runs over gloo)."""
+
+    def __init__(self, layout, rank, dist, like, dst=0, host_staged=False):
+        import torch
+        self.layout, self.rank, self.dist, self.dst, self.host_staged = layout, rank, dist, dst, host_staged
+        self.gathered = None
+        self.rows = None
+        self._host_in = None
+        n = layout.stride * TILE_PIX * 3
+        if layout.world > 1 and rank == dst:
+            dev = torch.device("cpu") if host_staged else like.device
+            self.gathered = torch.empty((layout.world, n), dtype=like.dtype, device=dev)
+            self.rows = list(self.gathered.unbind(0))
+            self._dev_out = torch.empty((layout.world, n), dtype=like.dtype, device=like.device) if host_staged else None
+        if layout.world > 1 and host_staged:
+            self._host_in = torch.empty(n, dtype=like.dtype, device="cpu")
+
+    def __call__(self, local_tiles):
+        if self.layout.world == 1:
+            return local_tiles
+        src = local_tiles
+        if self.host_staged:
+            self._host_in.copy_(local_tiles)
+            src = self._host_in
+        self.dist.gather(src, self.rows if self.rank == self.dst else None, dst=self.dst)
+        if self.rank != self.dst:
+            return None
+        if self.host_staged:
+            self._dev_out.copy_(self.gathered)
+            return self._dev_out.view(-1)
+        return self.gathered.view(-1)
+
+
 def gather_tiles(local_tiles, layout, rank, dist, dst=0):
-    """The one exchange step: every rank's padded tile buffer -> rank dst (torch tensors, any backend)."""
-    import torch
-    if layout.world == 1:
-        return local_tiles
-    glist = None
-    if rank == dst:
-        glist = [torch.empty_like(local_tiles) for _ in range(layout.world)]
-    dist.gather(local_tiles, glist, dst=dst)
-    return torch.cat(glist) if rank == dst else None
+    """One-shot form of TileGather (allocates its receive buffer per call; loops should keep a TileGather)."""
+    return TileGather(layout, rank, dist, local_tiles, dst)(local_tiles)
 
 
 def render_frame(render_tiles_fn, layout, rank, dist=None, stitch_fn=None, dst=0):

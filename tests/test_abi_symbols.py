@@ -89,3 +89,16 @@ def test_tonemap_host_matches_oracle():
     import rtamd
     x = np.concatenate([np.linspace(-0.5, 1.5, 4001), [np.nan, np.inf, -np.inf, 0.0, 1.0, (254.9999 / 255) ** 2]])
     assert np.array_equal(rtamd.tonemap_u8(x), oracle.tonemap_u8(x))
+
+
+def test_render_sppm_rejects_a_tile_partition():
+    """rt_render_sppm is 'one GPU, whole frame' (rtamd.h): world > 1 is an argument error, checked before any device work."""
+    import ctypes as C
+    import rtamd
+    w, cam = rtamd.select_scene(scene_path("cube.obj"), 1.0, 1)
+    p = rtamd.default_params(width=16, height=16, spp=1, rank=1, world=2)
+    cfg = rtamd.rt_sppm_config()
+    w.L.rt_default_sppm_config(C.byref(cfg))
+    out = np.zeros((16, 16, 3))
+    rc = w.L.rt_render_sppm(w.h, C.byref(cam.c), C.byref(p), C.byref(cfg), out.ctypes.data_as(C.POINTER(C.c_double)), None, None, None)
+    assert rc == -1 and b"world must be 1" in w.L.rt_last_error()

@@ -1,0 +1,95 @@
+"""bench.py's own N-rank launcher (`python bench.py --gpus N` without a rank environment) and its roofline objects.
+
+CPU half: the launcher must fail loudly -- never render on fewer GPUs than asked -- and the rank command must be the
+driver's.  GPU half (one-GPU box): the world-size-2 branch of bench.py rehearsed end to end through the same launcher
+(both ranks on device 0, gather over gloo through host memory; RCCL refuses two ranks on one device)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(args, env_extra=None, timeout=600):
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, BENCH] + args, capture_output=True, text=True, env=env, timeout=timeout)
+
+
+def _no_gpu_here():
+    import rtamd
+    return rtamd.device_count() == 0
+
+
+def test_gpus_2_without_devices_fails_loudly():
+    if not _no_gpu_here():
+        pytest.skip("box has a HIP device")
+    r = _run(["--gpus", "2", "--steps", "1"])
+    assert r.returncode != 0
+    assert "HIP device" in r.stderr and "--gpus 2" in r.stderr
+    assert r.stdout.strip() == ""      # no JSON line pretending to be a result
+
+
+def test_world_size_contradicting_gpus_is_an_error():
+    r = _run(["--gpus", "4", "--steps", "1"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "contradicts WORLD_SIZE=2" in r.stderr
+
+
+def test_rank_command_is_the_drivers():
+    sys.path.insert(0, ROOT)
+    import bench
+    cmd = bench.rank_command(8, ["--gpus", "8", "--steps", "3"], 29511)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert "--nproc-per-node=8" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[cmd.index("--master-port") + 1] == "29511"
+    assert cmd[-5:] == [BENCH, "--gpus", "8", "--steps", "3"][-5:]
+
+
+def test_launcher_source_never_execs_or_touches_the_gpu_before_spawning():
+    src = open(BENCH).read()
+    head = src.split("import torch\n")[0]          # everything that runs before the first torch import in main()
+    assert "launch_ranks(" in head and "os.exec" not in src and "execv" not in src
+    body = src.split("def launch_ranks")[1].split("\ndef ")[0]
+    assert "torch" not in body.replace("torch.distributed.run", "") and "rtamd." not in body
+
+
+def test_roofline_objects_are_physical():
+    sys.path.insert(0, ROOT)
+    import bench
+    model = json.load(open(bench.MODEL))
+    # a launch at exactly the modelled rate: samples/s = SIMDs * clock / (insts/sample * cycles/inst) * valu_busy
+    sps = bench.N_SIMDS * model["clock_ghz"] * 1e9 / (model["valu_insts_per_sample"] * model["valu_issue_cycles_per_inst"]) * 0.9
+    acc = {"kernel_ms": 100.0, "launches": 2, "samples": int(sps * 0.1)}
+    roof, contract, hbm = bench.roofline_objects(acc, 0.1)
+    assert roof["bound"] == "valu_issue" and 0.0 < roof["frac"] <= 1.05 and abs(roof["frac"] - 0.9) < 1e-6
+    assert 0.0 < roof["useful_frac"] < roof["frac"] and 0.0 < roof["lane_utilisation"] <= 1.0
+    assert roof["traffic"] == pytest.approx(model["hbm_bytes_per_sample"] * acc["samples"] / 2)
+    assert contract["bound"] == "hbm" and contract["alg_bytes_per_sample"] > 1000
+    assert hbm is not None and 0.0 < hbm["frac"] < 1.0
+    # a live rate the model cannot explain is reported as such, not as a fraction above 1
+    acc["kernel_ms"] = 10.0
+    roof, _, _ = bench.roofline_objects(acc, 0.01)
+    assert roof["frac"] is None and "stale" in roof["note"]
+
+
+@pytest.mark.gpu
+def test_two_rank_branch_of_bench_rehearsed_on_one_gpu():
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "1", "--width", "96", "--height", "72", "--spp", "8", "--cpu-spp", "0"],
+             {"RTAMD_BENCH_REHEARSE": "1"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and "rehearsal" in out
+    assert out["value"] > 0 and "cpu_baseline" not in out
+    # without the rehearsal switch the same command must refuse to run two ranks on one device
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--width", "96", "--height", "72", "--spp", "8", "--cpu-spp", "0"])
+    import rtamd
+    if rtamd.device_count() < 2:
+        assert r.returncode != 0 and "only 1 HIP device" in r.stderr

@@ -155,3 +155,42 @@ def test_png_writer(tmp_path):
     p = str(tmp_path / "x.png")
     rtamd.write_png(p, img)
     assert np.array_equal(np.asarray(Image.open(p)), img)
+
+
+def test_non_finite_geometry_is_an_argument_error():
+    import rtamd
+    w = rtamd.World()
+    m = w.Lambertian(w.ConstantTexture((1, 1, 1)))
+    nan, inf = float("nan"), float("inf")
+    for make in (lambda: w.Sphere((nan, 0, 0), 1, m), lambda: w.Sphere((0, 0, 0), inf, m),
+                 lambda: w.XZRectangle((0, 0), (1, nan), 2, m), lambda: w.Cube((0, 0, 0), (1, inf, 1), m),
+                 lambda: w.Mesh([[0, 0, 0], [1, 0, 0], [0, nan, 0]], [[0, 0, 1]] * 3, [[0, 1, 2]], m),
+                 lambda: w.Mesh([[0, 0, 0], [1, 0, 0], [0, 1, 0]], [[0, 0, 1], [0, nan, 1], [0, 0, 1]], [[0, 1, 2]], m),
+                 lambda: w.Transform((0, 0, nan), (1, 1, 1), (0, 0, 0), w.Sphere((0, 0, 0), 1, m))):
+        with pytest.raises(rtamd.RtError) as e:
+            make()
+        assert e.value.code == -1 and "finite" in str(e.value)
+
+
+def test_graph_introspection_matches_what_was_built():
+    import rtamd
+    w = rtamd.World()
+    m = w.Metal(w.ConstantTexture((1, 1, 1)), 0.25)
+    s = w.Sphere((1, 2, 3), 0.5, m)
+    r = w.XZRectangle((0, 1), (2, 3), 4, m)
+    c = w.Cube((0, 0, 0), (1, 2, 3), m)
+    lst = w.HitableList([s, r, c])
+    b = w.BVHNode_construct(s, c)
+    assert w.describe(s) == ("Sphere", {"material": m, "axis": 0, "v": [1, 2, 3, 0.5, 0, 0, 0, 0], "children": []})
+    kind, d = w.describe(r)
+    assert kind == "Rect" and d["axis"] == 1 and d["v"][:5] == [0, 1, 2, 3, 4] and d["material"] == m
+    kind, d = w.describe(c)
+    assert kind == "Cube" and len(d["children"]) == 6 and all(w.describe(k)[0] == "Rect" for k in d["children"])
+    assert w.describe(lst) == ("HitableList", {"material": -1, "axis": 0, "v": [0.0] * 8, "children": [s, r, c]})
+    assert w.describe(b)[1]["children"] == [s, c]
+    with pytest.raises(rtamd.RtError):
+        w.root()
+    w.set_root(lst)
+    assert w.root() == lst
+    with pytest.raises(rtamd.RtError):
+        w.describe(10 ** 6)

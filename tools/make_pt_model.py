@@ -1,0 +1,68 @@
+"""Build profiles/pt_kernel_model.json (what bench.py's `roofline` carries over) from rocprofv3 --pmc passes of the bench
+workload.  usage:
+    python tools/make_pt_model.py --samples N --source TEXT --out profiles/pt_kernel_model.json DIR [DIR ...]
+DIRs hold *_counter_collection.csv of separate passes (SQ set, GRBM, FETCH_SIZE, WRITE_SIZE); N = pixel-samples traced by the
+pt_kernel dispatches of ONE pass (every pass runs the same command).
+
+Formulas:
+  valu_insts_per_sample      = SQ_INSTS_VALU / N
+  valu_issue_cycles_per_inst = 4 * SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU      (SQ_ACTIVE_* count quad-cycles)
+  lane_utilisation           = SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU)
+  clock_ghz                  = GRBM_GUI_ACTIVE / 8 / kernel time            (the counter sums the 8 XCDs)
+  valu_busy                  = 4 * SQ_ACTIVE_INST_VALU / (1024 SIMDs * GRBM_GUI_ACTIVE / 8)
+  hbm_bytes_per_sample       = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 / N      (FETCH_SIZE x2: gfx950 correction, MI355X_MICROARCH.md)
+"""
+import argparse
+import csv
+import glob
+import json
+import os
+from collections import defaultdict
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--samples", type=float, required=True)
+ap.add_argument("--source", default="")
+ap.add_argument("--kernel", default="pt_kernel")
+ap.add_argument("--out", required=True)
+ap.add_argument("dirs", nargs="+")
+a = ap.parse_args()
+
+tot = defaultdict(float)      # counter -> sum over pt_kernel dispatches
+dur = defaultdict(float)      # counter -> kernel ns of the pass that counted it
+names = set()
+for d in a.dirs:
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        seen = set()
+        for r in csv.DictReader(open(f)):
+            if a.kernel not in r["Kernel_Name"]:
+                continue
+            names.add(r["Kernel_Name"].split("(")[0])
+            c = r["Counter_Name"]
+            tot[c] += float(r["Counter_Value"])
+            key = (c, r["Dispatch_Id"])
+            if key not in seen:
+                seen.add(key)
+                dur[c] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+
+N = a.samples
+m = {"kernel": sorted(names), "samples_in_pass": N, "source": a.source, "counters": {k: tot[k] for k in sorted(tot)}}
+if "SQ_INSTS_VALU" in tot and "SQ_ACTIVE_INST_VALU" in tot:
+    m["valu_insts_per_sample"] = tot["SQ_INSTS_VALU"] / N
+    m["valu_issue_cycles_per_inst"] = 4.0 * tot["SQ_ACTIVE_INST_VALU"] / tot["SQ_INSTS_VALU"]
+if "SQ_THREAD_CYCLES_VALU" in tot and "SQ_ACTIVE_INST_VALU" in tot:
+    m["lane_utilisation"] = tot["SQ_THREAD_CYCLES_VALU"] / (64.0 * tot["SQ_ACTIVE_INST_VALU"])
+if "GRBM_GUI_ACTIVE" in tot and dur["GRBM_GUI_ACTIVE"] > 0:
+    m["clock_ghz"] = tot["GRBM_GUI_ACTIVE"] / 8.0 / dur["GRBM_GUI_ACTIVE"]
+    m["kernel_ms_in_pass"] = dur["GRBM_GUI_ACTIVE"] / 1e6
+    if "SQ_ACTIVE_INST_VALU" in tot:
+        m["valu_busy"] = 4.0 * tot["SQ_ACTIVE_INST_VALU"] / (1024.0 * tot["GRBM_GUI_ACTIVE"] / 8.0)
+if "SQ_WAVE_CYCLES" in tot:
+    for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
+        if k in tot:
+            m["share_" + k.lower()] = tot[k] / tot["SQ_WAVE_CYCLES"]
+if "FETCH_SIZE" in tot or "WRITE_SIZE" in tot:
+    m["hbm_fetch_bytes"] = 2.0 * 1024.0 * tot.get("FETCH_SIZE", 0.0)
+    m["hbm_write_bytes"] = 1024.0 * tot.get("WRITE_SIZE", 0.0)
+    m["hbm_bytes_per_sample"] = (m["hbm_fetch_bytes"] + m["hbm_write_bytes"]) / N
+json.dump(m, open(a.out, "w"), indent=1)
+print(json.dumps({k: v for k, v in m.items() if k != "counters"}, indent=1))
