@@ -75,8 +75,8 @@ typedef struct rt_params {
     int32_t rank;        /* image-tile partition: this call renders tiles t with t % world == rank */
     int32_t world;       /* 1 = whole image */
     int32_t spp_chunk;   /* samples per pixel per kernel launch; 0 = auto */
-    int32_t kernel;      /* 0 = auto; 1 = reference-order stackless traversal; 2 = SAH-BVH2 accel traversal;
-                            (default when an accel exists); 3 = kernel 2 with an early-restart schedule (diagnostic).
+    int32_t kernel;      /* 0 = auto; 1 = reference-order stackless traversal; 2 = SAH-BVH2 accel traversal (auto when the
+                            scene's tables fit LDS); 4 = 8-wide quantised BVH traversal (auto for larger scenes).
                             All give bit-identical images (same f64 primitive tests, same tie rule). */
     int32_t device;      /* HIP device ordinal; -1 = current */
     int32_t integrator;  /* 0 = sample_ray as the reference structures it (BSDF sampling only; default);
@@ -105,6 +105,22 @@ int rt_abi_version(void);
 const char* rt_last_error(void);
 void rt_default_params(rt_params* p);           /* the reference's constants, see rt_params */
 int rt_device_count(void);                      /* HIP devices visible; 0 without a GPU */
+
+/* Measurement and test hooks.  The library reads NO environment variable: everything that changes how (never what) it
+ * renders is set here, process-wide, before the calls it should affect.  0 / negative = automatic (the default). */
+typedef struct rt_tuning {
+    int32_t no_lds;                /* 1: keep scene tables in global memory even when they fit LDS (A/B runs)            */
+    int32_t top_nodes;             /* >= 0: cap on the BVH nodes cached in LDS when the scene lives in L2/HBM; -1 auto  */
+    int32_t sub_spp;               /* > 0: sample indices per work unit (a wave's pool = 64 px x sub_spp); 0 auto       */
+    int32_t sample_budget_mb;      /* > 0: budget of the per-launch sample buffer in MiB; 0 auto                        */
+    int32_t workspace_limit_mb;    /* > 0: pretend the device cannot spare a larger sample buffer (launches are halved) */
+    int32_t max_leaf;              /* 1..4: accel builder, items per leaf; 0 auto (read at rt_scene_commit)             */
+    int32_t sppm_photon_capacity;  /* > 0: initial photon-buffer capacity (forces the grow-and-retry path); 0 auto      */
+    int32_t sppm_knn_candidates;   /* >= 0: k-nearest candidates kept in LDS (0 forces the out-of-LDS selection); -1 auto */
+    double sah_box_cost;           /* > 0: accel builder, SAH cost of a box-pair test relative to 2.0 per primitive; 0 auto */
+} rt_tuning;
+void rt_tuning_default(rt_tuning* t);
+int rt_tuning_set(const rt_tuning* t);
 
 /* ---- scene graph builders (one per reference constructor) ---------------- */
 int rt_scene_create(rt_scene** out);
@@ -193,7 +209,8 @@ typedef struct rt_scene_info {
     int32_t n_nodes, n_boxes, n_spheres, n_rects, n_tris, n_xforms, n_materials, n_textures;
     int32_t n_verts, max_depth, committed, reserved;
     uint64_t bytes;
-    int32_t accel_ok, accel_nodes, accel_items, accel_instances, accel_stack, reserved2;
+    int32_t accel_ok, accel_nodes, accel_items, accel_instances, accel_stack;
+    int32_t accel8_nodes;   /* Node8 count of the wide accel (kernel 4), 0 if none was built */
 } rt_scene_info;
 int rt_scene_info_get(const rt_scene* s, rt_scene_info* out);
 

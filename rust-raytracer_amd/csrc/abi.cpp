@@ -1,6 +1,7 @@
 // extern "C" entry points of librtamd.so (declared in include/rtamd.h).
 // Every function converts C++ exceptions into rt_status codes; nothing unwinds
 // across the boundary.
+#include <algorithm>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -14,6 +15,10 @@
 using namespace rtamd;
 
 static thread_local std::string g_err;
+static Tuning g_tuning;
+namespace rtamd {
+const Tuning& tuning() { return g_tuning; }
+}  // namespace rtamd
 
 rt_scene::~rt_scene() { free_device_copies(*this); }
 
@@ -65,6 +70,31 @@ void rt_default_params(rt_params* p) {
     p->integrator = 0;
 }
 int rt_device_count(void) { return device_count(); }
+void rt_tuning_default(rt_tuning* t) {
+    if (!t) return;
+    std::memset(t, 0, sizeof(*t));
+    t->top_nodes = -1;
+    t->sppm_knn_candidates = -1;
+}
+int rt_tuning_set(const rt_tuning* t) {
+    return guard([&] {
+        REQUIRE(t, "null argument");
+        REQUIRE(t->max_leaf >= 0 && t->max_leaf <= 4, "max_leaf must be 0 (auto) or 1..4");
+        REQUIRE(t->sah_box_cost >= 0. && t->sah_box_cost < 1e6, "sah_box_cost out of range");
+        Tuning n;
+        n.no_lds = t->no_lds != 0;
+        n.n_top = t->top_nodes < 0 ? -1 : t->top_nodes;
+        n.sub_spp = std::max(0, t->sub_spp);
+        n.sample_budget_mb = std::max(0, t->sample_budget_mb);
+        n.ws_limit_mb = std::max(0, t->workspace_limit_mb);
+        n.max_leaf = t->max_leaf;
+        n.sppm_cap = std::max(0, t->sppm_photon_capacity);
+        n.knn_cand = t->sppm_knn_candidates < 0 ? -1 : t->sppm_knn_candidates;
+        n.c_box = t->sah_box_cost;
+        g_tuning = n;
+        return (int)RT_OK;
+    });
+}
 
 int rt_scene_create(rt_scene** out) {
     return guard([&] {
@@ -374,7 +404,7 @@ static RenderPlan make_plan(const rt_params* p) {
     REQUIRE(p->spp > 0, "spp must be positive");
     REQUIRE(p->max_depth >= 0, "max_depth must be >= 0");
     REQUIRE(p->world >= 1 && p->rank >= 0 && p->rank < p->world, "bad rank/world");
-    REQUIRE(p->kernel >= 0 && p->kernel <= 3, "unknown kernel id");
+    REQUIRE(p->kernel == 0 || p->kernel == 1 || p->kernel == 2 || p->kernel == 4, "unknown kernel id (0 auto, 1, 2, 4)");
     REQUIRE(p->integrator >= 0 && p->integrator <= 2, "unknown integrator id");
     RenderPlan pl;
     pl.width = p->width; pl.height = p->height; pl.spp = p->spp; pl.max_depth = p->max_depth;
@@ -394,7 +424,7 @@ static RenderPlan make_plan(const rt_params* p) {
     if (chunk <= 0) {
         int64_t per_spp = std::max<int64_t>(1, pl.tiles_owned) * TILE_PIX * 3 * 8;
         int64_t budget = int64_t(12) << 30;
-        if (const char* e = getenv("RTAMD_SAMPLE_BUDGET_MB")) budget = std::max<int64_t>(1, atoll(e)) << 20;  // tuning knob (A/B runs)
+        if (tuning().sample_budget_mb > 0) budget = (int64_t)tuning().sample_budget_mb << 20;  // rt_tuning (A/B runs)
         int64_t c = std::max<int64_t>(1, std::min<int64_t>(budget / per_spp, 512));
         int64_t launches = (std::max(1, p->spp) + c - 1) / c;
         chunk = (int)((std::max(1, p->spp) + launches - 1) / launches);
@@ -413,7 +443,7 @@ static RenderPlan make_plan(const rt_params* p) {
     int64_t subs = std::max<int64_t>(1, want_units / std::max<int64_t>(1, pl.tiles_owned));
     int sub = (int)((chunk + subs - 1) / subs);
     pl.sub_spp = std::max(std::min(chunk, 4), std::min(sub, 8));
-    if (const char* e = getenv("RTAMD_SUB_SPP")) pl.sub_spp = std::max(1, std::min(chunk, atoi(e)));  // tuning knob (A/B runs)
+    if (tuning().sub_spp > 0) pl.sub_spp = std::max(1, std::min(chunk, tuning().sub_spp));  // rt_tuning (A/B runs)
     return pl;
 }
 
@@ -633,7 +663,7 @@ int rt_debug_math_device(int op, size_t n, const double* a_host, const double* b
 }
 int rt_debug_hit_device(const rt_scene* s, int kernel, size_t n, const double* rays_host, double t_min, double t_max, double* out_host) {
     return guard([&] {
-        REQUIRE(s && n > 0 && rays_host && out_host && (kernel == 1 || kernel == 2), "bad argument");
+        REQUIRE(s && n > 0 && rays_host && out_host && (kernel == 1 || kernel == 2 || kernel == 4), "bad argument");
         if (device_count() < 1) throw RtError(RT_ERR_NO_DEVICE, "no HIP device");
         debug_hit_device(*s, kernel, n, rays_host, t_min, t_max, out_host);
         return (int)RT_OK;

@@ -136,6 +136,12 @@ struct Acc {  // typed views into the blob (LDS or global; the address space is 
     uint32_t root2;
     const uint2* lights;     // {NK_SPHERE | NK_RECT_XZ, payload}
     uint32_t n_lights;
+    // wide accel (kernel 4)
+    const uint4* n8;         // 5 x uint4 per Node8
+    const uint4* n8_top;     // LDS copy of the first n8_top_count Node8 when the scene itself is not in LDS
+    uint32_t n8_top_count;
+    const uint2* inst8;      // {xform, root Node8}
+    uint32_t root8;
 };
 template <class P>
 DEV Acc make_acc(P hot, const char* gbase, const FlatView& v) {  // hot: LDS copy or the global blob; cold part always global
@@ -164,6 +170,11 @@ DEV Acc make_acc(P hot, const char* gbase, const FlatView& v) {  // hot: LDS cop
     a.root2 = v.root2;
     a.lights = (const uint2*)(gbase + v.off_lights);
     a.n_lights = v.n_lights;
+    a.n8 = (const uint4*)(hot + v.off_n8);
+    a.n8_top = nullptr;
+    a.n8_top_count = 0;
+    a.inst8 = (const uint2*)(hot + v.off_inst8);
+    a.root8 = v.root8;
     return a;
 }
 
@@ -179,9 +190,8 @@ struct RenderK {
     int sub_spp, subs_per_tile, n_units;
     int tiles_x, rank, world;
     int chunk_spp;  // sample-buffer stride
-    int restart_th; // kernel 3: lanes that must have finished a segment before the wave shades
     const double* sppm_est;  // INTEG 2: per pixel {caustic estimate[3], global estimate[3]}, index y*width + x
-    int n2_top;              // kernel 2 with the scene in L2/HBM: number of (depth-sorted) Node2 cached in LDS
+    int n_top;               // kernels 2 / 4 with the scene in L2/HBM: number of (depth-sorted) Node2 / Node8 cached in LDS
 };
 
 // ------------------------------------------------------ intersection ------
@@ -503,6 +513,178 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
     return h;
 }
 
+// ---------------------------------------------------------------- kernel 4 traversal ----
+// Closest hit through the wide accel (common/flat.h "Wide accel"): 8-ary nodes with 8-bit quantised child planes.
+// A child plane is decoded with ONE fma, lo = fl(q * s + o): q <= 255 and s = 2^e make the product exact, and the host
+// builder has checked with this very fma that lo <= (exact box min - pad) and hi >= (exact box max + pad).  The decoded
+// box therefore satisfies box32's hypothesis exactly as a stored Node2 box does, and the proof above box32 applies verbatim.
+// Everything else -- f64 primitive tests, inclusive ranges, the tie rule via `order` -- is traverse2's.
+// Per-lane stack of 64-bit entries in LDS: node groups {first inner child | remaining children in visit order, imask},
+// item groups {item_base, item mask} (only when an instance is entered with items of its node still pending) and the
+// restore-world marker.  "while-while": lanes visit nodes until each holds an item group, then all test items.
+DEV uint32_t ray_octant(const Ray32& r) { return (r.ix < 0.f ? 1u : 0u) | (r.iy < 0.f ? 2u : 0u) | (r.iz < 0.f ? 4u : 0u); }
+// hit-child mask from slot space to visit-order space: bit k of the result = bit (k ^ oct) of m (three conditional swaps)
+DEV uint32_t xor_permute8(uint32_t m, uint32_t oct) {
+    uint32_t t;
+    t = (m ^ (m >> 1)) & ((oct & 1u) ? 0x55u : 0u); m ^= t | (t << 1);
+    t = (m ^ (m >> 2)) & ((oct & 2u) ? 0x33u : 0u); m ^= t | (t << 2);
+    t = (m ^ (m >> 4)) & ((oct & 4u) ? 0x0Fu : 0u); m ^= t | (t << 4);
+    return m;
+}
+DEV float ubyte_f32(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xffu); }  // v_cvt_f32_ubyteK
+DEV D3 rcp3(D3 d) { return mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z); }
+
+template <bool GENERAL>
+DEV Hit traverse8(const Acc& A, uint2* stk, const int stride, D3 wo, D3 wd, double t_min, double t_max) {
+    D3 o = wo, d = wd;
+    double a = sqlen(d);
+    Hit h;
+    h.t = t_max;
+    h.node = -1;
+    h.xf = -1;
+    h.kp = 0;
+    int cur_xf = -1;
+    Ray32 r = make_ray32(o, rcp3(d), t_min, t_max);
+    uint32_t oct = ray_octant(r);
+    int sp = 0;                        // stack offset in entries (a multiple of stride)
+    uint32_t cur = A.root8;            // Node8 to visit, or NODE8_NONE
+    uint32_t ibase = 0, imask = 0;     // pending item group
+    for (;;) {
+        // ---- nodes: until this lane holds an item group or has nothing left ----
+        for (;;) {
+            if (cur == NODE8_NONE) {
+                if (imask != 0u || sp == 0) break;
+                sp -= stride;
+                const uint2 e = stk[sp];
+                const uint32_t tag = e.x >> 30;
+                if (tag == ST8_NODES) {  // next child of a node group, in visit order
+                    uint32_t km = e.y & 0xffu;
+                    const uint32_t im = (e.y >> 8) & 0xffu;
+                    const uint32_t slot = (uint32_t)(__ffs((int)km) - 1) ^ oct;
+                    km &= km - 1u;
+                    cur = (e.x & 0x3fffffffu) + (uint32_t)__popc(im & ((1u << slot) - 1u));
+                    if (km != 0u) {
+                        stk[sp] = make_uint2(e.x, (e.y & ~0xffu) | km);
+                        sp += stride;
+                    }
+                } else if (tag == ST8_ITEMS) {
+                    ibase = e.x & 0x3fffffffu;
+                    imask = e.y;
+                    break;
+                } else {  // ST8_RESTORE: leave the Transform
+                    o = wo;
+                    d = wd;
+                    a = sqlen(d);
+                    cur_xf = -1;
+                    r = make_ray32(o, rcp3(d), t_min, h.t);
+                    oct = ray_octant(r);
+                    continue;
+                }
+            }
+            uint4 w0, w1, w2, w3, w4;
+            if (cur < A.n8_top_count) {  // the shallowest levels are cached in LDS when the scene lives in L2/HBM
+                const uint4* p = A.n8_top + NODE8_U4 * cur;
+                w0 = p[0]; w1 = p[1]; w2 = p[2]; w3 = p[3]; w4 = p[4];
+            } else {
+                const uint4* p = A.n8 + NODE8_U4 * cur;
+                w0 = p[0]; w1 = p[1]; w2 = p[2]; w3 = p[3]; w4 = p[4];
+            }
+            const float ox = __uint_as_float(w0.x), oy = __uint_as_float(w0.y), oz = __uint_as_float(w0.z);
+            const float sx = __uint_as_float((w0.w & 0xffu) << 23), sy = __uint_as_float(((w0.w >> 8) & 0xffu) << 23),
+                        sz = __uint_as_float(((w0.w >> 16) & 0xffu) << 23);
+            uint32_t hits = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int k = i & 3;
+                const uint32_t qlx = (i < 4) ? w2.x : w2.y, qly = (i < 4) ? w2.z : w2.w, qlz = (i < 4) ? w3.x : w3.y;
+                const uint32_t qhx = (i < 4) ? w3.z : w3.w, qhy = (i < 4) ? w4.x : w4.y, qhz = (i < 4) ? w4.z : w4.w;
+                const float lox = __builtin_fmaf(ubyte_f32(qlx, k), sx, ox), loy = __builtin_fmaf(ubyte_f32(qly, k), sy, oy),
+                            loz = __builtin_fmaf(ubyte_f32(qlz, k), sz, oz);
+                const float hix = __builtin_fmaf(ubyte_f32(qhx, k), sx, ox), hiy = __builtin_fmaf(ubyte_f32(qhy, k), sy, oy),
+                            hiz = __builtin_fmaf(ubyte_f32(qhz, k), sz, oz);
+                float entry;
+                if (box32(lox, loy, loz, hix, hiy, hiz, r, entry)) hits |= 1u << i;
+            }
+            const uint32_t im = w0.w >> 24, lm = w1.x >> 24, cb = w1.x & 0xffffffu;
+            uint32_t lh = hits & lm;
+            uint32_t m = 0;
+            while (lh != 0u) {  // items of the leaf children that were hit
+                const uint32_t sl = (uint32_t)(__ffs((int)lh) - 1);
+                lh &= lh - 1u;
+                const uint32_t mt = (((sl < 4u) ? w1.z : w1.w) >> (8u * (sl & 3u))) & 0xffu;
+                m |= ((1u << (mt >> 5)) - 1u) << (mt & 31u);
+            }
+            uint32_t km = xor_permute8(hits & im, oct);
+            cur = NODE8_NONE;
+            if (m != 0u) {  // test this node's items first (they shrink the range), then its inner children
+                if (km != 0u) {
+                    stk[sp] = make_uint2(cb | (ST8_NODES << 30), km | (im << 8));
+                    sp += stride;
+                }
+                ibase = w1.y;
+                imask = m;
+                break;
+            }
+            if (km != 0u) {
+                const uint32_t slot = (uint32_t)(__ffs((int)km) - 1) ^ oct;
+                km &= km - 1u;
+                cur = cb + (uint32_t)__popc(im & ((1u << slot) - 1u));
+                if (km != 0u) {
+                    stk[sp] = make_uint2(cb | (ST8_NODES << 30), km | (im << 8));
+                    sp += stride;
+                }
+            }
+        }
+        if (imask == 0u && cur == NODE8_NONE) break;  // stack empty
+        // ---- items: the reference's f64 primitive tests ----
+        while (imask != 0u) {
+            const uint32_t idx = ibase + (uint32_t)(__ffs((int)imask) - 1);
+            imask &= imask - 1u;
+            const uint2 it = A.items2[idx];
+            const uint32_t kind = it.x & NK_MASK, pl = it.x >> NK_BITS;
+            double t = 0.;
+            bool got = false;
+            if (kind == NK_SPHERE) {
+                got = sphere_hit(A.spheres + 2 * pl, o, d, a, t_min, h.t, t);
+            } else if (GENERAL) {
+                if (kind == NK_RECT_YZ || kind == NK_RECT_XZ || kind == NK_RECT_XY) {
+                    got = rect_hit(A.rects + 3 * pl, (int)kind - (int)NK_RECT_YZ, o, d, t_min, h.t, t);
+                } else if (kind == NK_TRI) {
+                    double b1, b2;
+                    got = tri_hit(A.tripre2 + 5 * idx, o, d, t_min, h.t, t, b1, b2);
+                } else {  // NK_INSTANCE: Transform::hit, transform.rs:153-156 ; the node's remaining items wait on the stack
+                    if (imask != 0u) {
+                        stk[sp] = make_uint2(ibase | (ST8_ITEMS << 30), imask);
+                        sp += stride;
+                        imask = 0u;
+                    }
+                    stk[sp] = make_uint2(ST8_RESTORE << 30, 0u);
+                    sp += stride;
+                    const uint2 in = A.inst8[pl];
+                    const double* Minv = A.xforms + 32 * in.x;
+                    o = xf_point(Minv, wo);
+                    d = xf_dir(Minv, wd);
+                    a = sqlen(d);
+                    cur_xf = (int)in.x;
+                    r = make_ray32(o, rcp3(d), t_min, h.t);
+                    oct = ray_octant(r);
+                    cur = in.y;
+                    break;
+                }
+            }
+            // accepted candidates satisfy t <= h.t; an exact tie goes to the later one in reference order
+            if (got && (t < h.t || (int)it.y > h.node || !(t == t))) {
+                h.t = t;
+                h.node = (int)it.y;
+                h.xf = cur_xf;
+                h.kp = it.x;
+                r.best = ray32_best(t);
+            }
+        }
+    }
+    return h;
+}
+
 struct Rec {  // HitRecord, hit.rs:7-14
     D3 p, normal;
     bool front_face;
@@ -748,31 +930,49 @@ template <bool LDS, bool GENERAL, int ACCEL, int INTEG>
 __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, RenderK rk, double* __restrict__ samples,
                                                       unsigned int* __restrict__ counter, int* __restrict__ err) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // LDS map: [staged scene tables (LDS variants)] [kernel 2: per-lane traversal stacks, stack2 x blockDim words]
-    const uint32_t st_begin = (ACCEL == 2) ? sv.stage2_begin : 0u;
-    const uint32_t st_end = (ACCEL == 2) ? sv.stage2_end : sv.stage_bytes;
+    // LDS map: [staged scene tables (LDS variants) | top-of-BVH node cache (scene in L2/HBM)] [kernels 2 / 4: per-lane
+    // traversal stacks, stack2 x blockDim 32-bit words / stack8 x blockDim 64-bit entries]
+    const uint32_t st_begin = (ACCEL >= 2) ? sv.stage2_begin : 0u;
+    const uint32_t st_end = (ACCEL == 4) ? sv.stage8_mid : (ACCEL == 2) ? sv.stage2_end : sv.stage_bytes;
+    uint32_t staged = 0;  // bytes of LDS in front of the stacks
     Acc A;
     if (LDS) {
         const uint4* src = (const uint4*)(sv.base + st_begin);
         uint4* dst = (uint4*)smem;
         for (uint32_t i = threadIdx.x; i < (st_end - st_begin) / 16; i += blockDim.x) dst[i] = src[i];
-        __syncthreads();
+        staged = st_end - st_begin;
         A = make_acc(smem - st_begin, sv.base, sv);
+        if (ACCEL == 4) {  // second range: the Node8 array (the Node2 array lies between the two in the blob and is not needed)
+            const uint4* src8 = (const uint4*)(sv.base + sv.off_n8);
+            uint4* dst8 = (uint4*)(smem + staged);
+            for (uint32_t i = threadIdx.x; i < sv.n_nodes8 * NODE8_U4; i += blockDim.x) dst8[i] = src8[i];
+            A.n8 = (const uint4*)(smem + staged);
+            staged += sv.n_nodes8 * (uint32_t)sizeof(Node8);
+        }
+        __syncthreads();
     } else {
         A = make_acc(sv.base, sv.base, sv);
+        if (ACCEL == 2 && rk.n_top > 0) {  // scene in L2/HBM: the shallowest levels of every BVH (depth-sorted array) in LDS
+            const uint4* src = (const uint4*)(sv.base + sv.off_n2);
+            uint4* dst = (uint4*)smem;
+            for (uint32_t i = threadIdx.x; i < (uint32_t)rk.n_top * NODE2_F4; i += blockDim.x) dst[i] = src[i];
+            __syncthreads();
+            A.n2_top = (const float4*)smem;
+            A.n2_top_count = (uint32_t)rk.n_top;
+            staged = (uint32_t)rk.n_top * (uint32_t)sizeof(Node2);
+        }
+        if (ACCEL == 4 && rk.n_top > 0) {
+            const uint4* src = (const uint4*)(sv.base + sv.off_n8);
+            uint4* dst = (uint4*)smem;
+            for (uint32_t i = threadIdx.x; i < (uint32_t)rk.n_top * NODE8_U4; i += blockDim.x) dst[i] = src[i];
+            __syncthreads();
+            A.n8_top = (const uint4*)smem;
+            A.n8_top_count = (uint32_t)rk.n_top;
+            staged = (uint32_t)rk.n_top * (uint32_t)sizeof(Node8);
+        }
     }
-    // LDS map (non-LDS scene, kernel 2): [top-of-BVH Node2 cache, rk.n2_top nodes][stacks]
-    uint32_t top_bytes = 0;
-    if (!LDS && ACCEL == 2 && rk.n2_top > 0) {
-        const uint4* src = (const uint4*)(sv.base + sv.off_n2);
-        uint4* dst = (uint4*)smem;
-        for (uint32_t i = threadIdx.x; i < (uint32_t)rk.n2_top * NODE2_F4; i += blockDim.x) dst[i] = src[i];
-        __syncthreads();
-        A.n2_top = (const float4*)smem;
-        A.n2_top_count = (uint32_t)rk.n2_top;
-        top_bytes = (uint32_t)rk.n2_top * (uint32_t)sizeof(Node2);
-    }
-    uint32_t* stk = (uint32_t*)(smem + (LDS ? (st_end - st_begin) : top_bytes)) + threadIdx.x;
+    uint32_t* stk = (uint32_t*)(smem + staged) + threadIdx.x;
+    uint2* stk8 = (uint2*)(smem + staged) + threadIdx.x;
     const int stk_stride = (int)blockDim.x;
     const int lane = threadIdx.x & 63;
     const uint64_t lanemask_lt = (1ull << lane) - 1ull;
@@ -847,8 +1047,10 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
             }
             // ---- one path segment: sample_ray's loop body, photon_mapper.rs:335-362 ----
             if (alive) {
-                Hit h = (ACCEL == 2) ? traverse2<GENERAL>(A, stk, stk_stride, o, d, rk.t_min, INFINITY)
-                                     : traverse<GENERAL>(A, o, d, rk.t_min, INFINITY);
+                Hit h;
+                if (ACCEL == 4) h = traverse8<GENERAL>(A, stk8, stk_stride, o, d, rk.t_min, INFINITY);
+                else if (ACCEL == 2) h = traverse2<GENERAL>(A, stk, stk_stride, o, d, rk.t_min, INFINITY);
+                else h = traverse<GENERAL>(A, o, d, rk.t_min, INFINITY);
                 bool done = true;
                 if (h.node >= 0 && depth > 0) {  // Q12: depth test after the hit, before emission
                     depth -= 1;
@@ -888,250 +1090,6 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
     }
 }
 
-
-// ------------------------------------------------------- pt_kernel_sm (kernel 3) ---
-// EXPERIMENTAL / DIAGNOSTIC (not the default): kernel 2's work with an EARLY-RESTART schedule and optional
-// per-phase schedule statistics (RTAMD_SM_STATS=1).  Measured on scene_500: restarting early does not pay
-// (threshold 24: -20 %, 56: +2 %), because shading then runs with few lanes; kept for its instrumentation.
-// Kernel 2 shades only when every lane of the wave has finished its traversal, so a lane whose ray left the
-// scene after 3 nodes idles while a neighbour visits 40 (measured: 33 % VALU lane utilisation).  Here the
-// traversal state (cur, stack pointer, ray, best hit) persists across rounds: the wave leaves the traversal
-// loop as soon as SM_RESTART lanes (or all live ones) are done, shades / regenerates just those, and they
-// re-enter traversal at the root while the others resume where they stopped.
-// Scheduling changes nothing a lane computes: results stay bit-identical to kernels 1 and 2.
-#define SM_RESTART 56
-
-template <bool LDS, bool GENERAL>
-__global__ void __launch_bounds__(PT_BLOCK) pt_kernel_sm(FlatView sv, const CamK* __restrict__ camp, RenderK rk, double* __restrict__ samples,
-                                                         unsigned int* __restrict__ counter, int* __restrict__ err,
-                                                         unsigned long long* __restrict__ stats) {
-    // optional schedule statistics (RTAMD_SM_STATS=1): per phase, {wave-level executions, lane participations}
-    unsigned long long st_w[4] = {0, 0, 0, 0}, st_l[4] = {0, 0, 0, 0};
-#define SM_STAT(ph, active)                                         \
-    if (stats) {                                                    \
-        st_w[ph] += 1;                                              \
-        st_l[ph] += (unsigned long long)__popcll(__ballot(active)); \
-    }
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const uint32_t st_begin = sv.stage2_begin, st_end = sv.stage2_end;
-    Acc A;
-    if (LDS) {
-        const uint4* src = (const uint4*)(sv.base + st_begin);
-        uint4* dst = (uint4*)smem;
-        for (uint32_t i = threadIdx.x; i < (st_end - st_begin) / 16; i += blockDim.x) dst[i] = src[i];
-        __syncthreads();
-        A = make_acc(smem - st_begin, sv.base, sv);
-    } else {
-        A = make_acc(sv.base, sv.base, sv);
-    }
-    uint32_t* stk = (uint32_t*)(smem + (LDS ? (st_end - st_begin) : 0u)) + threadIdx.x;
-    const int stride = (int)blockDim.x;
-    const int lane = threadIdx.x & 63;
-    const uint64_t lanemask_lt = (1ull << lane) - 1ull;
-    const double t_min = rk.t_min;
-
-    for (;;) {
-        unsigned int unit = 0;
-        if (lane == 0) unit = atomicAdd(counter, 1u);
-        unit = __builtin_amdgcn_readfirstlane(unit);
-        if (unit >= (unsigned)rk.n_units) break;
-        const int lt = (int)(unit / (unsigned)rk.subs_per_tile);
-        const int sub_i = (int)(unit - (unsigned)lt * (unsigned)rk.subs_per_tile);
-        const int tile = lt * rk.world + rk.rank;
-        const int tx = tile % rk.tiles_x, ty = tile / rk.tiles_x;
-        const int s0 = rk.s_begin + sub_i * rk.sub_spp;
-        const int s1 = min(s0 + rk.sub_spp, rk.s_end);
-        const int pool = (s1 - s0) * TILE_PIX;
-        int next = 0;
-
-        bool alive = false;
-        D3 wo = mk(0, 0, 0), wd = mk(0, 0, 1);  // world-space ray of the current segment
-        D3 o = wo, d = wd;                        // GENERAL: ray in the space being traversed (object space inside a Transform)
-        double a = 1.;
-        Ray32 r = make_ray32(wo, mk(1, 1, 1), t_min, INFINITY);
-        Hit h;
-        h.t = INFINITY; h.node = -1; h.xf = -1; h.kp = 0;
-        uint32_t cur = REF_DONE;
-        int sp = 0, cur_xf = -1;
-        D3 beta = mk(1, 1, 1), L = mk(0, 0, 0);
-        int depth = 0;
-        size_t out_idx = 0;
-        Rng rng;
-        rng.s = 0;
-
-        for (;;) {
-            // ---- regeneration: dead lanes pull the next (pixel, sample) of the pool (camera.rs:97-99, :57-64) ----
-            const uint64_t dead = __ballot(!alive);
-            if (dead != 0ull && next < pool) {
-                const int k = next + __popcll(dead & lanemask_lt);
-                next = min(next + (int)__popcll(dead), pool);
-                SM_STAT(0, !alive && k < pool);
-                if (!alive && k < pool) {
-                    const int pix = k & (TILE_PIX - 1), s = s0 + (k >> 6);
-                    const int x = tx * TILE_W + (pix & (TILE_W - 1)), y = ty * TILE_H + (pix >> 3);
-                    if (x < rk.width && y < rk.height) {
-                        const CamK cam = *camp;
-                        rng.seed_stream(rk.seed, (uint64_t)y * (uint64_t)rk.width + (uint64_t)x, (uint64_t)s);
-                        double u = ((double)x + rng.gen_f64()) / (double)(rk.width - 1);
-                        double v = ((double)y + rng.gen_f64()) / (double)(rk.height - 1);
-                        double st = 1.0 - v;
-                        D3 rd = muls(random_in_unit_disk(rng), cam.lens_radius);
-                        D3 offset = add(muls(cam.u, rd.x), muls(cam.v, rd.y));
-                        wo = add(cam.origin, offset);
-                        wd = sub(sub(add(add(cam.llc, muls(cam.horizontal, u)), muls(cam.vertical, st)), cam.origin), offset);
-                        beta = mk(1., 1., 1.);
-                        L = mk(0., 0., 0.);
-                        depth = rk.max_depth;
-                        out_idx = ((size_t)((size_t)lt * rk.chunk_spp + (s - rk.s_begin)) * TILE_PIX + pix) * 3;
-                        alive = true;
-                        // begin the first segment: World::hit(ray, t_min, +inf)
-                        if (GENERAL) { o = wo; d = wd; }
-                        a = sqlen(wd);
-                        r = make_ray32(wo, mk(1.0 / wd.x, 1.0 / wd.y, 1.0 / wd.z), t_min, INFINITY);
-                        h.t = INFINITY; h.node = -1; h.xf = -1; h.kp = 0;
-                        cur = A.root2;
-                        sp = 0;
-                        cur_xf = -1;
-                    }
-                }
-            }
-            const int n_alive = __popcll(__ballot(alive));
-            if (n_alive == 0) {
-                if (next >= pool) break;
-                continue;
-            }
-            const int want_done = min(rk.restart_th, n_alive);
-
-            // ---- traversal, resumable: runs until `want_done` live lanes have finished their segment ----
-            for (;;) {
-                while (alive && (cur >> REF_TAG_SHIFT) == 0u) {  // inner node: both children, f32 conservative
-                    SM_STAT(1, true);
-                    const float4* p = A.n2 + NODE2_F4 * cur;
-                    float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
-                    float e0, e1;
-                    bool h0 = box32(q0.x, q0.z, q1.x, q1.z, q2.x, q2.z, r, e0);
-                    bool h1 = box32(q0.y, q0.w, q1.y, q1.w, q2.y, q2.w, r, e1);
-                    uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
-                    if (h0 && h1) {
-                        bool swap = e1 < e0;
-                        stk[sp * stride] = swap ? c0 : c1;
-                        sp++;
-                        cur = swap ? c1 : c0;
-                    } else if (h0 || h1) {
-                        cur = h0 ? c0 : c1;
-                    } else if (sp > 0) {
-                        sp--;
-                        cur = stk[sp * stride];
-                    } else {
-                        cur = REF_DONE;
-                    }
-                }
-                if ((int)__popcll(__ballot(alive && cur == REF_DONE)) >= want_done) break;
-                SM_STAT(2, alive && cur != REF_DONE);
-                if (alive && cur != REF_DONE) {
-                    const D3 ro = GENERAL ? o : wo, rdir = GENERAL ? d : wd;
-                    bool entered = false;
-                    if ((cur >> REF_TAG_SHIFT) == 1u) {  // leaf: the reference's f64 primitive tests
-                        uint32_t first = cur & REF_LEAF_FIRST_MASK, cnt = ((cur >> REF_LEAF_COUNT_SHIFT) & 7u) + 1u;
-                        uint32_t enter = REF_DONE;
-                        for (uint32_t i = 0; i < cnt; i++) {
-                            uint2 it = A.items2[first + i];
-                            uint32_t kind = it.x & NK_MASK, pl = it.x >> NK_BITS;
-                            double t = 0.;
-                            bool got = false;
-                            if (kind == NK_SPHERE) {
-                                got = sphere_hit(A.spheres + 2 * pl, ro, rdir, a, t_min, h.t, t);
-                            } else if (GENERAL) {
-                                if (kind == NK_RECT_YZ || kind == NK_RECT_XZ || kind == NK_RECT_XY) {
-                                    got = rect_hit(A.rects + 3 * pl, (int)kind - (int)NK_RECT_YZ, ro, rdir, t_min, h.t, t);
-                                } else if (kind == NK_TRI) {
-                                    double b1, b2;
-                                    got = tri_hit(A.tripre2 + 5 * (first + i), ro, rdir, t_min, h.t, t, b1, b2);
-                                } else {
-                                    enter = pl;
-                                }
-                            }
-                            if (got && (t < h.t || (int)it.y > h.node || !(t == t))) {
-                                h.t = t;
-                                h.node = (int)it.y;
-                                h.xf = cur_xf;
-                                h.kp = it.x;
-                                r.best = ray32_best(t);
-                            }
-                        }
-                        if (GENERAL && enter != REF_DONE) {  // Transform::hit entry, transform.rs:153-156
-                            uint2 in = A.inst2[enter];
-                            const double* Minv = A.xforms + 32 * in.x;
-                            o = xf_point(Minv, wo);
-                            d = xf_dir(Minv, wd);
-                            a = sqlen(d);
-                            cur_xf = (int)in.x;
-                            r = make_ray32(o, mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z), t_min, h.t);
-                            stk[sp * stride] = REF_RESTORE;
-                            sp++;
-                            cur = in.y;
-                            entered = true;
-                        }
-                    } else if (GENERAL) {  // REF_RESTORE: back to world space
-                        o = wo;
-                        d = wd;
-                        a = sqlen(d);
-                        cur_xf = -1;
-                        r = make_ray32(o, mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z), t_min, h.t);
-                    }
-                    if (!entered) {
-                        if (sp > 0) {
-                            sp--;
-                            cur = stk[sp * stride];
-                        } else {
-                            cur = REF_DONE;
-                        }
-                    }
-                }
-            }
-
-            // ---- shade the finished lanes: sample_ray's loop body after World::hit, photon_mapper.rs:336-362 ----
-            SM_STAT(3, alive && cur == REF_DONE);
-            if (alive && cur == REF_DONE) {
-                bool done = true;
-                if (h.node >= 0 && depth > 0) {
-                    depth -= 1;
-                    Rec rec = materialize<GENERAL>(A, h, wo, wd, err);
-                    D3 emitted, att, ndir;
-                    bool diffuse;
-                    bool scattered = shade(A, rec, wd, rng, emitted, att, ndir, diffuse, err);
-                    L = add(L, elemul(beta, emitted));
-                    if (scattered) {
-                        beta = elemul(beta, att);
-                        wo = rec.p;
-                        wd = ndir;
-                        done = false;
-                    }
-                }
-                if (done) {
-                    samples[out_idx] = L.x;
-                    samples[out_idx + 1] = L.y;
-                    samples[out_idx + 2] = L.z;
-                    alive = false;
-                } else {  // next segment
-                    if (GENERAL) { o = wo; d = wd; }
-                    a = sqlen(wd);
-                    r = make_ray32(wo, mk(1.0 / wd.x, 1.0 / wd.y, 1.0 / wd.z), t_min, INFINITY);
-                    h.t = INFINITY; h.node = -1; h.xf = -1; h.kp = 0;
-                    cur = A.root2;
-                    sp = 0;
-                    cur_xf = -1;
-                }
-            }
-        }
-    }
-    if (stats && lane == 0) {
-        for (int i = 0; i < 4; i++) {
-            atomicAdd(&stats[2 * i], st_w[i]);
-            atomicAdd(&stats[2 * i + 1], st_l[i]);
-        }
-    }
-}
 
 // per pixel: accum += samples in sample order (camera.rs:96-101). One thread per (tile, pixel).
 __global__ void reduce_kernel(const double* __restrict__ samples, double* __restrict__ accum, int64_t n_pix, int chunk_spp,
@@ -1209,8 +1167,9 @@ __global__ void hit_kernel(FlatView sv, int accel, size_t n, const double* rays,
     if (i >= n) return;
     Acc A = make_acc(sv.base, sv.base, sv);
     D3 o = mk(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]), d = mk(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
-    Hit h = (accel == 2) ? traverse2<true>(A, (uint32_t*)smem + threadIdx.x, (int)blockDim.x, o, d, t_min, t_max)
-                         : traverse<true>(A, o, d, t_min, t_max);
+    Hit h = (accel == 4)   ? traverse8<true>(A, (uint2*)smem + threadIdx.x, (int)blockDim.x, o, d, t_min, t_max)
+            : (accel == 2) ? traverse2<true>(A, (uint32_t*)smem + threadIdx.x, (int)blockDim.x, o, d, t_min, t_max)
+                           : traverse<true>(A, o, d, t_min, t_max);
     double* q = out + 12 * i;
     for (int k = 0; k < 12; k++) q[k] = 0.;
     if (h.node < 0) return;
@@ -1354,8 +1313,8 @@ struct WorkspaceLease {
         }
         try {
             if (!w->small) HIP_CHECK(hipMalloc(&w->small, WS_SMALL));
-            if (const char* e = getenv("RTAMD_WS_LIMIT_MB"))  // test knob: pretend the device cannot spare a sample buffer this large
-                if (need_samples > ((size_t)std::max(1, atoi(e)) << 20)) throw RtError(RT_ERR_HIP, "sample buffer over RTAMD_WS_LIMIT_MB");
+            if (tuning().ws_limit_mb > 0 && need_samples > ((size_t)tuning().ws_limit_mb << 20))  // rt_tuning test hook
+                throw RtError(RT_ERR_HIP, "sample buffer over rt_tuning.workspace_limit_mb");
             if (w->samples_bytes < need_samples) {
                 if (w->samples) (void)hipFree(w->samples);
                 w->samples = nullptr;
@@ -1383,7 +1342,14 @@ struct WorkspaceLease {
 };
 
 typedef void (*pt_fn)(FlatView, CamK, RenderK, double*, unsigned int*, int*);
-typedef void (*pt_sm_fn)(FlatView, const CamK*, RenderK, double*, unsigned int*, int*, unsigned long long*);
+
+template <int ACCEL>
+static pt_fn pick_pt_kernel(bool lds, bool general, int integ) {
+    if (integ == 1) return lds ? pt_kernel<true, true, ACCEL, 1> : pt_kernel<false, true, ACCEL, 1>;  // mixture / SPPM: general primitive set only
+    if (integ == 2) return lds ? pt_kernel<true, true, ACCEL, 2> : pt_kernel<false, true, ACCEL, 2>;
+    return lds ? (general ? pt_kernel<true, true, ACCEL, 0> : pt_kernel<true, false, ACCEL, 0>)
+               : (general ? pt_kernel<false, true, ACCEL, 0> : pt_kernel<false, false, ACCEL, 0>);
+}
 
 void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& plan_in, double* d_tiles, void* stream_, rt_stats* st) {
     if (!s.committed) throw RtError(RT_ERR_NOT_COMMITTED, "scene not committed");
@@ -1397,49 +1363,46 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
     view.base = device_blob(s, dev);
     const bool general = (view.kinds_mask & ~((1u << NK_BOX) | (1u << NK_SPHERE))) != 0;
     const size_t lds_max = di.lds_max;
-    // kernel 2 (accel) is the default when an accel exists and its padding covers this camera's origin
-    // (flatten.cpp: boxes are padded for ray origins up to origin_limit2); otherwise kernel 1 (reference order).
+    // The accel kernels need the camera inside the region the f32 boxes were padded for (flatten.cpp: origin_limit2) and
+    // t_min >= 0 (box32's proof); otherwise kernel 1 (reference order) renders.
     double cam_abs = std::fmax(std::fmax(std::fabs(cam.origin[0]), std::fabs(cam.origin[1])), std::fabs(cam.origin[2])) + std::fabs(cam.lens_radius);
-    const bool accel_usable = view.accel_ok && cam_abs <= view.origin_limit2 && std::isfinite(cam_abs) && plan.t_min >= 0. &&  // box32x2's proof
-                              (size_t)view.stack2 * PT_BLOCK * sizeof(uint32_t) <= lds_max;  // per-lane stacks live in LDS
+    const bool camera_ok = cam_abs <= view.origin_limit2 && std::isfinite(cam_abs) && plan.t_min >= 0.;
+    const size_t stack2_bytes = (size_t)view.stack2 * PT_BLOCK * sizeof(uint32_t), stack8_bytes = (size_t)view.stack8 * PT_BLOCK * sizeof(uint2);
+    const size_t hot1 = (size_t)view.stage_bytes, hot2 = (size_t)(view.stage2_end - view.stage2_begin),
+                 hot8 = (size_t)(view.stage8_mid - view.stage2_begin) + (size_t)view.n_nodes8 * sizeof(Node8);
+    const bool accel2_usable = view.accel_ok && camera_ok && stack2_bytes <= lds_max;  // per-lane stacks live in LDS
+    const bool accel8_usable = view.accel8_ok && camera_ok && stack8_bytes <= lds_max;
+    // default: the BVH2 kernel when its tables fit LDS beside the stacks (small scenes: cheapest node test); otherwise the
+    // wide BVH, whose nodes are read through L2 with the shallowest levels cached in LDS (far fewer dependent fetches)
     int kernel = plan.kernel;
-    if (kernel == 0) kernel = accel_usable ? 2 : 1;
-    if (kernel >= 2 && !accel_usable)
+    if (kernel == 0) {
+        if (accel2_usable && hot2 > 0 && hot2 + stack2_bytes <= lds_max) kernel = 2;
+        else if (accel8_usable) kernel = 4;
+        else kernel = accel2_usable ? 2 : 1;
+    }
+    if (kernel == 2 && !accel2_usable)
         throw RtError(RT_ERR_UNSUPPORTED, "kernel 2 requested but no usable accel for this scene/camera (unbounded item, depth overflow, stacks "
-                                          "larger than LDS, or camera farther than 64x the scene extent); use kernel 0/1");
-    const size_t stack_bytes = (kernel >= 2) ? (size_t)view.stack2 * PT_BLOCK * sizeof(uint32_t) : 0;
-    const size_t hot_bytes = (kernel >= 2) ? (size_t)(view.stage2_end - view.stage2_begin) : (size_t)view.stage_bytes;
-    if (stack_bytes > lds_max) throw RtError(RT_ERR_UNSUPPORTED, "accel stack does not fit LDS");
-    const bool lds = hot_bytes > 0 && hot_bytes + stack_bytes <= lds_max && !getenv("RTAMD_NO_LDS");  // RTAMD_NO_LDS: A/B knob
-    pt_fn fn = nullptr;
-    pt_sm_fn fn_sm = nullptr;
+                                          "larger than LDS, negative t_min, or camera farther than 64x the scene extent); use kernel 0/1");
+    if (kernel == 4 && !accel8_usable)
+        throw RtError(RT_ERR_UNSUPPORTED, "kernel 4 requested but no usable wide accel for this scene/camera; use kernel 0/1");
+    const size_t stack_bytes = (kernel == 4) ? stack8_bytes : (kernel == 2) ? stack2_bytes : 0;
+    const size_t hot_bytes = (kernel == 4) ? hot8 : (kernel == 2) ? hot2 : hot1;
+    const bool lds = hot_bytes > 0 && hot_bytes + stack_bytes <= lds_max && !tuning().no_lds;
     const int integ = plan.integrator;
     if (integ == 1 && view.n_lights == 0) throw RtError(RT_ERR_ARG, "integrator 1 (light importance sampling) needs rt_scene_set_lights");
     if (integ == 2 && !plan.sppm_est) throw RtError(RT_ERR_ARG, "integrator 2 (SPPM) is reached through rt_render_sppm");
-    if (integ != 0 && kernel == 3) throw RtError(RT_ERR_UNSUPPORTED, "the diagnostic kernel 3 implements integrator 0 only");
-    if (kernel == 3)
-        fn_sm = lds ? (general ? pt_kernel_sm<true, true> : pt_kernel_sm<true, false>) : (general ? pt_kernel_sm<false, true> : pt_kernel_sm<false, false>);
-    else if (integ == 1)  // the mixture / SPPM variants are built for the general primitive set only
-        fn = (kernel == 2) ? (lds ? pt_kernel<true, true, 2, 1> : pt_kernel<false, true, 2, 1>)
-                           : (lds ? pt_kernel<true, true, 1, 1> : pt_kernel<false, true, 1, 1>);
-    else if (integ == 2)
-        fn = (kernel == 2) ? (lds ? pt_kernel<true, true, 2, 2> : pt_kernel<false, true, 2, 2>)
-                           : (lds ? pt_kernel<true, true, 1, 2> : pt_kernel<false, true, 1, 2>);
-    else if (kernel == 2)
-        fn = lds ? (general ? pt_kernel<true, true, 2, 0> : pt_kernel<true, false, 2, 0>)
-                 : (general ? pt_kernel<false, true, 2, 0> : pt_kernel<false, false, 2, 0>);
-    else
-        fn = lds ? (general ? pt_kernel<true, true, 1, 0> : pt_kernel<true, false, 1, 0>)
-                 : (general ? pt_kernel<false, true, 1, 0> : pt_kernel<false, false, 1, 0>);
-    // scene too large for LDS: spend what is left after the stacks on the shallowest BVH levels (the Node2 array is depth-sorted)
-    int n2_top = 0;
-    if (kernel == 2 && !lds && lds_max > stack_bytes) {
-        size_t room = (lds_max - stack_bytes) / sizeof(Node2);
-        if (const char* e = getenv("RTAMD_N2_TOP")) room = std::min<size_t>(room, (size_t)std::max(0, atoi(e)));  // tuning knob (A/B runs)
-        n2_top = (int)std::min<size_t>(room, view.n_nodes2);
+    pt_fn fn = (kernel == 4) ? pick_pt_kernel<4>(lds, general, integ) : (kernel == 2) ? pick_pt_kernel<2>(lds, general, integ)
+                                                                                    : pick_pt_kernel<1>(lds, general, integ);
+    // scene too large for LDS: spend what is left after the stacks on the shallowest BVH levels (the node arrays are depth-sorted)
+    int n_top = 0;
+    if (kernel >= 2 && !lds && lds_max > stack_bytes) {
+        const size_t node_bytes = (kernel == 4) ? sizeof(Node8) : sizeof(Node2);
+        size_t room = (lds_max - stack_bytes) / node_bytes;
+        if (tuning().n_top >= 0) room = std::min<size_t>(room, (size_t)tuning().n_top);
+        n_top = (int)std::min<size_t>(room, (kernel == 4) ? view.n_nodes8 : view.n_nodes2);
     }
-    const size_t smem = (lds ? hot_bytes : (size_t)n2_top * sizeof(Node2)) + stack_bytes;
-    const void* fptr = (kernel == 3) ? (const void*)fn_sm : (const void*)fn;
+    const size_t smem = (lds ? hot_bytes : (size_t)n_top * ((kernel == 4) ? sizeof(Node8) : sizeof(Node2))) + stack_bytes;
+    const void* fptr = (const void*)fn;
     if (smem > 48 * 1024) HIP_CHECK(hipFuncSetAttribute(fptr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     int blocks_per_cu = 0;
     HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, fptr, PT_BLOCK, smem));
@@ -1466,8 +1429,7 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
         void* p;
     };
     char* small = (char*)lease.w->small;
-    Ptr samples{lease.w->samples}, accum{lease.w->accum}, counter{small}, err{small + 16}, camk{small + 64}, smstats{small + 512};
-    const bool want_stats = getenv("RTAMD_SM_STATS") != nullptr;
+    Ptr samples{lease.w->samples}, accum{lease.w->accum}, counter{small}, err{small + 16}, camk{small + 64};
     HIP_CHECK(hipMemsetAsync(small, 0, WS_SMALL, stream));
     Events events;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pt_ev, red_ev;
@@ -1488,19 +1450,13 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
         rk.tiles_x = plan.tiles_x; rk.rank = plan.rank; rk.world = plan.world;
         rk.chunk_spp = plan.spp_chunk;
         rk.sppm_est = plan.sppm_est;
-        rk.n2_top = n2_top;
-        rk.restart_th = SM_RESTART;
-        if (const char* e = getenv("RTAMD_SM_RESTART")) rk.restart_th = std::max(1, atoi(e));  // tuning knob (A/B runs)
+        rk.n_top = n_top;
         HIP_CHECK(hipMemsetAsync(counter.p, 0, sizeof(unsigned int), stream));
         hipEvent_t e0 = events.make(), e1 = events.make(), e2 = events.make();
         HIP_CHECK(hipEventRecord(e0, stream));
         if (rk.n_units > 0) {
-            if (kernel == 3)
-                hipLaunchKernelGGL(fn_sm, dim3(grid), dim3(PT_BLOCK), smem, stream, view, (const CamK*)camk.p, rk, (double*)samples.p,
-                                   (unsigned int*)counter.p, (int*)err.p, (unsigned long long*)(want_stats ? smstats.p : nullptr));
-            else
-                hipLaunchKernelGGL(fn, dim3(grid), dim3(PT_BLOCK), smem, stream, view, ck, rk, (double*)samples.p, (unsigned int*)counter.p,
-                                   (int*)err.p);
+            hipLaunchKernelGGL(fn, dim3(grid), dim3(PT_BLOCK), smem, stream, view, ck, rk, (double*)samples.p, (unsigned int*)counter.p,
+                               (int*)err.p);
             HIP_CHECK(hipGetLastError());
         }
         HIP_CHECK(hipEventRecord(e1, stream));
@@ -1543,14 +1499,6 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
         st->grid_blocks = grid;
         st->spp_chunk = plan.spp_chunk;
         st->scene_bytes = s.flat.blob.size();
-    }
-    if (want_stats && kernel == 3) {
-        unsigned long long hs[8];
-        HIP_CHECK(hipMemcpy(hs, smstats.p, sizeof(hs), hipMemcpyDeviceToHost));
-        const char* names[4] = {"regen", "inner", "leaf", "shade"};
-        for (int i = 0; i < 4; i++)
-            fprintf(stderr, "[rtamd sm-stats] %-5s wave-execs %llu lane-participations %llu utilisation %.1f%%\n", names[i], hs[2 * i], hs[2 * i + 1],
-                    hs[2 * i] ? 100.0 * hs[2 * i + 1] / (64.0 * hs[2 * i]) : 0.0);
     }
     if (h_err) throw RtError(RT_ERR_UNIT_ZERO, "unitizing zero vector (device)");
 }
@@ -1672,7 +1620,7 @@ void render_sppm(const rt_scene& s, const CameraDev& cam, RenderPlan plan, const
     // photon pass: stage the accel's hot tables into LDS when at least two 256-thread blocks still fit on a CU
     const size_t hot2 = (size_t)(view.stage2_end - view.stage2_begin);
     const size_t smem_photon = hot2 + smem;
-    const bool photon_lds = accel && hot2 > 0 && 2 * smem_photon <= di.lds_max && !getenv("RTAMD_NO_LDS");
+    const bool photon_lds = accel && hot2 > 0 && 2 * smem_photon <= di.lds_max && !tuning().no_lds;
     if (photon_lds && smem_photon > 48 * 1024)
         HIP_CHECK(hipFuncSetAttribute((const void*)photon_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_photon));
 
@@ -1733,7 +1681,7 @@ void render_sppm(const rt_scene& s, const CameraDev& cam, RenderPlan plan, const
     PhotonStore pg[2], pc[2];
     unsigned int cap_g = (unsigned int)std::min<uint64_t>((uint64_t)cfg.photons_per_iter * 8 + 1024, 0x7FFFFFFFu);
     unsigned int cap_c = (unsigned int)std::min<uint64_t>((uint64_t)cfg.photons_per_iter * 2 + 1024, 0x7FFFFFFFu);
-    if (const char* e = getenv("RTAMD_SPPM_CAP")) cap_g = cap_c = (unsigned int)std::max(1, atoi(e));  // test knob: forces the grow-and-retry path
+    if (tuning().sppm_cap > 0) cap_g = cap_c = (unsigned int)tuning().sppm_cap;  // rt_tuning test hook: forces the grow-and-retry path
     for (int j = 0; j < 2; j++) {
         pg[j].alloc(cap_g);
         pc[j].alloc(cap_c);
@@ -1747,7 +1695,7 @@ void render_sppm(const rt_scene& s, const CameraDev& cam, RenderPlan plan, const
     sk.k_global = cfg.k_global; sk.k_caustic = cfg.k_caustic; sk.max_bounces = cfg.max_bounces; sk.alpha = cfg.alpha;
     sk.seed = plan.seed; sk.S = S; sk.iteration = 0;
     sk.knn_cand = KNN_CAND;
-    if (const char* e = getenv("RTAMD_KNN_CAND")) sk.knn_cand = std::min(KNN_CAND, std::max(0, atoi(e)));  // test knob: forces the out-of-LDS selection
+    if (tuning().knn_cand >= 0) sk.knn_cand = std::min(KNN_CAND, tuning().knn_cand);  // rt_tuning test hook: forces the out-of-LDS selection
     // persistent photon waves: enough 256-thread blocks to fill every CU at 4 waves per SIMD, never more waves than chunks
     const int pblocks = (int)std::max<int64_t>(1, std::min<int64_t>(((int64_t)cfg.photons_per_iter + 4 * PHOTON_CHUNK - 1) / (4 * PHOTON_CHUNK), (int64_t)di.cus * 4));
     const int eblocks = (int)std::min<size_t>((npix + 255) / 256, (size_t)di.cus * 8);
@@ -1877,8 +1825,10 @@ void debug_hit_device(const rt_scene& s, int kernel, size_t n, const double* ray
     HIP_CHECK(hipMemset(err.p, 0, 4));
     HIP_CHECK(hipMemcpy(dr.p, rays, n * 48, hipMemcpyHostToDevice));
     if (kernel == 2 && !view.accel_ok) throw RtError(RT_ERR_UNSUPPORTED, "no accel for this scene");
-    if (kernel == 2 && !(t_min >= 0.)) throw RtError(RT_ERR_UNSUPPORTED, "kernel 2 needs t_min >= 0 (box32x2)");
-    hipLaunchKernelGGL(hit_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), (kernel == 2) ? view.stack2 * 64 * sizeof(uint32_t) : 0, 0, view,
+    if (kernel == 4 && !view.accel8_ok) throw RtError(RT_ERR_UNSUPPORTED, "no wide accel for this scene");
+    if (kernel >= 2 && !(t_min >= 0.)) throw RtError(RT_ERR_UNSUPPORTED, "kernels 2 and 4 need t_min >= 0 (box32)");
+    const size_t smem = (kernel == 4) ? view.stack8 * 64 * sizeof(uint2) : (kernel == 2) ? view.stack2 * 64 * sizeof(uint32_t) : 0;
+    hipLaunchKernelGGL(hit_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), smem, 0, view,
                        kernel, n, (const double*)dr.p, t_min, t_max, (double*)dout.p, (int*)err.p);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemcpy(out, dout.p, n * 96, hipMemcpyDeviceToHost));

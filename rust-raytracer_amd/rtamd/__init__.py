@@ -55,6 +55,12 @@ class rt_sppm_config(C.Structure):
                 ("max_bounces", C.c_int32), ("reserved", C.c_int32), ("alpha", C.c_double)]
 
 
+class rt_tuning(C.Structure):
+    _fields_ = [("no_lds", C.c_int32), ("top_nodes", C.c_int32), ("sub_spp", C.c_int32), ("sample_budget_mb", C.c_int32),
+                ("workspace_limit_mb", C.c_int32), ("max_leaf", C.c_int32), ("sppm_photon_capacity", C.c_int32),
+                ("sppm_knn_candidates", C.c_int32), ("sah_box_cost", C.c_double)]
+
+
 class rt_object_desc(C.Structure):
     _fields_ = [("type", C.c_int32), ("material", C.c_int32), ("n_children", C.c_int32), ("axis", C.c_int32), ("v", C.c_double * 8)]
 
@@ -65,7 +71,7 @@ OBJECT_TYPES = ("Sphere", "Rect", "Cube", "Triangle", "Mesh", "Transform", "Hita
 class rt_scene_info(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("n_nodes", "n_boxes", "n_spheres", "n_rects", "n_tris", "n_xforms", "n_materials",
                                          "n_textures", "n_verts", "max_depth", "committed", "reserved")] + [("bytes", C.c_uint64)] + \
-               [(n, C.c_int32) for n in ("accel_ok", "accel_nodes", "accel_items", "accel_instances", "accel_stack", "reserved2")]
+               [(n, C.c_int32) for n in ("accel_ok", "accel_nodes", "accel_items", "accel_instances", "accel_stack", "accel8_nodes")]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if not k.startswith("reserved")}
@@ -81,6 +87,8 @@ _SIGS = [
     ("rt_last_error", C.c_char_p, []),
     ("rt_default_params", None, [C.POINTER(rt_params)]),
     ("rt_device_count", C.c_int, []),
+    ("rt_tuning_default", None, [C.POINTER(rt_tuning)]),
+    ("rt_tuning_set", C.c_int, [C.POINTER(rt_tuning)]),
     ("rt_scene_create", C.c_int, [C.POINTER(C.c_void_p)]),
     ("rt_scene_destroy", None, [C.c_void_p]),
     ("rt_texture_constant", C.c_int, [C.c_void_p, _d3]),
@@ -437,6 +445,18 @@ def select_scene(cube_obj_path, aspect_ratio=1.0, bvh_seed=1):
     _chk(w.L.rt_scene_cornell_box(w.h, os.fsencode(cube_obj_path), float(aspect_ratio), int(bvh_seed), C.byref(cam)))
     w.commit()
     return w, Camera.from_struct(cam)
+
+
+def set_tuning(**fields):
+    """rt_tuning_set: measurement / test hooks (process-wide; the library reads no environment variable).
+    set_tuning() with no arguments restores the automatic defaults."""
+    t = rt_tuning()
+    lib().rt_tuning_default(C.byref(t))
+    for k, v in fields.items():
+        if not hasattr(t, k):
+            raise TypeError("unknown rt_tuning field %r" % k)
+        setattr(t, k, v)
+    _chk(lib().rt_tuning_set(C.byref(t)))
 
 
 def tiles_owned(params):

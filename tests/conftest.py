@@ -30,3 +30,11 @@ def _built():
 
 def scene_path(name):
     return os.path.join(SCENES, name)
+
+
+@pytest.fixture
+def tuning():
+    """rt_tuning_set for one test (the library reads no environment variable); defaults restored afterwards."""
+    import rtamd
+    yield rtamd.set_tuning
+    rtamd.set_tuning()

@@ -72,7 +72,7 @@ def test_mixture_needs_lights():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kernel", [1, 2])
+@pytest.mark.parametrize("kernel", [1, 2, 4])
 @pytest.mark.parametrize("rect_light", [False, True])
 def test_hip_mixture_bit_exact_vs_oracle(rect_light, kernel):
     o = oracle_scene(rect_light)

@@ -54,7 +54,7 @@ def test_device_sqrt_and_divide_are_correctly_rounded():
         assert np.array_equal(rtamd.debug_math(1, a, b), a / b)
 
 
-@pytest.mark.parametrize("kernel", [1, 2, 3])
+@pytest.mark.parametrize("kernel", [1, 2, 4])
 @pytest.mark.parametrize("name,w,h,spp,aspect", [
     ("scene_10.json", 64, 36, 16, 16.0 / 9.0),      # C1 at reduced size
     ("scene_10.yaml", 40, 24, 4, None),
@@ -108,14 +108,14 @@ def test_depth_limit_semantics():
     """Q12: depth is tested after the hit and before emission: max_depth hits contribute."""
     world, cam, ref = _pair("scene_500.json")
     for depth in (0, 1, 2, 5):
-        img, _ = world.render(cam, width=32, height=32, spp=4, seed=1, max_depth=depth, kernel=1 + depth % 3)
+        img, _ = world.render(cam, width=32, height=32, spp=4, seed=1, max_depth=depth, kernel=(1, 2, 4)[depth % 3])
         exp, _ = ref.render(32, 32, 4, max_depth=depth, seed=1)
         _assert_same(img, exp, "max_depth=%d" % depth)
     z, _ = world.render(cam, width=16, height=16, spp=2, seed=1, max_depth=0)
     assert not z.any()
 
 
-@pytest.mark.parametrize("kernel", [1, 2, 3])
+@pytest.mark.parametrize("kernel", [1, 2, 4])
 def test_cornell_box_bit_exact(kernel):
     """C3 geometry: rects, cube, transform(mesh), glass + mirror spheres, rect light (scene.rs:16-112)."""
     import oracle
@@ -129,7 +129,7 @@ def test_cornell_box_bit_exact(kernel):
     assert img.max() > 0
 
 
-@pytest.mark.parametrize("kernel", [1, 2, 3])
+@pytest.mark.parametrize("kernel", [1, 2, 4])
 def test_first_hit_records_match_oracle(kernel):
     """World::hit on explicit rays: t, p, normal, front_face identical to the oracle's HitRecord."""
     import oracle
@@ -198,16 +198,17 @@ def test_kernels_agree_on_random_sphere_soups_with_ties():
     rays[:, 3:] = target - rays[:, :3]
     a = w.debug_hit(rays, kernel=1)
     b = w.debug_hit(rays, kernel=2)
-    assert np.array_equal(a, b)
+    c = w.debug_hit(rays, kernel=4)
+    assert np.array_equal(a, b) and np.array_equal(a, c)
     assert a[:, 0].sum() > n // 2
     cam = rtamd.Camera(((0, 0, -20), (0, 0, 0)), (0, 1, 0), 40, 1.0, 0.0, 20.0)
     i1, _ = w.render(cam, width=48, height=48, spp=4, kernel=1)
     i2, _ = w.render(cam, width=48, height=48, spp=4, kernel=2)
-    i3, _ = w.render(cam, width=48, height=48, spp=4, kernel=3)
+    i3, _ = w.render(cam, width=48, height=48, spp=4, kernel=4)
     assert np.array_equal(i1, i2) and np.array_equal(i1, i3)
 
 
-@pytest.mark.parametrize("kernel", [1, 2])
+@pytest.mark.parametrize("kernel", [1, 2, 4])
 def test_image_texture_and_every_material_bit_exact(kernel):
     """ImageTexture (material.rs:70-84) on a sphere (uv by acos/atan2, sphere.rs:16-20) and on rectangles (uv by
     position), CheckerTexture, fuzzy Metal, Dielectric, a sphere light, a rotated + non-uniformly scaled Transform
@@ -248,7 +249,8 @@ def test_image_texture_and_every_material_bit_exact(kernel):
 
 @pytest.mark.parametrize("scale", [1e-3, 1.0, 250.0, 1e5])
 def test_accel_is_conservative_fuzz(scale):
-    """Kernel 2's f32 padded boxes must never cull what kernel 1 (f64 boxes, reference order) finds: random scenes of
+    """The f32 padded boxes of kernel 2 (BVH2) and the quantised ones of kernel 4 (8-wide BVH) must never cull what kernel 1
+    (f64 boxes, reference order) finds: random scenes of
     spheres, rectangles, cubes and rotated / non-uniformly scaled mesh instances at coordinate scales from 1e-3 to 1e5,
     rays from inside, outside, grazing and axis-parallel; the two traversals must return identical hit records."""
     import oracle
@@ -278,7 +280,7 @@ def test_accel_is_conservative_fuzz(scale):
             items.append(w.Transform(tuple(rng.uniform(-180, 180, 3)), tuple(rng.uniform(0.2, 2.0, 3) * scale),
                                      tuple((rng.random(3) - 0.5) * 16.0 * scale), mesh))
         w.new(items, bvh_seed=int(rng.integers(1 << 30)))
-        assert w.info()["accel_ok"] == 1
+        assert w.info()["accel_ok"] == 1 and w.info()["accel8_nodes"] > 0
         n = 6000
         o = (rng.random((n, 3)) - 0.5) * 30.0 * scale
         o[: n // 4] = (rng.random((n // 4, 3)) - 0.5) * 4.0 * scale            # origins inside the cloud
@@ -288,9 +290,10 @@ def test_accel_is_conservative_fuzz(scale):
         d[::13] *= 1e6                                                           # huge ones
         rays = np.concatenate([o, d], axis=1)
         a = w.debug_hit(rays, t_min=1e-3, kernel=1)
-        b = w.debug_hit(rays, t_min=1e-3, kernel=2)
-        bad = np.argwhere((a != b).any(axis=1))
-        assert len(bad) == 0, "trial %d: %d rays differ, first %s:\n k1 %s\n k2 %s" % (trial, len(bad), rays[bad[0, 0]], a[bad[0, 0]], b[bad[0, 0]])
+        for k in (2, 4):
+            b = w.debug_hit(rays, t_min=1e-3, kernel=k)
+            bad = np.argwhere((a != b).any(axis=1))
+            assert len(bad) == 0, "trial %d: %d rays differ, first %s:\n k1 %s\n k%d %s" % (trial, len(bad), rays[bad[0, 0]], a[bad[0, 0]], k, b[bad[0, 0]])
         assert a[:, 0].sum() > n // 20
         # grazing rays from FAR origins (up to the 64 x extent the boxes are padded for): aimed at the silhouette of every
         # sphere, just inside and just outside; of = fl32(o) and c = fl32(of * iv) are at their coarsest here
@@ -307,13 +310,14 @@ def test_accel_is_conservative_fuzz(scale):
         far, tgt = np.array(far), np.array(tgt)
         rays = np.concatenate([far, tgt - far], axis=1)
         a = w.debug_hit(rays, t_min=1e-3, kernel=1)
-        b = w.debug_hit(rays, t_min=1e-3, kernel=2)
-        bad = np.argwhere((a != b).any(axis=1))
-        assert len(bad) == 0, "trial %d (grazing): %d rays differ, first %s:\n k1 %s\n k2 %s" % (trial, len(bad), rays[bad[0, 0]], a[bad[0, 0]], b[bad[0, 0]])
+        for k in (2, 4):
+            b = w.debug_hit(rays, t_min=1e-3, kernel=k)
+            bad = np.argwhere((a != b).any(axis=1))
+            assert len(bad) == 0, "trial %d (grazing): %d rays differ, first %s:\n k1 %s\n k%d %s" % (trial, len(bad), rays[bad[0, 0]], a[bad[0, 0]], k, b[bad[0, 0]])
         assert 0.25 < a[:, 0].mean() < 0.95
 
 
-@pytest.mark.parametrize("kernel", [1, 2])
+@pytest.mark.parametrize("kernel", [1, 2, 4])
 def test_large_mesh_instance_outside_lds_bit_exact(kernel):
     """C4's shape at test size: the Cornell box with a 6,400-triangle torus instance (rtamd.shapes).  Its tables exceed
     LDS, so this runs the global-memory variants (kernel 2: depth-sorted Node2 array with the top levels cached in LDS,
@@ -336,7 +340,61 @@ def test_large_mesh_instance_outside_lds_bit_exact(kernel):
     assert st["scene_in_lds"] == 0
 
 
-@pytest.mark.parametrize("kernel", [1, 2])
+_C4 = {}
+
+
+def _c4_scene():
+    """BASELINE config C4 at its own mesh size: Cornell box + 102,400-triangle torus instance (built once per session)."""
+    if not _C4:
+        import oracle
+        import rtamd
+        from rtamd import shapes
+        P, N, I = shapes.torus(160, 320)
+        w = rtamd.World()
+        w.new(shapes.cornell_with_mesh(w, P, N, I), bvh_seed=1)
+        o = oracle.Scene()
+        o.World(shapes.cornell_with_mesh(o, P, N, I), 1)
+        o.Camera((278, 278, -800), (278, 278, 278), (0, 1, 0), 50, 1.0, 0.0, 10.0)
+        cam = rtamd.Camera(((278, 278, -800), (278, 278, 278)), (0, 1, 0), 50, 1.0, 0.0, 10.0)
+        exp, _ = o.render(64, 64, 4, seed=1)
+        _C4.update(world=w, oracle=o, cam=cam, exp=exp)
+    return _C4
+
+
+@pytest.mark.parametrize("kernel", [0, 1, 2, 4])
+def test_c4_full_size_mesh_bit_exact(kernel):
+    """Config C4 (Cornell box + ~100k-triangle mesh) at the configured mesh size, every traversal against the oracle:
+    64 x 64 x 4 spp of the 102,400-triangle torus instance (mesh.rs:57-137,144-208; transform.rs:152-165)."""
+    c = _c4_scene()
+    info = c["world"].info()
+    assert info["n_tris"] == 102400 and info["accel_ok"] == 1 and info["accel8_nodes"] > 1000
+    img, st = c["world"].render(c["cam"], width=64, height=64, spp=4, seed=1, kernel=kernel)
+    _assert_same(img, c["exp"], "C4 (102,400 triangles), kernel %d" % kernel)
+    assert st["scene_in_lds"] == 0 and img.max() > 0
+    if kernel == 0:
+        assert st["kernel_used"] == 4          # scenes beyond LDS default to the wide BVH
+
+
+def test_c4_first_hits_agree_between_traversals():
+    """closest-hit records (t, point, normal, winning leaf) of primary and random secondary rays through the 102,400-triangle
+    instance: kernels 2 and 4 against kernel 1's reference-order walk."""
+    c = _c4_scene()
+    rng = np.random.default_rng(77)
+    n = 20000
+    o = np.empty((n, 3))
+    o[: n // 2] = (278.0, 278.0, -800.0)
+    o[n // 2:] = rng.uniform(20.0, 535.0, size=(n - n // 2, 3))
+    tgt = np.array([278.0, 200.0, 278.0]) + rng.normal(0, 90.0, size=(n, 3))
+    rays = np.concatenate([o, tgt - o], axis=1)
+    a = c["world"].debug_hit(rays, kernel=1)
+    assert 0.3 < a[:, 0].mean()
+    for k in (2, 4):
+        b = c["world"].debug_hit(rays, kernel=k)
+        bad = np.argwhere((a != b).any(axis=1))
+        assert len(bad) == 0, "kernel %d: %d rays differ, first %s" % (k, len(bad), rays[bad[0, 0]] if len(bad) else None)
+
+
+@pytest.mark.parametrize("kernel", [1, 2, 4])
 def test_many_spheres_outside_lds_bit_exact(kernel):
     """30,000 spheres: the sphere-only kernels with the scene in L2/HBM instead of LDS (variants <LDS=false, GENERAL=false>)."""
     import oracle
@@ -375,26 +433,25 @@ def test_degenerate_image_sizes_match_the_oracle(w, h):
         assert np.array_equal(img, exp, equal_nan=True), (kernel, img, exp)
 
 
-def test_launches_shrink_when_the_sample_buffer_cannot_be_allocated(monkeypatch):
+def test_launches_shrink_when_the_sample_buffer_cannot_be_allocated(tuning):
     """make_plan budgets up to 12 GiB for the per-launch sample buffer; a device that cannot spare it gets smaller launches
     (halved until the buffer fits) and, since samples are reduced in sample order, the same image."""
     world, cam, _ = _pair("scene_500.json")
     w, h, spp = 256, 192, 40          # 40 spp x 48 Ki pixels x 24 B = 45 MiB in one launch
     full, st = world.render(cam, width=w, height=h, spp=spp, seed=5)
     assert st["launches"] == 1 and st["spp_chunk"] == spp
-    monkeypatch.setenv("RTAMD_WS_LIMIT_MB", "8")
+    tuning(workspace_limit_mb=8)
     small, st2 = world.render(cam, width=w, height=h, spp=spp, seed=5)
     assert st2["spp_chunk"] == 5 and st2["launches"] == 8           # 40 -> 20 -> 10 -> 5 sample indices per launch
     assert np.array_equal(small, full)
 
 
-def test_image_does_not_depend_on_the_work_partition_knobs(monkeypatch):
+def test_image_does_not_depend_on_the_work_partition_knobs(tuning):
     """work-unit size and launch size only change the schedule (which wave traces which path, in how many launches)."""
     world, cam, _ = _pair("scene_500.json")
     w, h, spp = 96, 72, 24
     full, st = world.render(cam, width=w, height=h, spp=spp, seed=9)
-    monkeypatch.setenv("RTAMD_SUB_SPP", "3")
-    monkeypatch.setenv("RTAMD_SAMPLE_BUDGET_MB", "1")           # 1 MiB: a few sample indices per launch
+    tuning(sub_spp=3, sample_budget_mb=1)                       # 1 MiB: a few sample indices per launch
     other, st2 = world.render(cam, width=w, height=h, spp=spp, seed=9)
     assert st2["launches"] > st["launches"]
     assert np.array_equal(other, full)
@@ -409,9 +466,10 @@ def test_negative_t_min_goes_through_the_reference_order_kernel():
     assert st["kernel_used"] == 1
     exp, _ = ref.render(40, 24, 3, seed=2, t_min=-0.25)
     _assert_same(img, exp, "t_min = -0.25")
-    with pytest.raises(rtamd.RtError) as e:
-        world.render(cam, width=8, height=8, spp=1, t_min=-0.25, kernel=2)
-    assert e.value.code == -10   # RT_ERR_UNSUPPORTED
+    for k in (2, 4):
+        with pytest.raises(rtamd.RtError) as e:
+            world.render(cam, width=8, height=8, spp=1, t_min=-0.25, kernel=k)
+        assert e.value.code == -10   # RT_ERR_UNSUPPORTED
 
 
 def test_coordinates_beyond_2_pow_36_use_the_reference_order_kernel():

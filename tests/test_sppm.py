@@ -37,7 +37,7 @@ def test_oracle_sppm_needs_lights():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kernel", [1, 2])
+@pytest.mark.parametrize("kernel", [1, 2, 4])
 def test_hip_sppm_bit_exact_vs_oracle_cornell(kernel):
     import oracle
     import rtamd
@@ -114,18 +114,18 @@ def test_hip_sppm_errors_and_prepass_only():
 
 
 @pytest.mark.gpu
-def test_hip_sppm_photon_buffer_overflow_retries_identically(monkeypatch):
+def test_hip_sppm_photon_buffer_overflow_retries_identically(tuning):
     """a photon buffer that is too small makes the (deterministic) photon pass repeat with a larger one: same result."""
     import rtamd
     w, cam = rtamd.select_scene(scene_path("cube.obj"), 1.0, 1)
     a = w.render_sppm(cam, width=16, height=16, spp=2, seed=1, **CFG)
-    monkeypatch.setenv("RTAMD_SPPM_CAP", "64")
+    tuning(sppm_photon_capacity=64)
     b = w.render_sppm(cam, width=16, height=16, spp=2, seed=1, **CFG)
     assert a[2] == b[2] and np.array_equal(a[1], b[1]) and np.array_equal(a[0], b[0], equal_nan=True)
 
 
 @pytest.mark.gpu
-def test_hip_sppm_knn_selection_outside_lds_is_identical(monkeypatch):
+def test_hip_sppm_knn_selection_outside_lds_is_identical(tuning):
     """the k-nearest selection keeps its candidates in LDS when they fit; the out-of-LDS path (more candidates than the
     buffer holds: bisection passes over the photon grid) must give the same statistics, and both equal the oracle's."""
     import oracle
@@ -133,7 +133,7 @@ def test_hip_sppm_knn_selection_outside_lds_is_identical(monkeypatch):
     w, cam = rtamd.select_scene(scene_path("cube.obj"), 1.0, 1)
     o = oracle.cornell_box_scene(scene_path("cube.obj"), 1.0, seed=1)
     a = w.render_sppm(cam, width=16, height=16, spp=1, seed=3, **CFG)
-    monkeypatch.setenv("RTAMD_KNN_CAND", "5")
+    tuning(sppm_knn_candidates=5)
     b = w.render_sppm(cam, width=16, height=16, spp=1, seed=3, **CFG)
     assert a[2] == b[2] and np.array_equal(a[1], b[1]) and np.array_equal(a[0], b[0], equal_nan=True)
     eimg, est, etot = o.render_sppm(16, 16, 1, seed=3, **CFG)
