@@ -76,7 +76,8 @@ typedef struct rt_params {
     int32_t world;       /* 1 = whole image */
     int32_t spp_chunk;   /* samples per pixel per kernel launch; 0 = auto */
     int32_t kernel;      /* 0 = auto; 1 = reference-order stackless traversal; 2 = SAH-BVH2 accel traversal (auto when the
-                            scene's tables fit LDS); 4 = 8-wide quantised BVH traversal (auto for larger scenes).
+                            scene's tables fit LDS); 4 = 8-wide quantised BVH traversal (never auto: measured slower);
+                            5 = kernel 2 with the cooperative instance service (auto for scenes with large mesh instances).
                             All give bit-identical images (same f64 primitive tests, same tie rule). */
     int32_t device;      /* HIP device ordinal; -1 = current */
     int32_t integrator;  /* 0 = sample_ray as the reference structures it (BSDF sampling only; default);

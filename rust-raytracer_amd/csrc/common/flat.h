@@ -147,6 +147,8 @@ struct FlatView {  // by-value kernel argument
     uint32_t root8;              // root Node8 index of the world-space BVH
     uint32_t stack8;             // 64-bit stack entries a lane can need
     uint32_t stage8_mid;         // kernel 4 stages [stage2_begin, stage8_mid) and [off_n8, off_n8 + 80 * n_nodes8) into LDS
+    uint32_t n_inst2;            // instances (object-space BVHs under a Transform)
+    uint32_t max_inst_nodes2;    // Node2 count of the largest instance BVH
 };
 
 }  // namespace rtamd

@@ -261,7 +261,7 @@ void flatten(rt_scene& s) {
     // ---- accel (kernel 2) ----
     AccelBuild ab;
     ab.ok = b.accel_ok;
-    uint32_t root2 = REF_DONE;
+    uint32_t root2 = REF_DONE, max_inst_nodes = 0;
     double origin_limit = 0.;
     if (ab.ok && !b.actx[0].items.empty()) {
         // E_w: largest |coordinate| of the world items; boxes are padded so that rounding a ray origin with
@@ -290,7 +290,9 @@ void flatten(rt_scene& s) {
                 for (auto& it : c.items)  // hit points inside the instance also serve as origins of secondary rays (in world space only)
                     for (int a = 0; a < 3; a++) oo = std::fmax(oo, std::fmax(std::fabs(it.box.mn[a]), std::fabs(it.box.mx[a])));
                 if (!(oo < 68719476736.)) { ab.ok = false; break; }
+                const size_t nodes_before = ab.nodes.size();
                 uint32_t r = accel_build_bvh(ab, c.items, std::ldexp(oo, -22), depth_tlas + 1);
+                max_inst_nodes = std::max<uint32_t>(max_inst_nodes, (uint32_t)(ab.nodes.size() - nodes_before));
                 ab.inst[2 * (i - 1)] = c.xform;
                 ab.inst[2 * (i - 1) + 1] = r;
             }
@@ -398,6 +400,8 @@ void flatten(rt_scene& s) {
     v.accel8_ok = a8.ok ? 1u : 0u;
     v.root8 = a8.root;
     v.stack8 = (uint32_t)(a8.max_depth + 4);
+    v.n_inst2 = (uint32_t)(ab.inst.size() / 2);
+    v.max_inst_nodes2 = max_inst_nodes;
     v.accel_ok = ab.ok ? 1u : 0u;
     v.root2 = root2;
     v.stack2 = (uint32_t)(ab.max_depth + 2);

@@ -115,7 +115,7 @@ def test_depth_limit_semantics():
     assert not z.any()
 
 
-@pytest.mark.parametrize("kernel", [1, 2, 4])
+@pytest.mark.parametrize("kernel", [1, 2, 4, 5])
 def test_cornell_box_bit_exact(kernel):
     """C3 geometry: rects, cube, transform(mesh), glass + mirror spheres, rect light (scene.rs:16-112)."""
     import oracle
@@ -208,7 +208,7 @@ def test_kernels_agree_on_random_sphere_soups_with_ties():
     assert np.array_equal(i1, i2) and np.array_equal(i1, i3)
 
 
-@pytest.mark.parametrize("kernel", [1, 2, 4])
+@pytest.mark.parametrize("kernel", [1, 2, 4, 5])
 def test_image_texture_and_every_material_bit_exact(kernel):
     """ImageTexture (material.rs:70-84) on a sphere (uv by acos/atan2, sphere.rs:16-20) and on rectangles (uv by
     position), CheckerTexture, fuzzy Metal, Dielectric, a sphere light, a rotated + non-uniformly scaled Transform
@@ -317,7 +317,7 @@ def test_accel_is_conservative_fuzz(scale):
         assert 0.25 < a[:, 0].mean() < 0.95
 
 
-@pytest.mark.parametrize("kernel", [1, 2, 4])
+@pytest.mark.parametrize("kernel", [1, 2, 4, 5])
 def test_large_mesh_instance_outside_lds_bit_exact(kernel):
     """C4's shape at test size: the Cornell box with a 6,400-triangle torus instance (rtamd.shapes).  Its tables exceed
     LDS, so this runs the global-memory variants (kernel 2: depth-sorted Node2 array with the top levels cached in LDS,
@@ -361,7 +361,7 @@ def _c4_scene():
     return _C4
 
 
-@pytest.mark.parametrize("kernel", [0, 1, 2, 4])
+@pytest.mark.parametrize("kernel", [0, 1, 2, 4, 5])
 def test_c4_full_size_mesh_bit_exact(kernel):
     """Config C4 (Cornell box + ~100k-triangle mesh) at the configured mesh size, every traversal against the oracle:
     64 x 64 x 4 spp of the 102,400-triangle torus instance (mesh.rs:57-137,144-208; transform.rs:152-165)."""
@@ -372,7 +372,31 @@ def test_c4_full_size_mesh_bit_exact(kernel):
     _assert_same(img, c["exp"], "C4 (102,400 triangles), kernel %d" % kernel)
     assert st["scene_in_lds"] == 0 and img.max() > 0
     if kernel == 0:
-        assert st["kernel_used"] == 4          # scenes beyond LDS default to the wide BVH
+        assert st["kernel_used"] == 5          # large mesh instances default to the cooperative instance service
+
+
+def test_c4_larger_frame_cooperative_kernel_equals_plain_kernel():
+    """kernel 5 re-packs in-mesh rays across the waves of a workgroup; at a size where every wave posts and serves
+    (256 x 256 x 16 spp, 1 M paths) the image must equal kernel 2's bit for bit, also with several instances of the mesh."""
+    c = _c4_scene()
+    a, sa = c["world"].render(c["cam"], width=256, height=256, spp=16, seed=3, kernel=2)
+    b, sb = c["world"].render(c["cam"], width=256, height=256, spp=16, seed=3, kernel=5)
+    assert sa["kernel_used"] == 2 and sb["kernel_used"] == 5
+    assert np.array_equal(a, b) and a.max() > 0
+    import rtamd
+    from rtamd import shapes
+    P, N, I = shapes.torus(48, 96)
+    w = rtamd.World()
+    white = w.Lambertian(w.ConstantTexture((0.7, 0.7, 0.7)))
+    mesh = w.Mesh(P, N, I, white, bvh_seed=2)
+    items = shapes.cornell_with_mesh(w, P, N, I, scale=70.0, translate=(150.0, 150.0, 200.0))
+    items += [w.Transform((10.0 * i, 25.0 * i, 5.0), (40.0, 55.0, 40.0), (120.0 + 90.0 * i, 330.0, 300.0 + 40.0 * i), mesh) for i in range(4)]
+    w.new(items, bvh_seed=3)
+    assert w.info()["accel_instances"] == 5
+    a, _ = w.render(c["cam"], width=160, height=160, spp=8, seed=5, kernel=2)
+    b, st = w.render(c["cam"], width=160, height=160, spp=8, seed=5, kernel=5)
+    k1, _ = w.render(c["cam"], width=160, height=160, spp=8, seed=5, kernel=1)
+    assert st["kernel_used"] == 5 and np.array_equal(a, b) and np.array_equal(a, k1)
 
 
 def test_c4_first_hits_agree_between_traversals():

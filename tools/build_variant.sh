@@ -6,6 +6,6 @@ name=$1; shift
 mkdir -p variants
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -I../include -Icsrc --offload-arch=gfx950 "$@" \
   -Rpass-analysis=kernel-resource-usage -c csrc/device/kernels.hip -o variants/kernels_$name.o 2>&1 \
-  | grep -E "Function Name|VGPRs:|ScratchSize" | grep -A2 "pt_kernelILb1ELb0ELi2ELb0" | grep -E "VGPRs|Scratch" | sed 's/.*remark: //' | cut -c1-50 | tr '\n' ' '
+  | grep -E "Function Name|VGPRs:|ScratchSize" | grep -A2 "pt_kernelILb1ELb0ELi2ELi0" | grep -E "VGPRs|Scratch" | sed 's/.*remark: //' | cut -c1-50 | tr '\n' ' '
 echo " <- $name"
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o variants/librtamd_$name.so csrc/abi.o csrc/host/*.o variants/kernels_$name.o
