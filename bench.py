@@ -149,7 +149,7 @@ def main():
     ap.add_argument("--height", type=int, default=1200)
     ap.add_argument("--spp", type=int, default=1000)
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--kernel", type=int, default=0, help="0 = library default; 1/2/4 force a traversal (A/B runs only)")
+    ap.add_argument("--kernel", type=int, default=0, help="0 = library default; 1/2 force a traversal (A/B runs only)")
     ap.add_argument("--cpu-spp", type=int, default=32, help="spp of the bounded CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
     if args.gpus < 1:
@@ -236,8 +236,7 @@ def main():
         total = args.width * args.height * args.spp * args.steps
         value = total / dt / 1e6
         roof, contract, hbm = roofline_objects(stats_acc, dt)
-        kernel_names = {1: "reference-order stackless", 2: "SAH-BVH2 accel, f32 conservative boxes",
-                        4: "8-wide quantised BVH accel, f32 conservative boxes"}
+        kernel_names = {1: "reference-order stackless", 2: "SAH-BVH2 accel, f32 conservative boxes"}
         out = {
             "metric": "Msamples/sec (px*spp), scene_500 %dx%d %dspp" % (args.width, args.height, args.spp),
             "value": value, "unit": "Msamples/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,

@@ -75,10 +75,8 @@ typedef struct rt_params {
     int32_t rank;        /* image-tile partition: this call renders tiles t with t % world == rank */
     int32_t world;       /* 1 = whole image */
     int32_t spp_chunk;   /* samples per pixel per kernel launch; 0 = auto */
-    int32_t kernel;      /* 0 = auto; 1 = reference-order stackless traversal; 2 = SAH-BVH2 accel traversal (auto when the
-                            scene's tables fit LDS); 4 = 8-wide quantised BVH traversal (never auto: measured slower);
-                            5 = kernel 2 with the cooperative instance service (auto for scenes with large mesh instances).
-                            All give bit-identical images (same f64 primitive tests, same tie rule). */
+    int32_t kernel;      /* 0 = auto; 1 = reference-order stackless traversal; 2 = SAH-BVH2 accel traversal (auto whenever the
+                            scene has a usable accel).  Both give bit-identical images (same f64 primitive tests, same tie rule). */
     int32_t device;      /* HIP device ordinal; -1 = current */
     int32_t integrator;  /* 0 = sample_ray as the reference structures it (BSDF sampling only; default);
                             1 = light importance sampling: on Diffuse hits the direction is drawn from the
@@ -210,8 +208,7 @@ typedef struct rt_scene_info {
     int32_t n_nodes, n_boxes, n_spheres, n_rects, n_tris, n_xforms, n_materials, n_textures;
     int32_t n_verts, max_depth, committed, reserved;
     uint64_t bytes;
-    int32_t accel_ok, accel_nodes, accel_items, accel_instances, accel_stack;
-    int32_t accel8_nodes;   /* Node8 count of the wide accel (kernel 4), 0 if none was built */
+    int32_t accel_ok, accel_nodes, accel_items, accel_instances, accel_stack, reserved2;
 } rt_scene_info;
 int rt_scene_info_get(const rt_scene* s, rt_scene_info* out);
 

@@ -404,7 +404,7 @@ static RenderPlan make_plan(const rt_params* p) {
     REQUIRE(p->spp > 0, "spp must be positive");
     REQUIRE(p->max_depth >= 0, "max_depth must be >= 0");
     REQUIRE(p->world >= 1 && p->rank >= 0 && p->rank < p->world, "bad rank/world");
-    REQUIRE(p->kernel == 0 || p->kernel == 1 || p->kernel == 2 || p->kernel == 4 || p->kernel == 5, "unknown kernel id (0 auto, 1, 2, 4, 5)");
+    REQUIRE(p->kernel >= 0 && p->kernel <= 2, "unknown kernel id (0 auto, 1, 2)");
     REQUIRE(p->integrator >= 0 && p->integrator <= 2, "unknown integrator id");
     RenderPlan pl;
     pl.width = p->width; pl.height = p->height; pl.spp = p->spp; pl.max_depth = p->max_depth;
@@ -663,7 +663,7 @@ int rt_debug_math_device(int op, size_t n, const double* a_host, const double* b
 }
 int rt_debug_hit_device(const rt_scene* s, int kernel, size_t n, const double* rays_host, double t_min, double t_max, double* out_host) {
     return guard([&] {
-        REQUIRE(s && n > 0 && rays_host && out_host && (kernel == 1 || kernel == 2 || kernel == 4), "bad argument");
+        REQUIRE(s && n > 0 && rays_host && out_host && (kernel == 1 || kernel == 2), "bad argument");
         if (device_count() < 1) throw RtError(RT_ERR_NO_DEVICE, "no HIP device");
         debug_hit_device(*s, kernel, n, rays_host, t_min, t_max, out_host);
         return (int)RT_OK;

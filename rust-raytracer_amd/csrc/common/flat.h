@@ -82,45 +82,6 @@ static const int ACCEL_MAX_LEAF = 8;      // limit of the 3-bit count field; the
 static const int ACCEL_DEFAULT_LEAF = 4;
 static const int ACCEL_MAX_STACK = 64;
 
-// ---------------------------------------------------------------------------
-// Wide accel ("kernel 4"): the same binned-SAH BVH2 collapsed into 8-ary nodes with child boxes QUANTISED to 8 bits per
-// plane inside the node's own frame (the layout idea of Ylitie, Karras, Laine 2017, "Efficient Incoherent Ray Traversal
-// on GPUs Through Compressed Wide BVHs"; code and slot ordering written for wave64 here).  It exists for scenes whose
-// tables do not fit LDS: a 102 400-triangle mesh needs ~11 k nodes of 80 B (0.9 MB, L2-resident, the top ~800 in LDS)
-// instead of 43 k Node2 of 64 B, and a ray descends 5-6 levels instead of 17, i.e. far fewer DEPENDENT fetches.
-//   Node8 (80 B = five 16-byte words):
-//     o[3]        f32 frame origin (<= every child's padded lower corner)
-//     e[3]        biased f32 exponent per axis: scale s_a = 2^(e_a - 127)
-//     imask       bit i: child slot i is an inner node
-//     cb_lm       low 24 bits: index of the first inner child (inner children are contiguous, in slot order);
-//                 high 8 bits: lmask, bit i: child slot i is a leaf
-//     item_base   first item (common/flat.h "item") of this node's leaf children; their items are contiguous
-//     meta[8]     leaf slot: count << 5 | offset  (1..4 items at item_base + offset, offset + count <= 32); inner 0xFF; empty 0
-//     qlo[3][8], qhi[3][8]   child planes: lo = o + qlo * s (computed as ONE f32 fma, exact by construction),
-//                 hi = o + qhi * s.  The builder checks with the very same fma that lo <= padded box min and
-//                 hi >= padded box max, so the decoded boxes satisfy the hypothesis of box32's proof (device/kernels.hip)
-//                 exactly as Node2's stored f32 boxes do.
-//   Child slots are assigned so that slot bit a says on which side of the node (along axis a) the child lies; a ray
-//   with direction-sign octant `oct` visits hit children in ascending (slot ^ oct): approximately near to far, no sort.
-//   Traversal stack entries are 64 bit: {tag << 30 | base, mask}: node group (first inner child, remaining children in
-//   visit order | imask << 8), item group (item_base, 32-bit item mask), or the restore-world marker.
-// ---------------------------------------------------------------------------
-struct Node8 {
-    float o[3];
-    uint8_t e[3];
-    uint8_t imask;
-    uint32_t cb_lm;
-    uint32_t item_base;
-    uint8_t meta[8];
-    uint8_t qlo[3][8];
-    uint8_t qhi[3][8];
-};
-static_assert(sizeof(Node8) == 80, "Node8 is five 16-byte words");
-static const uint32_t NODE8_U4 = 5;               // Node8 stride in 16-byte words
-static const uint32_t NODE8_NONE = 0xFFFFFFFFu;
-static const uint32_t ST8_NODES = 0u, ST8_ITEMS = 1u, ST8_RESTORE = 2u;  // stack entry tags (entry.x >> 30)
-static const int ACCEL8_MAX_STACK = 40;
-
 struct FlatView {  // by-value kernel argument
     const char* base;
     uint32_t off_meta, off_boxes, off_spheres, off_sphere_mat, off_rects, off_rect_mat, off_tris, off_xforms;
@@ -140,15 +101,6 @@ struct FlatView {  // by-value kernel argument
     uint32_t off_tripre2;     // accel: triangle records {pa, e0, e1, pad} in ITEM order (leaf-contiguous)
     uint32_t n_nodes2;        // Node2 count; the array is sorted by depth, so a prefix of it = the top of every BVH
     double origin_limit2;     // accel boxes are padded for ray origins with max-abs coordinate <= this (camera checked per render)
-    // wide accel (kernel 4): shares items2 / tripre2 with kernel 2 (the item order is the wide tree's)
-    uint32_t accel8_ok;
-    uint32_t off_n8, n_nodes8;   // Node8 array, breadth-first over all BVHs: a prefix of it = the shallowest levels
-    uint32_t off_inst8;          // per instance {xform, root Node8 index}
-    uint32_t root8;              // root Node8 index of the world-space BVH
-    uint32_t stack8;             // 64-bit stack entries a lane can need
-    uint32_t stage8_mid;         // kernel 4 stages [stage2_begin, stage8_mid) and [off_n8, off_n8 + 80 * n_nodes8) into LDS
-    uint32_t n_inst2;            // instances (object-space BVHs under a Transform)
-    uint32_t max_inst_nodes2;    // Node2 count of the largest instance BVH
 };
 
 }  // namespace rtamd

@@ -136,12 +136,6 @@ struct Acc {  // typed views into the blob (LDS or global; the address space is 
     uint32_t root2;
     const uint2* lights;     // {NK_SPHERE | NK_RECT_XZ, payload}
     uint32_t n_lights;
-    // wide accel (kernel 4)
-    const uint4* n8;         // 5 x uint4 per Node8
-    const uint4* n8_top;     // LDS copy of the first n8_top_count Node8 when the scene itself is not in LDS
-    uint32_t n8_top_count;
-    const uint2* inst8;      // {xform, root Node8}
-    uint32_t root8;
 };
 template <class P>
 DEV Acc make_acc(P hot, const char* gbase, const FlatView& v) {  // hot: LDS copy or the global blob; cold part always global
@@ -170,11 +164,6 @@ DEV Acc make_acc(P hot, const char* gbase, const FlatView& v) {  // hot: LDS cop
     a.root2 = v.root2;
     a.lights = (const uint2*)(gbase + v.off_lights);
     a.n_lights = v.n_lights;
-    a.n8 = (const uint4*)(hot + v.off_n8);
-    a.n8_top = nullptr;
-    a.n8_top_count = 0;
-    a.inst8 = (const uint2*)(hot + v.off_inst8);
-    a.root8 = v.root8;
     return a;
 }
 
@@ -191,7 +180,7 @@ struct RenderK {
     int tiles_x, rank, world;
     int chunk_spp;  // sample-buffer stride
     const double* sppm_est;  // INTEG 2: per pixel {caustic estimate[3], global estimate[3]}, index y*width + x
-    int n_top;               // kernels 2 / 4 with the scene in L2/HBM: number of (depth-sorted) Node2 / Node8 cached in LDS
+    int n_top;               // kernel 2 with the scene in L2/HBM: number of (depth-sorted) Node2 cached in LDS
 };
 
 // ------------------------------------------------------ intersection ------
@@ -406,10 +395,8 @@ DEV bool box32(float lox, float loy, float loz, float hix, float hiy, float hiz,
 // "while-while" form (all lanes descend inner nodes until each holds a leaf, then all test leaves).
 // Primitive tests, ranges and the tie rule are the reference's (see traverse<> above); only the order in which
 // primitives are met differs, which cannot change the result.
-// DEFER (cooperative kernel): an instance item is not entered; its index is recorded in *pend and its object-space BVH is
-// traversed later, by whichever wave serves the workgroup's request queue (coop_serve), starting from this walk's result.
-template <bool GENERAL, bool DEFER = false>
-DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, double t_min, double t_max, uint32_t* pend = nullptr) {
+template <bool GENERAL>
+DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, double t_min, double t_max) {
     D3 o = wo, d = wd;
     D3 inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
     double a = sqlen(d);
@@ -470,8 +457,6 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
                     } else if (kind == NK_TRI) {
                         double b1, b2;
                         got = tri_hit(A.tripre2 + 5 * (first + i), o, d, t_min, h.t, t, b1, b2);
-                    } else if (DEFER) {  // NK_INSTANCE, deferred (at most 32 instances, checked on the host)
-                        *pend |= 1u << pl;
                     } else {  // NK_INSTANCE: descend into its object-space BVH after the remaining items
                         enter = pl;
                     }
@@ -485,7 +470,7 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
                     r.best = ray32_best(t);
                 }
             }
-            if (GENERAL && !DEFER && enter != REF_DONE) {  // Transform::hit, transform.rs:153-156
+            if (GENERAL && enter != REF_DONE) {  // Transform::hit, transform.rs:153-156
                 uint2 in = A.inst2[enter];
                 const double* Minv = A.xforms + 32 * in.x;
                 o = xf_point(Minv, wo);
@@ -512,178 +497,6 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
             cur = stk[sp];
         } else {
             cur = REF_DONE;
-        }
-    }
-    return h;
-}
-
-// ---------------------------------------------------------------- kernel 4 traversal ----
-// Closest hit through the wide accel (common/flat.h "Wide accel"): 8-ary nodes with 8-bit quantised child planes.
-// A child plane is decoded with ONE fma, lo = fl(q * s + o): q <= 255 and s = 2^e make the product exact, and the host
-// builder has checked with this very fma that lo <= (exact box min - pad) and hi >= (exact box max + pad).  The decoded
-// box therefore satisfies box32's hypothesis exactly as a stored Node2 box does, and the proof above box32 applies verbatim.
-// Everything else -- f64 primitive tests, inclusive ranges, the tie rule via `order` -- is traverse2's.
-// Per-lane stack of 64-bit entries in LDS: node groups {first inner child | remaining children in visit order, imask},
-// item groups {item_base, item mask} (only when an instance is entered with items of its node still pending) and the
-// restore-world marker.  "while-while": lanes visit nodes until each holds an item group, then all test items.
-DEV uint32_t ray_octant(const Ray32& r) { return (r.ix < 0.f ? 1u : 0u) | (r.iy < 0.f ? 2u : 0u) | (r.iz < 0.f ? 4u : 0u); }
-// hit-child mask from slot space to visit-order space: bit k of the result = bit (k ^ oct) of m (three conditional swaps)
-DEV uint32_t xor_permute8(uint32_t m, uint32_t oct) {
-    uint32_t t;
-    t = (m ^ (m >> 1)) & ((oct & 1u) ? 0x55u : 0u); m ^= t | (t << 1);
-    t = (m ^ (m >> 2)) & ((oct & 2u) ? 0x33u : 0u); m ^= t | (t << 2);
-    t = (m ^ (m >> 4)) & ((oct & 4u) ? 0x0Fu : 0u); m ^= t | (t << 4);
-    return m;
-}
-DEV float ubyte_f32(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xffu); }  // v_cvt_f32_ubyteK
-DEV D3 rcp3(D3 d) { return mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z); }
-
-template <bool GENERAL>
-DEV Hit traverse8(const Acc& A, uint2* stk, const int stride, D3 wo, D3 wd, double t_min, double t_max) {
-    D3 o = wo, d = wd;
-    double a = sqlen(d);
-    Hit h;
-    h.t = t_max;
-    h.node = -1;
-    h.xf = -1;
-    h.kp = 0;
-    int cur_xf = -1;
-    Ray32 r = make_ray32(o, rcp3(d), t_min, t_max);
-    uint32_t oct = ray_octant(r);
-    int sp = 0;                        // stack offset in entries (a multiple of stride)
-    uint32_t cur = A.root8;            // Node8 to visit, or NODE8_NONE
-    uint32_t ibase = 0, imask = 0;     // pending item group
-    for (;;) {
-        // ---- nodes: until this lane holds an item group or has nothing left ----
-        for (;;) {
-            if (cur == NODE8_NONE) {
-                if (imask != 0u || sp == 0) break;
-                sp -= stride;
-                const uint2 e = stk[sp];
-                const uint32_t tag = e.x >> 30;
-                if (tag == ST8_NODES) {  // next child of a node group, in visit order
-                    uint32_t km = e.y & 0xffu;
-                    const uint32_t im = (e.y >> 8) & 0xffu;
-                    const uint32_t slot = (uint32_t)(__ffs((int)km) - 1) ^ oct;
-                    km &= km - 1u;
-                    cur = (e.x & 0x3fffffffu) + (uint32_t)__popc(im & ((1u << slot) - 1u));
-                    if (km != 0u) {
-                        stk[sp] = make_uint2(e.x, (e.y & ~0xffu) | km);
-                        sp += stride;
-                    }
-                } else if (tag == ST8_ITEMS) {
-                    ibase = e.x & 0x3fffffffu;
-                    imask = e.y;
-                    break;
-                } else {  // ST8_RESTORE: leave the Transform
-                    o = wo;
-                    d = wd;
-                    a = sqlen(d);
-                    cur_xf = -1;
-                    r = make_ray32(o, rcp3(d), t_min, h.t);
-                    oct = ray_octant(r);
-                    continue;
-                }
-            }
-            uint4 w0, w1, w2, w3, w4;
-            if (cur < A.n8_top_count) {  // the shallowest levels are cached in LDS when the scene lives in L2/HBM
-                const uint4* p = A.n8_top + NODE8_U4 * cur;
-                w0 = p[0]; w1 = p[1]; w2 = p[2]; w3 = p[3]; w4 = p[4];
-            } else {
-                const uint4* p = A.n8 + NODE8_U4 * cur;
-                w0 = p[0]; w1 = p[1]; w2 = p[2]; w3 = p[3]; w4 = p[4];
-            }
-            const float ox = __uint_as_float(w0.x), oy = __uint_as_float(w0.y), oz = __uint_as_float(w0.z);
-            const float sx = __uint_as_float((w0.w & 0xffu) << 23), sy = __uint_as_float(((w0.w >> 8) & 0xffu) << 23),
-                        sz = __uint_as_float(((w0.w >> 16) & 0xffu) << 23);
-            uint32_t hits = 0;
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const int k = i & 3;
-                const uint32_t qlx = (i < 4) ? w2.x : w2.y, qly = (i < 4) ? w2.z : w2.w, qlz = (i < 4) ? w3.x : w3.y;
-                const uint32_t qhx = (i < 4) ? w3.z : w3.w, qhy = (i < 4) ? w4.x : w4.y, qhz = (i < 4) ? w4.z : w4.w;
-                const float lox = __builtin_fmaf(ubyte_f32(qlx, k), sx, ox), loy = __builtin_fmaf(ubyte_f32(qly, k), sy, oy),
-                            loz = __builtin_fmaf(ubyte_f32(qlz, k), sz, oz);
-                const float hix = __builtin_fmaf(ubyte_f32(qhx, k), sx, ox), hiy = __builtin_fmaf(ubyte_f32(qhy, k), sy, oy),
-                            hiz = __builtin_fmaf(ubyte_f32(qhz, k), sz, oz);
-                float entry;
-                if (box32(lox, loy, loz, hix, hiy, hiz, r, entry)) hits |= 1u << i;
-            }
-            const uint32_t im = w0.w >> 24, lm = w1.x >> 24, cb = w1.x & 0xffffffu;
-            uint32_t lh = hits & lm;
-            uint32_t m = 0;
-            while (lh != 0u) {  // items of the leaf children that were hit
-                const uint32_t sl = (uint32_t)(__ffs((int)lh) - 1);
-                lh &= lh - 1u;
-                const uint32_t mt = (((sl < 4u) ? w1.z : w1.w) >> (8u * (sl & 3u))) & 0xffu;
-                m |= ((1u << (mt >> 5)) - 1u) << (mt & 31u);
-            }
-            uint32_t km = xor_permute8(hits & im, oct);
-            cur = NODE8_NONE;
-            if (m != 0u) {  // test this node's items first (they shrink the range), then its inner children
-                if (km != 0u) {
-                    stk[sp] = make_uint2(cb | (ST8_NODES << 30), km | (im << 8));
-                    sp += stride;
-                }
-                ibase = w1.y;
-                imask = m;
-                break;
-            }
-            if (km != 0u) {
-                const uint32_t slot = (uint32_t)(__ffs((int)km) - 1) ^ oct;
-                km &= km - 1u;
-                cur = cb + (uint32_t)__popc(im & ((1u << slot) - 1u));
-                if (km != 0u) {
-                    stk[sp] = make_uint2(cb | (ST8_NODES << 30), km | (im << 8));
-                    sp += stride;
-                }
-            }
-        }
-        if (imask == 0u && cur == NODE8_NONE) break;  // stack empty
-        // ---- items: the reference's f64 primitive tests ----
-        while (imask != 0u) {
-            const uint32_t idx = ibase + (uint32_t)(__ffs((int)imask) - 1);
-            imask &= imask - 1u;
-            const uint2 it = A.items2[idx];
-            const uint32_t kind = it.x & NK_MASK, pl = it.x >> NK_BITS;
-            double t = 0.;
-            bool got = false;
-            if (kind == NK_SPHERE) {
-                got = sphere_hit(A.spheres + 2 * pl, o, d, a, t_min, h.t, t);
-            } else if (GENERAL) {
-                if (kind == NK_RECT_YZ || kind == NK_RECT_XZ || kind == NK_RECT_XY) {
-                    got = rect_hit(A.rects + 3 * pl, (int)kind - (int)NK_RECT_YZ, o, d, t_min, h.t, t);
-                } else if (kind == NK_TRI) {
-                    double b1, b2;
-                    got = tri_hit(A.tripre2 + 5 * idx, o, d, t_min, h.t, t, b1, b2);
-                } else {  // NK_INSTANCE: Transform::hit, transform.rs:153-156 ; the node's remaining items wait on the stack
-                    if (imask != 0u) {
-                        stk[sp] = make_uint2(ibase | (ST8_ITEMS << 30), imask);
-                        sp += stride;
-                        imask = 0u;
-                    }
-                    stk[sp] = make_uint2(ST8_RESTORE << 30, 0u);
-                    sp += stride;
-                    const uint2 in = A.inst8[pl];
-                    const double* Minv = A.xforms + 32 * in.x;
-                    o = xf_point(Minv, wo);
-                    d = xf_dir(Minv, wd);
-                    a = sqlen(d);
-                    cur_xf = (int)in.x;
-                    r = make_ray32(o, rcp3(d), t_min, h.t);
-                    oct = ray_octant(r);
-                    cur = in.y;
-                    break;
-                }
-            }
-            // accepted candidates satisfy t <= h.t; an exact tie goes to the later one in reference order
-            if (got && (t < h.t || (int)it.y > h.node || !(t == t))) {
-                h.t = t;
-                h.node = (int)it.y;
-                h.xf = cur_xf;
-                h.kp = it.x;
-                r.best = ray32_best(t);
-            }
         }
     }
     return h;
@@ -934,10 +747,10 @@ template <bool LDS, bool GENERAL, int ACCEL, int INTEG>
 __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, RenderK rk, double* __restrict__ samples,
                                                       unsigned int* __restrict__ counter, int* __restrict__ err) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // LDS map: [staged scene tables (LDS variants) | top-of-BVH node cache (scene in L2/HBM)] [kernels 2 / 4: per-lane
-    // traversal stacks, stack2 x blockDim 32-bit words / stack8 x blockDim 64-bit entries]
-    const uint32_t st_begin = (ACCEL >= 2) ? sv.stage2_begin : 0u;
-    const uint32_t st_end = (ACCEL == 4) ? sv.stage8_mid : (ACCEL == 2) ? sv.stage2_end : sv.stage_bytes;
+    // LDS map: [staged scene tables (LDS variants) | top-of-BVH Node2 cache (scene in L2/HBM)] [kernel 2: per-lane
+    // traversal stacks, stack2 x blockDim 32-bit words]
+    const uint32_t st_begin = (ACCEL == 2) ? sv.stage2_begin : 0u;
+    const uint32_t st_end = (ACCEL == 2) ? sv.stage2_end : sv.stage_bytes;
     uint32_t staged = 0;  // bytes of LDS in front of the stacks
     Acc A;
     if (LDS) {
@@ -945,15 +758,8 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
         uint4* dst = (uint4*)smem;
         for (uint32_t i = threadIdx.x; i < (st_end - st_begin) / 16; i += blockDim.x) dst[i] = src[i];
         staged = st_end - st_begin;
-        A = make_acc(smem - st_begin, sv.base, sv);
-        if (ACCEL == 4) {  // second range: the Node8 array (the Node2 array lies between the two in the blob and is not needed)
-            const uint4* src8 = (const uint4*)(sv.base + sv.off_n8);
-            uint4* dst8 = (uint4*)(smem + staged);
-            for (uint32_t i = threadIdx.x; i < sv.n_nodes8 * NODE8_U4; i += blockDim.x) dst8[i] = src8[i];
-            A.n8 = (const uint4*)(smem + staged);
-            staged += sv.n_nodes8 * (uint32_t)sizeof(Node8);
-        }
         __syncthreads();
+        A = make_acc(smem - st_begin, sv.base, sv);
     } else {
         A = make_acc(sv.base, sv.base, sv);
         if (ACCEL == 2 && rk.n_top > 0) {  // scene in L2/HBM: the shallowest levels of every BVH (depth-sorted array) in LDS
@@ -965,18 +771,8 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
             A.n2_top_count = (uint32_t)rk.n_top;
             staged = (uint32_t)rk.n_top * (uint32_t)sizeof(Node2);
         }
-        if (ACCEL == 4 && rk.n_top > 0) {
-            const uint4* src = (const uint4*)(sv.base + sv.off_n8);
-            uint4* dst = (uint4*)smem;
-            for (uint32_t i = threadIdx.x; i < (uint32_t)rk.n_top * NODE8_U4; i += blockDim.x) dst[i] = src[i];
-            __syncthreads();
-            A.n8_top = (const uint4*)smem;
-            A.n8_top_count = (uint32_t)rk.n_top;
-            staged = (uint32_t)rk.n_top * (uint32_t)sizeof(Node8);
-        }
     }
     uint32_t* stk = (uint32_t*)(smem + staged) + threadIdx.x;
-    uint2* stk8 = (uint2*)(smem + staged) + threadIdx.x;
     const int stk_stride = (int)blockDim.x;
     const int lane = threadIdx.x & 63;
     const uint64_t lanemask_lt = (1ull << lane) - 1ull;
@@ -1051,10 +847,8 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
             }
             // ---- one path segment: sample_ray's loop body, photon_mapper.rs:335-362 ----
             if (alive) {
-                Hit h;
-                if (ACCEL == 4) h = traverse8<GENERAL>(A, stk8, stk_stride, o, d, rk.t_min, INFINITY);
-                else if (ACCEL == 2) h = traverse2<GENERAL>(A, stk, stk_stride, o, d, rk.t_min, INFINITY);
-                else h = traverse<GENERAL>(A, o, d, rk.t_min, INFINITY);
+                Hit h = (ACCEL == 2) ? traverse2<GENERAL>(A, stk, stk_stride, o, d, rk.t_min, INFINITY)
+                                     : traverse<GENERAL>(A, o, d, rk.t_min, INFINITY);
                 bool done = true;
                 if (h.node >= 0 && depth > 0) {  // Q12: depth test after the hit, before emission
                     depth -= 1;
@@ -1094,541 +888,6 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
     }
 }
 
-
-// ------------------------------------------------------- pt_kernel_coop ---
-// Path tracer for scenes whose mesh instances are LARGE (object-space BVHs far outside LDS; BASELINE config C4).
-// Measured on the plain kernel (profiles/r02/pmc_c4_before_bvh2.csv): the VALU is 76 % busy at 15 % lane utilisation --
-// the third of a wave's rays that reach the instance walk 35..100 dependent steps while the other lanes wait, and the
-// wave pays every instruction at full price.  The fix is to re-pack those rays ACROSS the waves of a workgroup, and to
-// have more paths in flight than lanes so that no lane ever waits:
-//   * a lane walks the world-space BVH to the end with instance items DEFERRED (traverse2<.., DEFER>: a bit per instance);
-//   * a path with a deferred instance is PARKED: its whole state plus the request -- object-space ray (Transform::hit's
-//     M^-1 * ray, transform.rs:153-156), best t and tie-break order so far, root of the instance's BVH -- goes to a slot of
-//     a per-workgroup pool in global memory (written through to L2), the slot id to the request ring RQ in LDS, and the
-//     lane is free again (it adopts an answered path or generates a new one);
-//   * when a wave's worth of requests waits, a wave SERVES: 64 lanes take 64 requests, walk the object-space BVH and refill
-//     from RQ as lanes finish (coop_serve), so the long walks run in dense waves; answers go to the slot, its id to the
-//     answer ring AQ;
-//   * free lanes ADOPT answered paths: state back into registers, answer merged with the reference's acceptance rule
-//     (smaller t, or equal t and later in reference order) -- what the inline walk does when it reaches the instance last.
-// What a path computes is unchanged: every primitive still sees the reference's f64 test with [t_min, best-so-far], the
-// closest hit does not depend on the order in which candidates are met (tie rule by `order`), RNG streams belong to the
-// path, and a finished path stores its sample to its own slot.  Images are bit-identical to kernels 1 and 2.
-#ifndef COOP_POOL
-#define COOP_POOL 2048     // parked paths per workgroup (power of two)
-#endif
-#ifndef COOP_BATCH
-#define COOP_BATCH 64      // a wave starts serving once this many requests wait
-#endif
-#ifndef COOP_REFILL_TH
-#define COOP_REFILL_TH 48  // a serving wave goes back for more requests when fewer lanes than this still walk
-#endif
-#ifndef COOP_ADOPT_MIN
-#define COOP_ADOPT_MIN 8   // free lanes a wave needs before it adopts / regenerates (as REGEN_MIN)
-#endif
-static const int COOP_MAX_INST = 32;    // one pending bit per instance
-static const int COOP_REC = 26;         // u64 per pool slot:
-//   request  [0..5] object-space ray o, d   [6] best t so far   [7] root of the instance BVH << 32 | order of the best hit so far
-//            [8] (xform of the best hit so far + 1) << 32 | depth << 8 | instance index
-//   answer   [9] t   [10] kind|payload << 32 | order     (order unchanged = nothing closer inside the instance)
-//   path     [11..16] o, d (world)   [17..19] beta   [20..22] L   [23] rng   [24] kind|payload of the best hit so far << 32 | pix_id
-//            [25] instances still deferred << 32 | out_slot
-
-#ifdef RTAMD_COOP_STATS  // tools-only build (tools/build_variant.sh stats -DRTAMD_COOP_STATS): schedule counters of pt_kernel_coop
-__device__ unsigned long long g_coop_stats[16];
-struct CoopStats {
-    unsigned long long ev[6] = {0, 0, 0, 0, 0, 0}, ln[6] = {0, 0, 0, 0, 0, 0};
-};
-#define COOP_STATS_ARG , CoopStats& cs
-#define COOP_STATS_PASS , cs
-#define COOP_STAT(i, lanes_mask)                                        \
-    do {                                                                \
-        cs.ev[i] += 1ull;                                               \
-        cs.ln[i] += (unsigned long long)__popcll(lanes_mask);           \
-    } while (0)
-#else
-#define COOP_STATS_ARG
-#define COOP_STATS_PASS
-#define COOP_STAT(i, lanes_mask) \
-    do {                         \
-    } while (0)
-#endif
-
-struct CoopRing {  // multi-producer multi-consumer ring of slot ids in LDS; entries are id + 1, 0 = not yet written
-    volatile uint32_t* buf;
-    uint32_t* ht;  // {head, tail}: monotonic counters
-};
-DEV uint64_t ld_sc1(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }  // L2, never this CU's L1
-DEV uint32_t lds_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-DEV uint32_t ring_len(const CoopRing& R) { return lds_load(&R.ht[1]) - lds_load(&R.ht[0]); }
-// push the ids of the flagged lanes; `drain`: their records were just stored and must be in L2 before the ids are visible
-DEV void ring_push(const CoopRing& R, bool push, uint32_t id, int lane, uint64_t lanemask_lt, bool drain) {
-    const uint64_t m = __ballot(push);
-    if (m == 0ull) return;
-    const int leader = __ffsll((long long)m) - 1;
-    uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(&R.ht[1], (uint32_t)__popcll(m));
-    base = __shfl(base, leader);
-    if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (push) R.buf[(base + (uint32_t)__popcll(m & lanemask_lt)) & (COOP_POOL - 1)] = id + 1u;
-}
-// pop up to popcount(want) ids; lanes of `want` that get one return it, the others return -1
-DEV int ring_pop(const CoopRing& R, uint64_t want, int lane, uint64_t lanemask_lt) {
-    if (want == 0ull) return -1;
-    uint32_t h0 = 0, k = 0;
-    if (lane == 0) {
-        for (;;) {
-            const uint32_t hd = lds_load(&R.ht[0]), tl = lds_load(&R.ht[1]);
-            if (hd == tl) break;
-            const uint32_t n = min((uint32_t)__popcll(want), tl - hd);
-            if (atomicCAS(&R.ht[0], hd, hd + n) == hd) {
-                h0 = hd;
-                k = n;
-                break;
-            }
-        }
-    }
-    h0 = __builtin_amdgcn_readfirstlane(h0);
-    k = __builtin_amdgcn_readfirstlane(k);
-    const int rank = __popcll(want & lanemask_lt);
-    int id = -1;
-    if (((want >> lane) & 1ull) != 0ull && rank < (int)k) {
-        const uint32_t slot = (h0 + (uint32_t)rank) & (COOP_POOL - 1);
-        uint32_t v;
-        do { v = R.buf[slot]; } while (v == 0u);  // its producer reserved the slot and writes it within a few instructions
-        R.buf[slot] = 0u;
-        id = (int)v - 1;
-    }
-    return id;
-}
-
-struct CoopLds {
-    CoopRing rq, aq, fq;  // requests, answers, free pool slots
-    uint32_t* n_parked;   // paths currently in the pool
-};
-
-// One while-while pass of the object-space walk for the lanes with `act`: descend to a leaf, test its items (traverse2's
-// node and leaf steps; no instances below an instance).  cur == REF_DONE afterwards means the walk is complete.
-DEV void blas_pass(const Acc& A, bool act, uint32_t* stk, const int stride, D3 o, D3 d, double a, double t_min, Ray32& r, double& ht, int& hnode,
-                   uint32_t& hkp, uint32_t& cur, int& sp, int* err) {
-    while (act && (cur >> REF_TAG_SHIFT) == 0u) {  // inner node: both children, conservative f32 boxes
-        float4 q0, q1, q2, q3;
-        if (cur < A.n2_top_count) {
-            const float4* p = A.n2_top + NODE2_F4 * cur;
-            q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
-        } else {
-            const float4* p = A.n2 + NODE2_F4 * cur;
-            q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
-        }
-        float e0, e1;
-        const bool h0 = box32(q0.x, q0.z, q1.x, q1.z, q2.x, q2.z, r, e0);
-        const bool h1 = box32(q0.y, q0.w, q1.y, q1.w, q2.y, q2.w, r, e1);
-        const uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
-        if (h0 && h1) {
-            const bool swap = e1 < e0;
-            stk[sp] = swap ? c0 : c1;
-            sp += stride;
-            cur = swap ? c1 : c0;
-        } else if (h0) {
-            cur = c0;
-        } else if (h1) {
-            cur = c1;
-        } else if (sp > 0) {
-            sp -= stride;
-            cur = stk[sp];
-        } else {
-            cur = REF_DONE;
-        }
-    }
-    if (act && cur != REF_DONE) {  // leaf: the reference's f64 primitive tests (tie rule as in traverse2)
-        const uint32_t first = cur & REF_LEAF_FIRST_MASK, cnt = ((cur >> REF_LEAF_COUNT_SHIFT) & 7u) + 1u;
-        for (uint32_t i = 0; i < cnt; i++) {
-            const uint2 it = A.items2[first + i];
-            const uint32_t kind = it.x & NK_MASK, pl = it.x >> NK_BITS;
-            double t = 0.;
-            bool got = false;
-            if (kind == NK_SPHERE) {
-                got = sphere_hit(A.spheres + 2 * pl, o, d, a, t_min, ht, t);
-            } else if (kind == NK_RECT_YZ || kind == NK_RECT_XZ || kind == NK_RECT_XY) {
-                got = rect_hit(A.rects + 3 * pl, (int)kind - (int)NK_RECT_YZ, o, d, t_min, ht, t);
-            } else if (kind == NK_TRI) {
-                double b1, b2;
-                got = tri_hit(A.tripre2 + 5 * (first + i), o, d, t_min, ht, t, b1, b2);
-            } else {
-                atomicOr(err, 2);  // an instance below an instance: flatten.cpp refuses such scenes
-            }
-            if (got && (t < ht || (int)it.y > hnode || !(t == t))) {
-                ht = t;
-                hnode = (int)it.y;
-                hkp = it.x;
-                r.best = ray32_best(t);
-            }
-        }
-        if (sp > 0) {
-            sp -= stride;
-            cur = stk[sp];
-        } else {
-            cur = REF_DONE;
-        }
-    }
-}
-
-// Serve the request ring with this wave until it is empty and every taken request is answered.
-DEV void coop_serve(const CoopLds& C, const Acc& A, uint32_t* stk, const int stride, uint64_t* pool, double t_min, int lane, uint64_t lanemask_lt,
-                    int* err COOP_STATS_ARG) {
-    int rid = -1;
-    D3 o = mk(0, 0, 0), d = mk(0, 0, 1);
-    double a = 1.;
-    Ray32 r = make_ray32(o, mk(1, 1, 1), t_min, 0.);
-    double ht = 0.;
-    int hnode = -1;
-    uint32_t hkp = 0, cur = REF_DONE;
-    int sp = 0;
-    for (;;) {
-        // ---- refill: idle lanes take requests ----
-        const int got = ring_pop(C.rq, __ballot(rid < 0), lane, lanemask_lt);
-        if (got >= 0) {
-            rid = got;
-            const uint64_t* q = pool + (size_t)COOP_REC * (size_t)rid;
-            o = mk(__longlong_as_double(ld_sc1(q + 0)), __longlong_as_double(ld_sc1(q + 1)), __longlong_as_double(ld_sc1(q + 2)));
-            d = mk(__longlong_as_double(ld_sc1(q + 3)), __longlong_as_double(ld_sc1(q + 4)), __longlong_as_double(ld_sc1(q + 5)));
-            ht = __longlong_as_double(ld_sc1(q + 6));
-            const uint64_t w7 = ld_sc1(q + 7);
-            hnode = (int)(uint32_t)w7;
-            cur = (uint32_t)(w7 >> 32);
-            hkp = 0u;
-            sp = 0;
-            a = sqlen(d);
-            r = make_ray32(o, rcp3(d), t_min, ht);
-        }
-        if (__ballot(rid >= 0) == 0ull) return;
-        COOP_STAT(0, __ballot(rid >= 0));  // serve rounds: lanes holding a request at the start of a round
-        for (;;) {
-            COOP_STAT(1, __ballot(rid >= 0));  // serve passes: busy lanes
-            blas_pass(A, rid >= 0, stk, stride, o, d, a, t_min, r, ht, hnode, hkp, cur, sp, err);
-            const bool fin = rid >= 0 && cur == REF_DONE;
-            if (fin) {
-                uint64_t* w = pool + (size_t)COOP_REC * (size_t)rid + 9;
-                w[0] = __double_as_longlong(ht);
-                w[1] = ((uint64_t)hkp << 32) | (uint64_t)(uint32_t)hnode;
-            }
-            ring_push(C.aq, fin, (uint32_t)rid, lane, lanemask_lt, true);
-            if (fin) rid = -1;
-            const int busy = __popcll(__ballot(rid >= 0));
-            if (busy == 0) break;
-            if (busy < COOP_REFILL_TH && ring_len(C.rq) != 0u) break;  // more requests wait: refill the idle lanes
-        }
-    }
-}
-
-template <bool LDS, int INTEG>
-__global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam, RenderK rk, double* __restrict__ samples,
-                                                           unsigned int* __restrict__ counter, int* __restrict__ err, uint64_t* coop) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    // LDS map: [staged tables | top-of-BVH Node2 cache][stacks: stack2 x PT_BLOCK words][RQ, AQ, FQ: COOP_POOL words each][8 counters]
-    const uint32_t st_begin = sv.stage2_begin, st_end = sv.stage2_end;
-    uint32_t staged = 0;
-    Acc A;
-    if (LDS) {
-        const uint4* src = (const uint4*)(sv.base + st_begin);
-        uint4* dst = (uint4*)smem;
-        for (uint32_t i = threadIdx.x; i < (st_end - st_begin) / 16; i += blockDim.x) dst[i] = src[i];
-        staged = st_end - st_begin;
-        A = make_acc(smem - st_begin, sv.base, sv);
-    } else {
-        A = make_acc(sv.base, sv.base, sv);
-        if (rk.n_top > 0) {
-            const uint4* src = (const uint4*)(sv.base + sv.off_n2);
-            uint4* dst = (uint4*)smem;
-            for (uint32_t i = threadIdx.x; i < (uint32_t)rk.n_top * NODE2_F4; i += blockDim.x) dst[i] = src[i];
-            A.n2_top = (const float4*)smem;
-            A.n2_top_count = (uint32_t)rk.n_top;
-            staged = (uint32_t)rk.n_top * (uint32_t)sizeof(Node2);
-        }
-    }
-    uint32_t* stk = (uint32_t*)(smem + staged) + threadIdx.x;
-    const int stk_stride = (int)blockDim.x;
-    uint32_t* coop_base = (uint32_t*)(smem + staged) + (size_t)sv.stack2 * PT_BLOCK;
-    CoopLds C;
-    C.rq.buf = coop_base;
-    C.aq.buf = coop_base + COOP_POOL;
-    C.fq.buf = coop_base + 2 * COOP_POOL;
-    uint32_t* cnt = coop_base + 3 * COOP_POOL;
-    C.rq.ht = cnt;
-    C.aq.ht = cnt + 2;
-    C.fq.ht = cnt + 4;
-    C.n_parked = cnt + 6;
-    for (uint32_t i = threadIdx.x; i < (uint32_t)COOP_POOL; i += blockDim.x) {
-        C.rq.buf[i] = 0u;
-        C.aq.buf[i] = 0u;
-        C.fq.buf[i] = i + 1u;  // every pool slot is free
-    }
-    if (threadIdx.x < 8) cnt[threadIdx.x] = (threadIdx.x == 5) ? (uint32_t)COOP_POOL : 0u;  // FQ tail = COOP_POOL
-    __syncthreads();
-    const int lane = threadIdx.x & 63;
-    const uint64_t lanemask_lt = (1ull << lane) - 1ull;
-    uint64_t* pool_mem = coop + (size_t)blockIdx.x * COOP_POOL * COOP_REC;
-
-    int lt = 0, tx = 0, ty = 0, s0 = 0, pool = 0, next = 0;
-    bool more_units = true;
-
-    bool alive = false;   // the lane holds a path
-    bool ready = false;   // ... whose closest hit is known (shade next); otherwise it needs its world-space walk
-    D3 o = mk(0, 0, 0), d = mk(0, 0, 1), beta = mk(1, 1, 1), L = mk(0, 0, 0);
-    int depth = 0, pix_id = 0;
-    uint32_t out_slot = 0, pend = 0u;
-    Rng rng;
-    rng.s = 0;
-    Hit h;
-    h.t = INFINITY; h.node = -1; h.xf = -1; h.kp = 0;
-#ifdef RTAMD_COOP_STATS
-    CoopStats cs;
-#endif
-
-    for (;;) {
-        // ---- free lanes: adopt answered paths first, then generate new ones ----
-        uint64_t dead = __ballot(!alive);
-        if ((int)__popcll(dead) < COOP_ADOPT_MIN && dead != ~0ull) dead = 0ull;
-        if (dead != 0ull && ring_len(C.aq) != 0u) {
-            const int id = ring_pop(C.aq, dead, lane, lanemask_lt);
-            bool repost = false, freed = false;
-            if (id >= 0) {
-                uint64_t* q = pool_mem + (size_t)COOP_REC * (size_t)id;
-                const uint64_t w8 = ld_sc1(q + 8), w10 = ld_sc1(q + 10), w25 = ld_sc1(q + 25);
-                const uint32_t inst = (uint32_t)w8 & 0xffu;
-                depth = (int)(((uint32_t)w8 >> 8) & 0xffffffu);
-                h.t = __longlong_as_double(ld_sc1(q + 6));  // best hit before this instance: as posted
-                h.node = (int)(uint32_t)ld_sc1(q + 7);
-                h.xf = (int)(uint32_t)(w8 >> 32) - 1;
-                h.kp = (uint32_t)(ld_sc1(q + 24) >> 32);
-                if ((int)(uint32_t)w10 != h.node) {  // the walk accepted a candidate of this instance
-                    h.t = __longlong_as_double(ld_sc1(q + 9));
-                    h.node = (int)(uint32_t)w10;
-                    h.kp = (uint32_t)(w10 >> 32);
-                    h.xf = (int)A.inst2[inst].x;
-                }
-                pend = (uint32_t)(w25 >> 32);
-                out_slot = (uint32_t)w25;
-                o = mk(__longlong_as_double(ld_sc1(q + 11)), __longlong_as_double(ld_sc1(q + 12)), __longlong_as_double(ld_sc1(q + 13)));
-                d = mk(__longlong_as_double(ld_sc1(q + 14)), __longlong_as_double(ld_sc1(q + 15)), __longlong_as_double(ld_sc1(q + 16)));
-                if (pend != 0u) {  // next deferred instance of the same segment: the path stays parked, new request
-                    const uint32_t ni = (uint32_t)(__ffs((int)pend) - 1);
-                    pend &= pend - 1u;
-                    const uint2 in = A.inst2[ni];
-                    const double* Minv = A.xforms + 32 * in.x;
-                    const D3 oo = xf_point(Minv, o), dd = xf_dir(Minv, d);
-                    q[0] = __double_as_longlong(oo.x); q[1] = __double_as_longlong(oo.y); q[2] = __double_as_longlong(oo.z);
-                    q[3] = __double_as_longlong(dd.x); q[4] = __double_as_longlong(dd.y); q[5] = __double_as_longlong(dd.z);
-                    q[6] = __double_as_longlong(h.t);
-                    q[7] = ((uint64_t)in.y << 32) | (uint64_t)(uint32_t)h.node;
-                    q[8] = ((uint64_t)(uint32_t)(h.xf + 1) << 32) | (uint64_t)(((uint32_t)depth << 8) | ni);
-                    const uint64_t w24 = ld_sc1(q + 24);
-                    q[24] = ((uint64_t)h.kp << 32) | (uint64_t)(uint32_t)w24;
-                    q[25] = ((uint64_t)pend << 32) | (uint64_t)out_slot;
-                    repost = true;
-                } else {
-                    beta = mk(__longlong_as_double(ld_sc1(q + 17)), __longlong_as_double(ld_sc1(q + 18)), __longlong_as_double(ld_sc1(q + 19)));
-                    L = mk(__longlong_as_double(ld_sc1(q + 20)), __longlong_as_double(ld_sc1(q + 21)), __longlong_as_double(ld_sc1(q + 22)));
-                    rng.s = ld_sc1(q + 23);
-                    pix_id = (int)(uint32_t)ld_sc1(q + 24);
-                    alive = true;
-                    ready = true;
-                    freed = true;
-                }
-            }
-            ring_push(C.rq, repost, (uint32_t)id, lane, lanemask_lt, true);
-            {
-                const uint64_t mf = __ballot(freed);
-                if (mf != 0ull) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the slot's loads have returned before it can be reused
-                    if (lane == __ffsll((long long)mf) - 1) atomicSub(C.n_parked, (uint32_t)__popcll(mf));
-                }
-                ring_push(C.fq, freed, (uint32_t)id, lane, lanemask_lt, false);
-            }
-            dead = __ballot(!alive);
-            if ((int)__popcll(dead) < COOP_ADOPT_MIN && dead != ~0ull) dead = 0ull;
-        }
-        if (dead != 0ull && next >= pool && more_units) {
-            unsigned int unit = 0;
-            if (lane == 0) unit = atomicAdd(counter, 1u);
-            unit = __builtin_amdgcn_readfirstlane(unit);
-            if (unit >= (unsigned)rk.n_units) {
-                more_units = false;
-            } else {
-                lt = (int)(unit / (unsigned)rk.subs_per_tile);
-                const int sub_i = (int)(unit - (unsigned)lt * (unsigned)rk.subs_per_tile);
-                const int tile = lt * rk.world + rk.rank;
-                tx = tile % rk.tiles_x;
-                ty = tile / rk.tiles_x;
-                s0 = rk.s_begin + sub_i * rk.sub_spp;
-                const int s1 = min(s0 + rk.sub_spp, rk.s_end);
-                pool = (s1 - s0) * TILE_PIX;
-                next = 0;
-            }
-        }
-        if (dead != 0ull && next < pool) {
-            int k = next + __popcll(dead & lanemask_lt);
-            next = min(next + (int)__popcll(dead), pool);
-            if (!alive && k < pool) {
-                int pix = k & (TILE_PIX - 1), s = s0 + (k >> 6);
-                int x = tx * TILE_W + (pix & (TILE_W - 1)), y = ty * TILE_H + (pix >> 3);
-                if (x < rk.width && y < rk.height) {  // camera.rs:97-99 + Camera::get_ray camera.rs:57-64
-                    rng.seed_stream(rk.seed, (uint64_t)y * (uint64_t)rk.width + (uint64_t)x, (uint64_t)s);
-                    double u = ((double)x + rng.gen_f64()) / (double)(rk.width - 1);
-                    double v = ((double)y + rng.gen_f64()) / (double)(rk.height - 1);
-                    double stt = 1.0 - v;
-                    D3 rd = muls(random_in_unit_disk(rng), cam.lens_radius);
-                    D3 offset = add(muls(cam.u, rd.x), muls(cam.v, rd.y));
-                    o = add(cam.origin, offset);
-                    d = sub(sub(add(add(cam.llc, muls(cam.horizontal, u)), muls(cam.vertical, stt)), cam.origin), offset);
-                    beta = mk(1., 1., 1.);
-                    L = mk(0., 0., 0.);
-                    depth = rk.max_depth;
-                    pix_id = y * rk.width + x;
-                    out_slot = ((uint32_t)lt * (uint32_t)rk.chunk_spp + (uint32_t)(s - rk.s_begin)) * (uint32_t)TILE_PIX + (uint32_t)pix;
-                    alive = true;
-                    ready = false;
-                }
-            }
-        }
-        if (__ballot(alive) == 0ull) {
-            // nothing in registers: help with what the workgroup still has parked, or leave
-            const bool can_regen = next < pool || more_units;
-            if (can_regen) continue;
-            if (ring_len(C.aq) != 0u) continue;  // every lane is free: the adoption above takes them
-            if (ring_len(C.rq) != 0u) {
-                coop_serve(C, A, stk, stk_stride, pool_mem, rk.t_min, lane, lanemask_lt, err COOP_STATS_PASS);
-                continue;
-            }
-            if (lds_load(C.n_parked) == 0u) break;
-            COOP_STAT(5, 0ull);
-            __builtin_amdgcn_s_sleep(8);  // another wave is serving the last requests
-            continue;
-        }
-        // ---- world-space walk of the lanes that start a segment, instances deferred ----
-        if (__ballot(alive && !ready) != 0ull) COOP_STAT(2, __ballot(alive && !ready));
-        if (alive && !ready) {
-            pend = 0u;
-            h = traverse2<true, true>(A, stk, stk_stride, o, d, rk.t_min, INFINITY, &pend);
-            if (pend == 0u) ready = true;
-        }
-        // ---- park the paths with a deferred instance ----
-        {
-            const bool want = alive && !ready;
-            const uint64_t mw = __ballot(want);
-            if (mw != 0ull) {
-                const int id = ring_pop(C.fq, mw, lane, lanemask_lt);
-                const bool park = want && id >= 0;
-                COOP_STAT(4, __ballot(want && id < 0));  // parking attempts: lanes that found the pool exhausted
-                if (park) {
-                    const uint32_t ni = (uint32_t)(__ffs((int)pend) - 1);
-                    pend &= pend - 1u;
-                    const uint2 in = A.inst2[ni];
-                    const double* Minv = A.xforms + 32 * in.x;
-                    const D3 oo = xf_point(Minv, o), dd = xf_dir(Minv, d);
-                    uint64_t* q = pool_mem + (size_t)COOP_REC * (size_t)id;
-                    q[0] = __double_as_longlong(oo.x); q[1] = __double_as_longlong(oo.y); q[2] = __double_as_longlong(oo.z);
-                    q[3] = __double_as_longlong(dd.x); q[4] = __double_as_longlong(dd.y); q[5] = __double_as_longlong(dd.z);
-                    q[6] = __double_as_longlong(h.t);
-                    q[7] = ((uint64_t)in.y << 32) | (uint64_t)(uint32_t)h.node;
-                    q[8] = ((uint64_t)(uint32_t)(h.xf + 1) << 32) | (uint64_t)(((uint32_t)depth << 8) | ni);
-                    q[11] = __double_as_longlong(o.x); q[12] = __double_as_longlong(o.y); q[13] = __double_as_longlong(o.z);
-                    q[14] = __double_as_longlong(d.x); q[15] = __double_as_longlong(d.y); q[16] = __double_as_longlong(d.z);
-                    q[17] = __double_as_longlong(beta.x); q[18] = __double_as_longlong(beta.y); q[19] = __double_as_longlong(beta.z);
-                    q[20] = __double_as_longlong(L.x); q[21] = __double_as_longlong(L.y); q[22] = __double_as_longlong(L.z);
-                    q[23] = rng.s;
-                    q[24] = ((uint64_t)h.kp << 32) | (uint64_t)(uint32_t)pix_id;
-                    q[25] = ((uint64_t)pend << 32) | (uint64_t)out_slot;
-                    alive = false;
-                }
-                const uint64_t mp = __ballot(park);
-                if (mp != 0ull && lane == __ffsll((long long)mp) - 1) atomicAdd(C.n_parked, (uint32_t)__popcll(mp));
-                ring_push(C.rq, park, (uint32_t)id, lane, lanemask_lt, true);
-                // pool exhausted (rare): walk the deferred instances in this lane, sparsely, as the plain kernel does
-                bool inl = want && id < 0;
-                while (__ballot(inl) != 0ull) {
-                    D3 oo = o, dd = d;
-                    double a = 1., ht = h.t;
-                    int hnode = h.node, sp = 0;
-                    uint32_t hkp = 0u, cur = REF_DONE, xf = 0u;
-                    Ray32 r = make_ray32(o, mk(1, 1, 1), rk.t_min, 0.);
-                    if (inl) {
-                        const uint32_t ni = (uint32_t)(__ffs((int)pend) - 1);
-                        pend &= pend - 1u;
-                        const uint2 in = A.inst2[ni];
-                        const double* Minv = A.xforms + 32 * in.x;
-                        oo = xf_point(Minv, o);
-                        dd = xf_dir(Minv, d);
-                        a = sqlen(dd);
-                        r = make_ray32(oo, rcp3(dd), rk.t_min, ht);
-                        cur = in.y;
-                        xf = in.x;
-                    }
-                    while (__ballot(inl && cur != REF_DONE) != 0ull)
-                        blas_pass(A, inl && cur != REF_DONE, stk, stk_stride, oo, dd, a, rk.t_min, r, ht, hnode, hkp, cur, sp, err);
-                    if (inl && hnode != h.node) {
-                        h.t = ht;
-                        h.node = hnode;
-                        h.kp = hkp;
-                        h.xf = (int)xf;
-                    }
-                    if (inl && pend == 0u) {
-                        ready = true;
-                        inl = false;
-                    }
-                }
-            }
-        }
-        // ---- shade: sample_ray's loop body after World::hit, photon_mapper.rs:336-362 ----
-        if (__ballot(alive && ready) != 0ull) COOP_STAT(3, __ballot(alive && ready));
-        if (alive && ready) {
-            bool done = true;
-            if (h.node >= 0 && depth > 0) {
-                depth -= 1;
-                Rec rec = materialize<true>(A, h, o, d, err);
-                D3 emitted, att, ndir;
-                bool diffuse;
-                bool scattered = shade(A, rec, d, rng, emitted, att, ndir, diffuse, err);
-                L = add(L, elemul(beta, emitted));
-                if (scattered) {
-                    bool go = true;
-                    if (INTEG == 2 && diffuse) {
-                        const double* e = rk.sppm_est + 6 * (size_t)pix_id;
-                        L = add(L, elemul(beta, mk(e[0], e[1], e[2])));
-                        L = add(L, elemul(beta, mk(e[3], e[4], e[5])));
-                        go = false;
-                    } else if (INTEG == 1 && diffuse) {
-                        go = mixture_step(A, rec, rng, att, beta, ndir, err);
-                    } else {
-                        beta = elemul(beta, att);
-                    }
-                    if (go) {
-                        o = rec.p;
-                        d = ndir;
-                        done = false;
-                    }
-                }
-            }
-            ready = false;
-            if (done) {
-                double* dst = samples + 3 * (size_t)out_slot;
-                dst[0] = L.x;
-                dst[1] = L.y;
-                dst[2] = L.z;
-                alive = false;
-            }
-        }
-        // ---- a wave's worth of requests waits: serve them densely ----
-        if (ring_len(C.rq) >= (uint32_t)COOP_BATCH) coop_serve(C, A, stk, stk_stride, pool_mem, rk.t_min, lane, lanemask_lt, err COOP_STATS_PASS);
-    }
-#ifdef RTAMD_COOP_STATS
-    if (lane == 0)
-        for (int i = 0; i < 6; i++) {
-            atomicAdd(&g_coop_stats[2 * i], cs.ev[i]);
-            atomicAdd(&g_coop_stats[2 * i + 1], cs.ln[i]);
-        }
-#endif
-}
 
 // per pixel: accum += samples in sample order (camera.rs:96-101). One thread per (tile, pixel).
 __global__ void reduce_kernel(const double* __restrict__ samples, double* __restrict__ accum, int64_t n_pix, int chunk_spp,
@@ -1706,9 +965,8 @@ __global__ void hit_kernel(FlatView sv, int accel, size_t n, const double* rays,
     if (i >= n) return;
     Acc A = make_acc(sv.base, sv.base, sv);
     D3 o = mk(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]), d = mk(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
-    Hit h = (accel == 4)   ? traverse8<true>(A, (uint2*)smem + threadIdx.x, (int)blockDim.x, o, d, t_min, t_max)
-            : (accel == 2) ? traverse2<true>(A, (uint32_t*)smem + threadIdx.x, (int)blockDim.x, o, d, t_min, t_max)
-                           : traverse<true>(A, o, d, t_min, t_max);
+    Hit h = (accel == 2) ? traverse2<true>(A, (uint32_t*)smem + threadIdx.x, (int)blockDim.x, o, d, t_min, t_max)
+                         : traverse<true>(A, o, d, t_min, t_max);
     double* q = out + 12 * i;
     for (int k = 0; k < 12; k++) q[k] = 0.;
     if (h.node < 0) return;
@@ -1828,14 +1086,14 @@ static const DevInfo& dev_info(int dev) {
 struct Workspace {
     int device = -1;
     bool busy = false;
-    void *samples = nullptr, *accum = nullptr, *small = nullptr, *coop = nullptr;
-    size_t samples_bytes = 0, accum_bytes = 0, coop_bytes = 0;
+    void *samples = nullptr, *accum = nullptr, *small = nullptr;
+    size_t samples_bytes = 0, accum_bytes = 0;
 };
 static std::vector<Workspace*> g_ws;
 static const size_t WS_SMALL = 1024;
 struct WorkspaceLease {
     Workspace* w = nullptr;
-    WorkspaceLease(int dev, size_t need_samples, size_t need_accum, size_t need_coop) {
+    WorkspaceLease(int dev, size_t need_samples, size_t need_accum) {
         {
             std::lock_guard<std::mutex> g(g_mu);
             for (Workspace* c : g_ws)
@@ -1868,13 +1126,6 @@ struct WorkspaceLease {
                 HIP_CHECK(hipMalloc(&w->accum, need_accum));
                 w->accum_bytes = need_accum;
             }
-            if (w->coop_bytes < need_coop) {
-                if (w->coop) (void)hipFree(w->coop);
-                w->coop = nullptr;
-                w->coop_bytes = 0;
-                HIP_CHECK(hipMalloc(&w->coop, need_coop));
-                w->coop_bytes = need_coop;
-            }
         } catch (...) {
             std::lock_guard<std::mutex> g(g_mu);
             w->busy = false;
@@ -1888,7 +1139,6 @@ struct WorkspaceLease {
 };
 
 typedef void (*pt_fn)(FlatView, CamK, RenderK, double*, unsigned int*, int*);
-typedef void (*pt_coop_fn)(FlatView, CamK, RenderK, double*, unsigned int*, int*, uint64_t*);
 
 template <int ACCEL>
 static pt_fn pick_pt_kernel(bool lds, bool general, int integ) {
@@ -1914,53 +1164,30 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
     // t_min >= 0 (box32's proof); otherwise kernel 1 (reference order) renders.
     double cam_abs = std::fmax(std::fmax(std::fabs(cam.origin[0]), std::fabs(cam.origin[1])), std::fabs(cam.origin[2])) + std::fabs(cam.lens_radius);
     const bool camera_ok = cam_abs <= view.origin_limit2 && std::isfinite(cam_abs) && plan.t_min >= 0.;
-    const size_t stack2_bytes = (size_t)view.stack2 * PT_BLOCK * sizeof(uint32_t), stack8_bytes = (size_t)view.stack8 * PT_BLOCK * sizeof(uint2);
-    const size_t hot1 = (size_t)view.stage_bytes, hot2 = (size_t)(view.stage2_end - view.stage2_begin),
-                 hot8 = (size_t)(view.stage8_mid - view.stage2_begin) + (size_t)view.n_nodes8 * sizeof(Node8);
+    const size_t stack2_bytes = (size_t)view.stack2 * PT_BLOCK * sizeof(uint32_t);
+    const size_t hot1 = (size_t)view.stage_bytes, hot2 = (size_t)(view.stage2_end - view.stage2_begin);
     const bool accel2_usable = view.accel_ok && camera_ok && stack2_bytes <= lds_max;  // per-lane stacks live in LDS
-    const bool accel8_usable = view.accel8_ok && camera_ok && stack8_bytes <= lds_max;
-    // default: the BVH2 kernel when its tables fit LDS beside the stacks (small scenes: cheapest node test); otherwise the
-    // wide BVH, whose nodes are read through L2 with the shallowest levels cached in LDS (far fewer dependent fetches)
-    // kernel 5 = kernel 2's BVH2 with the cooperative instance service (pt_kernel_coop): for scenes with LARGE mesh instances
-    const size_t coop_lds = (size_t)(3 * COOP_POOL + 8) * sizeof(uint32_t);  // three rings of pool-slot ids, counters
-    const bool coop_usable = accel2_usable && general && view.n_inst2 >= 1 && view.n_inst2 <= (uint32_t)COOP_MAX_INST &&
-                             stack2_bytes + coop_lds <= lds_max && plan.max_depth < (1 << 24);
     int kernel = plan.kernel;
-    if (kernel == 0) {
-        const bool fits2 = accel2_usable && hot2 > 0 && hot2 + stack2_bytes <= lds_max;
-        if (coop_usable && !fits2 && view.max_inst_nodes2 >= 1024) kernel = 5;
-        else kernel = accel2_usable ? 2 : 1;   // (kernel 4, the 8-wide BVH, is never the default: measured slower, DESIGN s5)
-    }
-    if (kernel == 5 && !coop_usable)
-        throw RtError(RT_ERR_UNSUPPORTED, "kernel 5 (cooperative instance service) needs a usable accel and 1..32 mesh instances");
-    if ((kernel == 2 || kernel == 5) && !accel2_usable)
+    if (kernel == 0) kernel = accel2_usable ? 2 : 1;
+    if (kernel == 2 && !accel2_usable)
         throw RtError(RT_ERR_UNSUPPORTED, "kernel 2 requested but no usable accel for this scene/camera (unbounded item, depth overflow, stacks "
                                           "larger than LDS, negative t_min, or camera farther than 64x the scene extent); use kernel 0/1");
-    if (kernel == 4 && !accel8_usable)
-        throw RtError(RT_ERR_UNSUPPORTED, "kernel 4 requested but no usable wide accel for this scene/camera; use kernel 0/1");
-    const size_t stack_bytes = (kernel == 4) ? stack8_bytes : (kernel == 2) ? stack2_bytes : (kernel == 5) ? stack2_bytes + coop_lds : 0;
-    const size_t hot_bytes = (kernel == 4) ? hot8 : (kernel == 2 || kernel == 5) ? hot2 : hot1;
+    const size_t stack_bytes = (kernel == 2) ? stack2_bytes : 0;
+    const size_t hot_bytes = (kernel == 2) ? hot2 : hot1;
     const bool lds = hot_bytes > 0 && hot_bytes + stack_bytes <= lds_max && !tuning().no_lds;
     const int integ = plan.integrator;
     if (integ == 1 && view.n_lights == 0) throw RtError(RT_ERR_ARG, "integrator 1 (light importance sampling) needs rt_scene_set_lights");
     if (integ == 2 && !plan.sppm_est) throw RtError(RT_ERR_ARG, "integrator 2 (SPPM) is reached through rt_render_sppm");
-    pt_fn fn = (kernel == 4) ? pick_pt_kernel<4>(lds, general, integ) : (kernel == 2) ? pick_pt_kernel<2>(lds, general, integ)
-                                                                                    : pick_pt_kernel<1>(lds, general, integ);
-    pt_coop_fn fn_coop = nullptr;
-    if (kernel == 5)
-        fn_coop = (integ == 1) ? (lds ? pt_kernel_coop<true, 1> : pt_kernel_coop<false, 1>)
-                : (integ == 2) ? (lds ? pt_kernel_coop<true, 2> : pt_kernel_coop<false, 2>)
-                               : (lds ? pt_kernel_coop<true, 0> : pt_kernel_coop<false, 0>);
-    // scene too large for LDS: spend what is left after the stacks on the shallowest BVH levels (the node arrays are depth-sorted)
+    pt_fn fn = (kernel == 2) ? pick_pt_kernel<2>(lds, general, integ) : pick_pt_kernel<1>(lds, general, integ);
+    // scene too large for LDS: spend what is left after the stacks on the shallowest BVH levels (the Node2 array is depth-sorted)
     int n_top = 0;
-    if (kernel >= 2 && !lds && lds_max > stack_bytes) {
-        const size_t node_bytes = (kernel == 4) ? sizeof(Node8) : sizeof(Node2);  // kernel 5 walks the BVH2 too
-        size_t room = (lds_max - stack_bytes) / node_bytes;
+    if (kernel == 2 && !lds && lds_max > stack_bytes) {
+        size_t room = (lds_max - stack_bytes) / sizeof(Node2);
         if (tuning().n_top >= 0) room = std::min<size_t>(room, (size_t)tuning().n_top);
-        n_top = (int)std::min<size_t>(room, (kernel == 4) ? view.n_nodes8 : view.n_nodes2);
+        n_top = (int)std::min<size_t>(room, view.n_nodes2);
     }
-    const size_t smem = (lds ? hot_bytes : (size_t)n_top * ((kernel == 4) ? sizeof(Node8) : sizeof(Node2))) + stack_bytes;
-    const void* fptr = (kernel == 5) ? (const void*)fn_coop : (const void*)fn;
+    const size_t smem = (lds ? hot_bytes : (size_t)n_top * sizeof(Node2)) + stack_bytes;
+    const void* fptr = (const void*)fn;
     if (smem > 48 * 1024) HIP_CHECK(hipFuncSetAttribute(fptr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     int blocks_per_cu = 0;
     HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, fptr, PT_BLOCK, smem));
@@ -1973,8 +1200,7 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
     for (;;) {
         try {
             lease_p.reset(new WorkspaceLease(dev, std::max<size_t>(16, (size_t)n_pix * plan.spp_chunk * 3 * sizeof(double)),
-                                             std::max<size_t>(16, (size_t)n_pix * 3 * sizeof(double)),
-                                             (kernel == 5) ? (size_t)grid * COOP_POOL * COOP_REC * sizeof(uint64_t) : 16));
+                                             std::max<size_t>(16, (size_t)n_pix * 3 * sizeof(double))));
             break;
         } catch (const RtError&) {
             (void)hipGetLastError();
@@ -2014,12 +1240,8 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
         hipEvent_t e0 = events.make(), e1 = events.make(), e2 = events.make();
         HIP_CHECK(hipEventRecord(e0, stream));
         if (rk.n_units > 0) {
-            if (kernel == 5)
-                hipLaunchKernelGGL(fn_coop, dim3(grid), dim3(PT_BLOCK), smem, stream, view, ck, rk, (double*)samples.p, (unsigned int*)counter.p,
-                                   (int*)err.p, (uint64_t*)lease.w->coop);
-            else
-                hipLaunchKernelGGL(fn, dim3(grid), dim3(PT_BLOCK), smem, stream, view, ck, rk, (double*)samples.p, (unsigned int*)counter.p,
-                                   (int*)err.p);
+            hipLaunchKernelGGL(fn, dim3(grid), dim3(PT_BLOCK), smem, stream, view, ck, rk, (double*)samples.p, (unsigned int*)counter.p,
+                               (int*)err.p);
             HIP_CHECK(hipGetLastError());
         }
         HIP_CHECK(hipEventRecord(e1, stream));
@@ -2063,18 +1285,6 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
         st->spp_chunk = plan.spp_chunk;
         st->scene_bytes = s.flat.blob.size();
     }
-#ifdef RTAMD_COOP_STATS
-    if (kernel == 5) {
-        unsigned long long hs[16];
-        HIP_CHECK(hipMemcpyFromSymbol(hs, HIP_SYMBOL(g_coop_stats), sizeof(hs)));
-        const char* names[6] = {"serve rounds", "serve passes", "world walks", "shade passes", "parkings (lanes: pool exhausted)", "sleeps"};
-        for (int i = 0; i < 6; i++)
-            fprintf(stderr, "[coop stats] %-32s %12llu  lanes %14llu  (%.1f per event)\n", names[i], hs[2 * i], hs[2 * i + 1],
-                    hs[2 * i] ? (double)hs[2 * i + 1] / (double)hs[2 * i] : 0.);
-        unsigned long long z[16] = {0};
-        HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_coop_stats), z, sizeof(z)));
-    }
-#endif
     if (h_err) throw RtError(RT_ERR_UNIT_ZERO, "unitizing zero vector (device)");
 }
 
@@ -2400,9 +1610,8 @@ void debug_hit_device(const rt_scene& s, int kernel, size_t n, const double* ray
     HIP_CHECK(hipMemset(err.p, 0, 4));
     HIP_CHECK(hipMemcpy(dr.p, rays, n * 48, hipMemcpyHostToDevice));
     if (kernel == 2 && !view.accel_ok) throw RtError(RT_ERR_UNSUPPORTED, "no accel for this scene");
-    if (kernel == 4 && !view.accel8_ok) throw RtError(RT_ERR_UNSUPPORTED, "no wide accel for this scene");
-    if (kernel >= 2 && !(t_min >= 0.)) throw RtError(RT_ERR_UNSUPPORTED, "kernels 2 and 4 need t_min >= 0 (box32)");
-    const size_t smem = (kernel == 4) ? view.stack8 * 64 * sizeof(uint2) : (kernel == 2) ? view.stack2 * 64 * sizeof(uint32_t) : 0;
+    if (kernel == 2 && !(t_min >= 0.)) throw RtError(RT_ERR_UNSUPPORTED, "kernel 2 needs t_min >= 0 (box32)");
+    const size_t smem = (kernel == 2) ? view.stack2 * 64 * sizeof(uint32_t) : 0;
     hipLaunchKernelGGL(hit_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), smem, 0, view,
                        kernel, n, (const double*)dr.p, t_min, t_max, (double*)dout.p, (int*)err.p);
     HIP_CHECK(hipGetLastError());

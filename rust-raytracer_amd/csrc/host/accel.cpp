@@ -8,7 +8,6 @@
 
 #include <algorithm>
 #include <cmath>
-#include <cstring>
 #include <limits>
 
 namespace rtamd {
@@ -151,14 +150,10 @@ uint32_t build(Ctx& c, int begin, int end, int depth) {
     }
     uint32_t idx = (uint32_t)c.out.nodes.size();
     c.out.nodes.push_back(Node2{});
-    c.out.cbox.resize(2 * c.out.nodes.size());
-    c.out.npad.resize(c.out.nodes.size(), c.pad);
     uint32_t child[2];
     Box cbx[2] = {empty_box(), empty_box()};
     for (int i = begin; i < mid; i++) cbx[0] = merge(cbx[0], c.items[i].box);
     for (int i = mid; i < end; i++) cbx[1] = merge(cbx[1], c.items[i].box);
-    c.out.cbox[2 * idx] = cbx[0];
-    c.out.cbox[2 * idx + 1] = cbx[1];
     child[0] = build(c, begin, mid, depth + 1);
     child[1] = build(c, mid, end, depth + 1);
     Node2& nd = c.out.nodes[idx];
@@ -190,10 +185,6 @@ uint32_t accel_build_bvh(AccelBuild& out, std::vector<AccelItem>& items, double 
         // a single item still needs one inner node so that the root is box-tested like everything else
         uint32_t idx = (uint32_t)out.nodes.size();
         out.nodes.push_back(Node2{});
-        out.cbox.resize(2 * out.nodes.size());
-        out.npad.resize(out.nodes.size(), pad);
-        out.cbox[2 * idx] = items[0].box;
-        out.cbox[2 * idx + 1] = empty_box();
         uint32_t leaf = make_leaf(c, 0, 1);
         Node2& nd = out.nodes[idx];
         const Box& b = items[0].box;
@@ -211,15 +202,10 @@ uint32_t accel_build_bvh(AccelBuild& out, std::vector<AccelItem>& items, double 
     uint32_t root = build(c, 0, (int)items.size(), depth0);
     if (out.ok && (root >> REF_TAG_SHIFT) == 1u) {
         // the SAH kept everything in one leaf: still give the BVH an inner root so that every BVH starts with a box test
-        // (and the wide collapse has a node to start from)
         Box all = empty_box();
         for (auto& it : items) all = merge(all, it.box);
         uint32_t idx = (uint32_t)out.nodes.size();
         out.nodes.push_back(Node2{});
-        out.cbox.resize(2 * out.nodes.size());
-        out.npad.resize(out.nodes.size(), pad);
-        out.cbox[2 * idx] = all;
-        out.cbox[2 * idx + 1] = empty_box();
         Node2& nd = out.nodes[idx];
         const float inf = std::numeric_limits<float>::infinity();
         nd.lo_x[0] = round_down(all.mn[0] - pad); nd.hi_x[0] = round_up(all.mx[0] + pad);
@@ -234,202 +220,6 @@ uint32_t accel_build_bvh(AccelBuild& out, std::vector<AccelItem>& items, double 
         return idx;
     }
     return root;
-}
-
-// ------------------------------------------------------------------ wide accel (Node8) ----
-namespace {
-
-struct WideChild {
-    uint32_t ref;  // BVH2 ref: inner Node2 index or leaf
-    Box box;       // exact f64 box
-};
-
-// quantise one axis of a node: frame origin o (f32), exponent byte e, planes qlo/qhi for every child, all verified with the
-// device's own decode  lo = fmaf((float)q, s, o)
-bool quantise_axis(const std::vector<WideChild>& ch, const int* slot_of, int axis, double pad, float& o_out, uint8_t& e_out, uint8_t* qlo,
-                   uint8_t* qhi) {
-    double lo = std::numeric_limits<double>::infinity(), hi = -lo;
-    for (auto& c : ch) {
-        lo = std::fmin(lo, c.box.mn[axis] - pad);
-        hi = std::fmax(hi, c.box.mx[axis] + pad);
-    }
-    const float o = round_down(lo);
-    if (!std::isfinite(o) || !std::isfinite(hi)) return false;
-    double ext = hi - (double)o;
-    int e0 = -120;
-    if (ext > 0.) {
-        int ex;
-        std::frexp(ext / 255.0, &ex);  // ext/255 = m * 2^ex, m in [0.5, 1)  ->  2^ex >= ext/255
-        e0 = std::max(ex - 1, -120);
-    }
-    for (int e = e0; e <= 100; e++) {
-        const float s = std::ldexp(1.0f, e);
-        bool ok = true;
-        for (size_t i = 0; i < ch.size() && ok; i++) {
-            const double clo = ch[i].box.mn[axis] - pad, chi = ch[i].box.mx[axis] + pad;
-            double ql = std::floor((clo - (double)o) / (double)s);
-            if (ql > 255.) ql = 255.;
-            if (ql < 0.) ql = 0.;
-            int q = (int)ql;
-            while (q > 0 && (double)std::fmaf((float)q, s, o) > clo) q--;
-            if ((double)std::fmaf((float)q, s, o) > clo) ok = false;
-            int q2 = 0;
-            if (ok) {
-                double qh = std::ceil((chi - (double)o) / (double)s);
-                if (qh < 0.) qh = 0.;
-                if (qh > 255.) { ok = false; break; }
-                q2 = (int)qh;
-                while (q2 <= 255 && (double)std::fmaf((float)q2, s, o) < chi) q2++;
-                if (q2 > 255) ok = false;
-            }
-            if (ok) {
-                qlo[slot_of[i]] = (uint8_t)q;
-                qhi[slot_of[i]] = (uint8_t)q2;
-            }
-        }
-        if (ok) {
-            o_out = o;
-            e_out = (uint8_t)(e + 127);
-            return e + 127 >= 1 && e + 127 <= 254;
-        }
-    }
-    return false;
-}
-
-}  // namespace
-
-void accel8_build(AccelBuild& ab, uint32_t& root2, Accel8Build& out) {
-    out = Accel8Build{};
-    if (!ab.ok || (root2 >> REF_TAG_SHIFT) != 0u) return;
-    const size_t n_inst = ab.inst.size() / 2;
-    for (size_t i = 0; i < n_inst; i++)
-        if ((ab.inst[2 * i + 1] >> REF_TAG_SHIFT) != 0u) return;  // every BVH has an inner root (accel_build_bvh)
-    // breadth-first over all BVHs at once: node index order == depth order
-    struct Pending {
-        uint32_t node2;  // Node2 the wide node grows from
-        int depth;       // 1 = root of its BVH
-        bool world;      // part of the world-space BVH (else: of an instance's object-space BVH)
-    };
-    std::vector<Pending> queue;
-    queue.push_back({root2, 1, true});
-    out.root = 0;
-    out.inst.assign(2 * n_inst, 0u);
-    for (size_t i = 0; i < n_inst; i++) {
-        out.inst[2 * i] = ab.inst[2 * i];
-        out.inst[2 * i + 1] = (uint32_t)queue.size();
-        queue.push_back({ab.inst[2 * i + 1], 1, false});
-    }
-    out.nodes.resize(queue.size());
-    std::vector<uint32_t> new_items;            // items in wide-node order
-    new_items.reserve(ab.items.size());
-    std::vector<uint32_t> new_first(ab.items.size() / 2 + 1, 0xFFFFFFFFu);  // old first item of a BVH2 leaf -> new first
-    int depth_world = 0, depth_inst = 0;
-    for (size_t qi = 0; qi < queue.size(); qi++) {
-        const Pending pn = queue[qi];
-        // collapse: open the inner child with the largest surface area until there are 8 children or only leaves
-        std::vector<WideChild> ch;
-        const double pad = ab.npad[pn.node2];
-        for (int k = 0; k < 2; k++) {
-            const Box& b = ab.cbox[2 * pn.node2 + k];
-            if (b.mn[0] <= b.mx[0]) ch.push_back({ab.nodes[pn.node2].child[k], b});  // skip the empty child of a one-item BVH
-        }
-        for (;;) {
-            if (ch.size() >= 8) break;
-            int best = -1;
-            double best_area = -1.;
-            for (size_t i = 0; i < ch.size(); i++)
-                if ((ch[i].ref >> REF_TAG_SHIFT) == 0u) {
-                    double a = area(ch[i].box);
-                    if (a > best_area) { best_area = a; best = (int)i; }
-                }
-            if (best < 0) break;
-            const uint32_t n2 = ch[best].ref;
-            WideChild c0{ab.nodes[n2].child[0], ab.cbox[2 * n2]}, c1{ab.nodes[n2].child[1], ab.cbox[2 * n2 + 1]};
-            ch[best] = c0;
-            if (c1.box.mn[0] <= c1.box.mx[0]) ch.push_back(c1);
-        }
-        // slots: bit a of the slot index = the child lies on the + side of the node along axis a (greedy assignment of
-        // children to the 8 octant directions by the projection of their centroid offset)
-        Box nb = empty_box();
-        for (auto& c : ch) nb = merge(nb, c.box);
-        double cost[8][8];
-        for (size_t i = 0; i < ch.size(); i++)
-            for (int s = 0; s < 8; s++) {
-                double v = 0.;
-                for (int a = 0; a < 3; a++) {
-                    double off = 0.5 * (ch[i].box.mn[a] + ch[i].box.mx[a]) - 0.5 * (nb.mn[a] + nb.mx[a]);
-                    v += ((s >> a) & 1) ? off : -off;
-                }
-                cost[i][s] = v;
-            }
-        int slot_of[8];
-        bool child_done[8] = {false}, slot_used[8] = {false};
-        for (size_t round = 0; round < ch.size(); round++) {
-            int bi = -1, bs = -1;
-            for (size_t i = 0; i < ch.size(); i++) {
-                if (child_done[i]) continue;
-                for (int s = 0; s < 8; s++)
-                    if (!slot_used[s] && (bi < 0 || cost[i][s] > cost[bi][bs])) { bi = (int)i; bs = s; }
-            }
-            slot_of[bi] = bs;
-            child_done[bi] = true;
-            slot_used[bs] = true;
-        }
-        Node8 nd;
-        std::memset(&nd, 0, sizeof(nd));
-        for (int a = 0; a < 3; a++)
-            if (!quantise_axis(ch, slot_of, a, pad, nd.o[a], nd.e[a], nd.qlo[a], nd.qhi[a])) return;  // out.ok stays false
-        // children in slot order: inner ones get contiguous Node8 indices, leaves get contiguous items
-        const uint32_t child_base = (uint32_t)out.nodes.size();
-        const uint32_t item_base = (uint32_t)(new_items.size() / 2);
-        uint32_t imask = 0, lmask = 0, n_inner = 0, n_item = 0;
-        int child_in_slot[8];
-        for (int s = 0; s < 8; s++) child_in_slot[s] = -1;
-        for (size_t i = 0; i < ch.size(); i++) child_in_slot[slot_of[i]] = (int)i;
-        for (int s = 0; s < 8; s++) {
-            if (child_in_slot[s] < 0) continue;
-            const WideChild& c = ch[child_in_slot[s]];
-            if ((c.ref >> REF_TAG_SHIFT) == 0u) {
-                imask |= 1u << s;
-                nd.meta[s] = 0xFF;
-                queue.push_back({c.ref, pn.depth + 1, pn.world});
-                n_inner++;
-            } else {
-                const uint32_t first = c.ref & REF_LEAF_FIRST_MASK, cnt = ((c.ref >> REF_LEAF_COUNT_SHIFT) & 7u) + 1u;
-                if (cnt > 4 || n_item + cnt > 32) return;
-                lmask |= 1u << s;
-                nd.meta[s] = (uint8_t)((cnt << 5) | n_item);
-                if (new_first[first] == 0xFFFFFFFFu) new_first[first] = item_base + n_item;
-                for (uint32_t j = 0; j < cnt; j++) {
-                    new_items.push_back(ab.items[2 * (first + j)]);
-                    new_items.push_back(ab.items[2 * (first + j) + 1]);
-                }
-                n_item += cnt;
-            }
-        }
-        out.nodes.resize(out.nodes.size() + n_inner);
-        if (out.nodes.size() >= (1u << 24)) return;
-        nd.imask = (uint8_t)imask;
-        nd.cb_lm = child_base | (lmask << 24);
-        nd.item_base = item_base;
-        out.nodes[qi] = nd;
-        if (pn.world) depth_world = std::max(depth_world, pn.depth);
-        else depth_inst = std::max(depth_inst, pn.depth);
-    }
-    out.max_depth = depth_world + depth_inst;
-    if (new_items.size() != ab.items.size()) return;  // every BVH2 leaf is reached exactly once
-    // one item array for both accels: adopt the wide order and re-point the BVH2 leaves
-    ab.items.swap(new_items);
-    auto patch = [&](uint32_t r) -> uint32_t {
-        if ((r >> REF_TAG_SHIFT) != 1u) return r;
-        const uint32_t first = r & REF_LEAF_FIRST_MASK;
-        return (r & ~REF_LEAF_FIRST_MASK) | new_first[first];
-    };
-    for (auto& n : ab.nodes) {
-        n.child[0] = patch(n.child[0]);
-        n.child[1] = patch(n.child[1]);
-    }
-    out.ok = true;
 }
 
 }  // namespace rtamd

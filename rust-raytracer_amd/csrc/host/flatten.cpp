@@ -261,7 +261,7 @@ void flatten(rt_scene& s) {
     // ---- accel (kernel 2) ----
     AccelBuild ab;
     ab.ok = b.accel_ok;
-    uint32_t root2 = REF_DONE, max_inst_nodes = 0;
+    uint32_t root2 = REF_DONE;
     double origin_limit = 0.;
     if (ab.ok && !b.actx[0].items.empty()) {
         // E_w: largest |coordinate| of the world items; boxes are padded so that rounding a ray origin with
@@ -290,9 +290,7 @@ void flatten(rt_scene& s) {
                 for (auto& it : c.items)  // hit points inside the instance also serve as origins of secondary rays (in world space only)
                     for (int a = 0; a < 3; a++) oo = std::fmax(oo, std::fmax(std::fabs(it.box.mn[a]), std::fabs(it.box.mx[a])));
                 if (!(oo < 68719476736.)) { ab.ok = false; break; }
-                const size_t nodes_before = ab.nodes.size();
                 uint32_t r = accel_build_bvh(ab, c.items, std::ldexp(oo, -22), depth_tlas + 1);
-                max_inst_nodes = std::max<uint32_t>(max_inst_nodes, (uint32_t)(ab.nodes.size() - nodes_before));
                 ab.inst[2 * (i - 1)] = c.xform;
                 ab.inst[2 * (i - 1) + 1] = r;
             }
@@ -301,11 +299,6 @@ void flatten(rt_scene& s) {
         ab.ok = false;
     }
     if (ab.max_depth + 2 > ACCEL_MAX_STACK) ab.ok = false;
-    // wide accel (kernel 4): collapse of the same BVH2s; adopts its own item order for both accels (before the relabelling
-    // below, which does not touch leaf refs)
-    Accel8Build a8;
-    if (ab.ok) accel8_build(ab, root2, a8);
-    if (a8.max_depth + 4 > ACCEL8_MAX_STACK) a8.ok = false;
     std::vector<double> tripre2;  // triangle records in ACCEL ITEM order: a leaf's 1..4 triangles are contiguous
     if (ab.ok) {
         // (b) relabel the Node2 array by depth (all BVHs interleaved): the first K nodes are the K shallowest, which is
@@ -376,32 +369,15 @@ void flatten(rt_scene& s) {
         ab.nodes.clear();
         ab.items.clear();
         ab.inst.clear();
-        a8 = Accel8Build{};
     }
-    if (!a8.ok) {
-        a8.nodes.clear();
-        a8.inst.clear();
-    }
-    // [spheres .. xforms | items2 | inst2 | inst8 | tripre2 | n2 | n8]: kernel 2 stages [spheres, end of n2), kernel 4 stages
-    // [spheres, begin of n2) and [n8]
+    // kernel 2 stages [spheres .. xforms | items2 | inst2 | tripre2 | n2] into LDS when it fits
     v.off_items2 = append(f.blob, ab.items);
     v.off_inst2 = append(f.blob, ab.inst);
-    v.off_inst8 = append(f.blob, a8.inst);
     v.off_tripre2 = append(f.blob, tripre2);  // triangle records in item order (big meshes); staged with the rest when everything fits
-    f.blob.resize((f.blob.size() + 15) & ~size_t(15));
-    v.stage8_mid = (uint32_t)f.blob.size();
     v.off_n2 = append(f.blob, ab.nodes);
     f.blob.resize((f.blob.size() + 15) & ~size_t(15));
     v.stage2_end = (uint32_t)f.blob.size();
-    v.off_n8 = append(f.blob, a8.nodes);
-    f.blob.resize((f.blob.size() + 15) & ~size_t(15));
     v.n_nodes2 = (uint32_t)ab.nodes.size();
-    v.n_nodes8 = (uint32_t)a8.nodes.size();
-    v.accel8_ok = a8.ok ? 1u : 0u;
-    v.root8 = a8.root;
-    v.stack8 = (uint32_t)(a8.max_depth + 4);
-    v.n_inst2 = (uint32_t)(ab.inst.size() / 2);
-    v.max_inst_nodes2 = max_inst_nodes;
     v.accel_ok = ab.ok ? 1u : 0u;
     v.root2 = root2;
     v.stack2 = (uint32_t)(ab.max_depth + 2);
@@ -441,7 +417,6 @@ void flatten(rt_scene& s) {
     in.accel_items = (int32_t)(ab.items.size() / 2);
     in.accel_instances = (int32_t)(ab.inst.size() / 2);
     in.accel_stack = (int32_t)v.stack2;
-    in.accel8_nodes = (int32_t)a8.nodes.size();
     s.committed = true;
 }
 

@@ -71,7 +71,7 @@ OBJECT_TYPES = ("Sphere", "Rect", "Cube", "Triangle", "Mesh", "Transform", "Hita
 class rt_scene_info(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("n_nodes", "n_boxes", "n_spheres", "n_rects", "n_tris", "n_xforms", "n_materials",
                                          "n_textures", "n_verts", "max_depth", "committed", "reserved")] + [("bytes", C.c_uint64)] + \
-               [(n, C.c_int32) for n in ("accel_ok", "accel_nodes", "accel_items", "accel_instances", "accel_stack", "accel8_nodes")]
+               [(n, C.c_int32) for n in ("accel_ok", "accel_nodes", "accel_items", "accel_instances", "accel_stack", "reserved2")]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if not k.startswith("reserved")}
