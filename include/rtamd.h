@@ -74,7 +74,7 @@ typedef struct rt_params {
     uint64_t seed;       /* rtamd-rng-1 stream seed (replaces thread_rng) */
     int32_t rank;        /* image-tile partition: this call renders tiles t with t % world == rank */
     int32_t world;       /* 1 = whole image */
-    int32_t spp_chunk;   /* samples per pixel per kernel launch; 0 = auto */
+    int32_t spp_chunk;   /* samples per pixel per kernel launch; 0 = all in one launch */
     int32_t kernel;      /* 0 = auto; 1 = reference-order stackless traversal; 2 = SAH-BVH2 accel traversal (auto whenever the
                             scene has a usable accel).  Both give bit-identical images (same f64 primitive tests, same tie rule). */
     int32_t device;      /* HIP device ordinal; -1 = current */
@@ -87,7 +87,7 @@ typedef struct rt_params {
 typedef struct rt_stats {
     double seconds;          /* wall time of the call (host clock) */
     double kernel_ms;        /* sum of path-trace kernel launch durations (HIP events on the launch stream) */
-    double reduce_ms;        /* sum of ordered-reduction kernel durations */
+    double reduce_ms;        /* 0: the ordered reduction happens inside the path-trace kernel */
     uint64_t samples;        /* pixel-samples traced by this call (this rank) */
     int32_t launches;        /* path-trace kernel launches */
     int32_t kernel_used;     /* which kernel ran */
@@ -96,7 +96,7 @@ typedef struct rt_stats {
     int32_t grid_blocks;
     int32_t spp_chunk;
     uint64_t scene_bytes;    /* flattened scene size */
-    uint64_t reserved[4];
+    uint64_t reserved[4];    /* [0] SPPM pre-pass microseconds, [1] render workspace bytes on the device */
 } rt_stats;
 
 /* ---- library ------------------------------------------------------------ */
@@ -110,9 +110,8 @@ int rt_device_count(void);                      /* HIP devices visible; 0 withou
 typedef struct rt_tuning {
     int32_t no_lds;                /* 1: keep scene tables in global memory even when they fit LDS (A/B runs)            */
     int32_t top_nodes;             /* >= 0: cap on the BVH nodes cached in LDS when the scene lives in L2/HBM; -1 auto  */
-    int32_t sub_spp;               /* > 0: sample indices per work unit (a wave's pool = 64 px x sub_spp); 0 auto       */
-    int32_t sample_budget_mb;      /* > 0: budget of the per-launch sample buffer in MiB; 0 auto                        */
-    int32_t workspace_limit_mb;    /* > 0: pretend the device cannot spare a larger sample buffer (launches are halved) */
+    int32_t sub_spp;               /* 1..8: sample indices per work unit (a wave's pool = 64 px x sub_spp); 0 auto      */
+    int32_t reserved;
     int32_t max_leaf;              /* 1..4: accel builder, items per leaf; 0 auto (read at rt_scene_commit)             */
     int32_t sppm_photon_capacity;  /* > 0: initial photon-buffer capacity (forces the grow-and-retry path); 0 auto      */
     int32_t sppm_knn_candidates;   /* >= 0: k-nearest candidates kept in LDS (0 forces the out-of-LDS selection); -1 auto */
@@ -120,6 +119,9 @@ typedef struct rt_tuning {
 } rt_tuning;
 void rt_tuning_default(rt_tuning* t);
 int rt_tuning_set(const rt_tuning* t);
+/* The render entry points keep a workspace per device for the life of the process (unit rings of the resident waves, ~0.3 GB,
+ * accumulator, tickets: no hipMalloc on the hot path).  This frees the idle ones; returns the bytes released. */
+int64_t rt_release_workspaces(void);
 
 /* ---- scene graph builders (one per reference constructor) ---------------- */
 int rt_scene_create(rt_scene** out);

@@ -70,6 +70,14 @@ void rt_default_params(rt_params* p) {
     p->integrator = 0;
 }
 int rt_device_count(void) { return device_count(); }
+int64_t rt_release_workspaces(void) {
+    int64_t n = 0;
+    guard([&] {
+        n = (int64_t)release_workspaces();
+        return (int)RT_OK;
+    });
+    return n;
+}
 void rt_tuning_default(rt_tuning* t) {
     if (!t) return;
     std::memset(t, 0, sizeof(*t));
@@ -85,8 +93,6 @@ int rt_tuning_set(const rt_tuning* t) {
         n.no_lds = t->no_lds != 0;
         n.n_top = t->top_nodes < 0 ? -1 : t->top_nodes;
         n.sub_spp = std::max(0, t->sub_spp);
-        n.sample_budget_mb = std::max(0, t->sample_budget_mb);
-        n.ws_limit_mb = std::max(0, t->workspace_limit_mb);
         n.max_leaf = t->max_leaf;
         n.sppm_cap = std::max(0, t->sppm_photon_capacity);
         n.knn_cand = t->sppm_knn_candidates < 0 ? -1 : t->sppm_knn_candidates;
@@ -416,26 +422,10 @@ static RenderPlan make_plan(const rt_params* p) {
     if (pl.tiles_owned < 0) pl.tiles_owned = 0;
     pl.kernel = p->kernel;
     pl.integrator = p->integrator;
-    // Samples of one launch are stored one by one (24 B each) and reduced in sample order afterwards.  Few, long launches keep
-    // the 4096 persistent waves busy (each launch ends with a tail while the last paths finish): budget 12 GiB of the 288 GB
-    // for that buffer, at most 512 sample indices per launch, launches of equal size
-    // (headline workload, Msamples/s: 0.75 GiB 2123, 1.5 GiB 2248, 3 GiB 2303, 6 GiB 2330, 9 GiB 2348).
-    int chunk = p->spp_chunk;
-    if (chunk <= 0) {
-        int64_t per_spp = std::max<int64_t>(1, pl.tiles_owned) * TILE_PIX * 3 * 8;
-        int64_t budget = int64_t(12) << 30;
-        if (tuning().sample_budget_mb > 0) budget = (int64_t)tuning().sample_budget_mb << 20;  // rt_tuning (A/B runs)
-        int64_t c = std::max<int64_t>(1, std::min<int64_t>(budget / per_spp, 512));
-        int64_t launches = (std::max(1, p->spp) + c - 1) / c;
-        chunk = (int)((std::max(1, p->spp) + launches - 1) / launches);
-    }
+    // One launch renders all sample indices unless the caller splits them (rt_params.spp_chunk): samples are folded into the
+    // accumulator inside the kernel, unit by unit, so no per-launch sample buffer bounds the launch size.
+    int chunk = p->spp_chunk > 0 ? p->spp_chunk : p->spp;
     if (chunk > p->spp) chunk = p->spp;
-    {   // the kernels address a sample by a 32-bit slot index: tiles * chunk * 64 slots per launch
-        const int64_t max_chunk = (int64_t(1) << 32) / (std::max<int64_t>(1, pl.tiles_owned) * TILE_PIX) - 1;
-        if (max_chunk < 1) throw RtError(RT_ERR_UNSUPPORTED, "image too large for one rank: more than 2^32 pixel slots");
-        if (chunk > max_chunk) chunk = (int)max_chunk;
-    }
-    pl.spp_chunk = chunk;
     // one work unit = 64 pixels x sub_spp samples (a wave works through it with in-wave regeneration and fetches the next
     // one as soon as its pool is empty).  Many units balance the 4096 resident waves at the end of a launch: aim at
     // >= ~12 units per wave, 4 <= sub_spp <= 8 (measured on the headline workload: 4: 2144, 8: 2166, 16: 2104 Msamples/s).
@@ -443,7 +433,13 @@ static RenderPlan make_plan(const rt_params* p) {
     int64_t subs = std::max<int64_t>(1, want_units / std::max<int64_t>(1, pl.tiles_owned));
     int sub = (int)((chunk + subs - 1) / subs);
     pl.sub_spp = std::max(std::min(chunk, 4), std::min(sub, 8));
-    if (tuning().sub_spp > 0) pl.sub_spp = std::max(1, std::min(chunk, tuning().sub_spp));  // rt_tuning (A/B runs)
+    if (tuning().sub_spp > 0) pl.sub_spp = std::max(1, std::min(std::min(chunk, 8), tuning().sub_spp));  // rt_tuning (A/B runs)
+    {   // at most 2^31 work units per launch
+        const int64_t max_chunk = ((int64_t(1) << 31) - 1) / std::max<int64_t>(1, pl.tiles_owned) * pl.sub_spp;
+        if (max_chunk < 1) throw RtError(RT_ERR_UNSUPPORTED, "image too large for one rank");
+        if (chunk > max_chunk) chunk = (int)max_chunk;
+    }
+    pl.spp_chunk = chunk;
     return pl;
 }
 

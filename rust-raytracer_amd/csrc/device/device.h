@@ -16,8 +16,8 @@ struct RenderPlan {
     int rank, world;
     int tiles_x, tiles_y;
     int64_t tiles_total, tiles_owned;
-    int spp_chunk;  // samples per pixel per launch (sample-buffer capacity)
-    int sub_spp;    // samples per pixel per work unit (one wave drains 64*sub_spp paths)
+    int spp_chunk;  // samples per pixel per launch (default: all of them)
+    int sub_spp;    // samples per pixel per work unit (a wave's pool = 64 * sub_spp paths; at most 8)
     int kernel;
     int integrator;  // 0 BSDF sampling, 1 light/cosine mixture pdf, 2 SPPM final gather (needs sppm_est)
     const double* sppm_est = nullptr;  // device: per pixel {caustic estimate[3], global estimate[3]}
@@ -40,5 +40,6 @@ void dev_free(void* p);
 void dev_copy_to_host(void* dst, const void* src, size_t n);
 void dev_set_device(int d);
 void free_device_copies(rt_scene& s);
+size_t release_workspaces();
 
 }  // namespace rtamd

@@ -8,10 +8,9 @@
 //   f32 boxes, per-lane stack in LDS; kernel 1: the reference-order program), hit record, emission + scatter.
 //   The flattened scene (common/flat.h) is staged once per workgroup into LDS when it fits (its traversal tables;
 //   scene_500: 72 KB + 56 KB of stacks of the CU's 160 KB), otherwise read through L2 with the top of the BVHs cached.
-//   Each finished path stores its radiance to the per-sample buffer; nothing is accumulated out of order.
-// reduce_kernel -- per pixel, adds the launch's samples IN SAMPLE ORDER into the
-//   f64 accumulator: the reference's `pixel_color += sample` loop (camera.rs:96-101),
-//   which makes the image independent of how work was scheduled.
+//   Each finished path stores its radiance to its unit's buffer in the wave's ring; a complete unit is folded into the f64
+//   accumulator IN SAMPLE ORDER (the reference's `pixel_color += sample` loop, camera.rs:96-101; per-tile tickets order the
+//   units across waves), which makes the image independent of how work was scheduled.
 // finalize / assemble -- `pixel_color /= spp` (camera.rs:102) and the tile stitch
 //   (camera.rs:115-123).
 //
@@ -178,7 +177,7 @@ struct RenderK {
     int s_begin, s_end;  // sample indices of this launch
     int sub_spp, subs_per_tile, n_units;
     int tiles_x, rank, world;
-    int chunk_spp;  // sample-buffer stride
+    int tiles_owned;  // units are dealt sample-major: unit u = (tile u % tiles_owned, sample block u / tiles_owned)
     const double* sppm_est;  // INTEG 2: per pixel {caustic estimate[3], global estimate[3]}, index y*width + x
     int n_top;               // kernel 2 with the scene in L2/HBM: number of (depth-sorted) Node2 cached in LDS
 };
@@ -742,13 +741,78 @@ DEV bool mixture_step(const Acc& A, const Rec& rec, Rng& rng, D3 att, D3& beta, 
 // ------------------------------------------------------------ pt_kernel ---
 // INTEG: 0 = sample_ray with BSDF sampling; 1 = light/cosine mixture pdf; 2 = the reference's literal SPPM sample_ray:
 // the first Diffuse hit adds the pixel's pre-computed photon estimates and ends the path (photon_mapper.rs:345-352)
+//
+// Where the samples go.  `pixel_color += sample` runs in sample order in the reference (camera.rs:96-101) and f64 addition does
+// not commute, so the accumulator must see a pixel's samples in index order whatever the schedule.  A work unit = (8x8 tile,
+// <= UNIT_SPP consecutive sample indices).  A wave owns a small RING of unit buffers in global memory (RING_UNITS x 12 KB);
+// finished paths store their radiance there, an LDS counter per ring slot tells when a unit is complete, and the wave then
+// FOLDS it: lane = pixel, accum += the unit's samples in index order.  Units of one tile are folded in order across waves
+// through a per-tile ticket (= number of units folded).  Units are dealt sample-major (all tiles' unit 0, then all tiles'
+// unit 1, ...), so a unit's predecessor on the same tile was handed out thousands of units earlier and is normally long folded;
+// when it is not, the wave keeps tracing its newer units and retries (it only waits when its ring is full).  No deadlock: the
+// unfolded unit with the smallest index is at the head of its wave's ring and its predecessor is folded.
+// Accumulator and ticket cross waves on different XCDs (L2s are not coherent): both are accessed ONLY with 8-/4-byte agent-scope
+// atomics (served at the memory side), the folding wave drains its stores (s_waitcnt vmcnt(0)) before it advances the ticket.
 static const int REGEN_MIN = 8;
+static const int UNIT_SPP = 8;                              // sample indices per work unit, at most
+#ifndef RING_UNITS
+#define RING_UNITS 6                                         // unit buffers per wave
+#endif
+static const int UNIT_DOUBLES = UNIT_SPP * TILE_PIX * 3;    // 12 KB per unit
+DEV uint64_t ld_agent(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEV void st_agent(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Fold the wave's completed units, oldest first, into the accumulator (see "Where the samples go" below).  Returns how many
+// units were folded.  `idle`: the wave has nothing else to do, so it waits for the tile's previous unit instead of returning.
+__device__ __attribute__((noinline)) int fold_units(const uint32_t* rmeta, const double* wring, double* accum, unsigned int* tickets, int tiles_owned,
+                                                    bool first_launch, int r_head, int r_cnt, bool idle, int lane) {
+    int folded = 0;
+    while (r_cnt > 0) {
+        const uint32_t* m = rmeta + 4 * r_head;
+        if (__hip_atomic_load(&m[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) break;  // paths still running
+        const uint32_t unit = m[0], ns = m[1];
+        const uint32_t ult = unit % (uint32_t)tiles_owned, usub = unit / (uint32_t)tiles_owned;
+        const uint32_t tk = __hip_atomic_load(&tickets[ult], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tk != usub) {  // the tile's previous unit is not folded yet (rare): trace on unless nothing else is left to do
+            if (!idle) break;
+            __builtin_amdgcn_s_sleep(4);
+            continue;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's sample stores are in L2
+        {
+            uint64_t* acc = (uint64_t*)accum + ((size_t)ult * TILE_PIX + (size_t)lane) * 3;
+            double ax = 0., ay = 0., az = 0.;
+            if (!(usub == 0u && first_launch)) {
+                ax = __longlong_as_double(ld_agent(acc));
+                ay = __longlong_as_double(ld_agent(acc + 1));
+                az = __longlong_as_double(ld_agent(acc + 2));
+            }
+            const uint64_t* p = (const uint64_t*)wring + ((size_t)r_head * UNIT_SPP * TILE_PIX + (size_t)lane) * 3;
+            for (uint32_t si = 0; si < ns; si++) {  // pixel_color += sample, in sample order (camera.rs:96-101)
+                ax = ax + __longlong_as_double(ld_agent(p));
+                ay = ay + __longlong_as_double(ld_agent(p + 1));
+                az = az + __longlong_as_double(ld_agent(p + 2));
+                p += TILE_PIX * 3;
+            }
+            st_agent(acc, __double_as_longlong(ax));
+            st_agent(acc + 1, __double_as_longlong(ay));
+            st_agent(acc + 2, __double_as_longlong(az));
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // accumulator stores done before the ticket moves
+        if (lane == 0) __hip_atomic_store(&tickets[ult], usub + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        r_head = (r_head + 1 == RING_UNITS) ? 0 : r_head + 1;
+        r_cnt--;
+        folded++;
+    }
+    return folded;
+}
+
 template <bool LDS, bool GENERAL, int ACCEL, int INTEG>
-__global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, RenderK rk, double* __restrict__ samples,
-                                                      unsigned int* __restrict__ counter, int* __restrict__ err) {
+__global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, RenderK rk, double* __restrict__ ring, double* accum,
+                                                      unsigned int* tickets, unsigned int* __restrict__ counter, int* __restrict__ err) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // LDS map: [staged scene tables (LDS variants) | top-of-BVH Node2 cache (scene in L2/HBM)] [kernel 2: per-lane
-    // traversal stacks, stack2 x blockDim 32-bit words]
+    // traversal stacks, stack2 x blockDim 32-bit words] [per wave: RING_UNITS x {unit, samples, paths still running}]
     const uint32_t st_begin = (ACCEL == 2) ? sv.stage2_begin : 0u;
     const uint32_t st_end = (ACCEL == 2) ? sv.stage2_end : sv.stage_bytes;
     uint32_t staged = 0;  // bytes of LDS in front of the stacks
@@ -776,19 +840,24 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
     const int stk_stride = (int)blockDim.x;
     const int lane = threadIdx.x & 63;
     const uint64_t lanemask_lt = (1ull << lane) - 1ull;
+    const int wave = threadIdx.x >> 6;
+    // ring bookkeeping of this wave in LDS: unit index, its sample count, paths still running
+    uint32_t* rmeta = (uint32_t*)(smem + staged) + (size_t)((ACCEL == 2) ? sv.stack2 : 0u) * PT_BLOCK + (size_t)wave * RING_UNITS * 4;
+    double* wring = ring + ((size_t)blockIdx.x * (PT_BLOCK / 64) + (size_t)wave) * RING_UNITS * UNIT_DOUBLES;
+    int r_head = 0, r_cnt = 0;  // oldest unit in flight, units in flight (wave-uniform)
 
     // current work unit (wave-uniform); `pool` paths, of which `next` have been handed out.  A wave does not drain a unit
     // before it takes the next one: as soon as the pool is empty and a lane is free the next unit is fetched, so the lanes
     // still finishing long paths of the old unit run beside fresh paths of the new one (a finished path knows where its
     // sample goes: out_slot is per lane).  Only the end of the launch has a tail.
-    int lt = 0, tx = 0, ty = 0, s0 = 0, pool = 0, next = 0;
+    int tx = 0, ty = 0, s0 = 0, pool = 0, next = 0, cur_slot = 0;
     bool more_units = true;
 
     bool alive = false;
     D3 o = mk(0, 0, 0), d = mk(0, 0, 1), beta = mk(1, 1, 1), L = mk(0, 0, 0);
     int depth = 0;
     int pix_id = 0;
-    uint32_t out_slot = 0;  // index of this path's sample in the launch's sample buffer (make_plan keeps it below 2^32)
+    uint32_t out_slot = 0;  // this path's sample in the wave's ring: (ring slot * UNIT_SPP + sample within the unit) * 64 + pixel
     Rng rng;
     rng.s = 0;
     {
@@ -798,22 +867,43 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
             // the regeneration code runs for the whole wave however few lanes need it: wait until REGEN_MIN lanes are free
             // (measured: 1 -> 2142, 4 -> 2174, 8 -> 2228, 12 -> 2210, 16 -> 2189, 24 -> 2094 Msamples/s)
             if ((int)__popcll(dead) < REGEN_MIN && dead != ~0ull) dead = 0ull;
-            if (dead != 0ull && next >= pool && more_units) {
+            // ---- fold completed units, oldest first: looked at only when the wave is about to fetch a unit (or has run out of them),
+            // i.e. about once per unit; out of line, so that its registers stay out of the hot loop ----
+            if (dead != 0ull && next >= pool && r_cnt > 0 &&
+                __hip_atomic_load(&rmeta[4 * r_head + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) {
+                const bool idle = dead == ~0ull && (r_cnt == RING_UNITS || !more_units);
+                const int folded = fold_units(rmeta, wring, accum, tickets, rk.tiles_owned, rk.s_begin == 0, r_head, r_cnt, idle, lane);
+                r_head += folded;
+                if (r_head >= RING_UNITS) r_head -= RING_UNITS;
+                r_cnt -= folded;
+            }
+            if (dead != 0ull && next >= pool && more_units && r_cnt < RING_UNITS) {
                 unsigned int unit = 0;
                 if (lane == 0) unit = atomicAdd(counter, 1u);
                 unit = __builtin_amdgcn_readfirstlane(unit);
                 if (unit >= (unsigned)rk.n_units) {
                     more_units = false;  // every wave gets here: the counter only grows
                 } else {
-                    lt = (int)(unit / (unsigned)rk.subs_per_tile);
-                    const int sub_i = (int)(unit - (unsigned)lt * (unsigned)rk.subs_per_tile);
-                    const int tile = lt * rk.world + rk.rank;
+                    const int ult = (int)(unit % (unsigned)rk.tiles_owned);  // sample-major: all tiles' unit k before any tile's unit k+1
+                    const int sub_i = (int)(unit / (unsigned)rk.tiles_owned);
+                    const int tile = ult * rk.world + rk.rank;
                     tx = tile % rk.tiles_x;
                     ty = tile / rk.tiles_x;
                     s0 = rk.s_begin + sub_i * rk.sub_spp;
                     const int s1 = min(s0 + rk.sub_spp, rk.s_end);
                     pool = (s1 - s0) * TILE_PIX;
                     next = 0;
+                    cur_slot = r_head + r_cnt;
+                    if (cur_slot >= RING_UNITS) cur_slot -= RING_UNITS;
+                    r_cnt++;
+                    if (lane == 0) {
+                        uint32_t* m = rmeta + 4 * cur_slot;
+                        m[0] = unit;
+                        m[1] = (uint32_t)(s1 - s0);
+                        // paths the unit will run: its pixels inside the image (edge tiles are partial) x its sample indices
+                        const int w_in = min(TILE_W, rk.width - tx * TILE_W), h_in = min(TILE_H, rk.height - ty * TILE_H);
+                        __hip_atomic_store(&m[2], (uint32_t)((s1 - s0) * w_in * h_in), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
                 }
             }
             if (dead != 0ull && next < pool) {
@@ -836,13 +926,13 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
                         L = mk(0., 0., 0.);
                         depth = rk.max_depth;
                         pix_id = y * rk.width + x;
-                        out_slot = ((uint32_t)lt * (uint32_t)rk.chunk_spp + (uint32_t)(s - rk.s_begin)) * (uint32_t)TILE_PIX + (uint32_t)pix;
+                        out_slot = ((uint32_t)cur_slot * (uint32_t)UNIT_SPP + (uint32_t)(k >> 6)) * (uint32_t)TILE_PIX + (uint32_t)pix;
                         alive = true;
-                    }
+                    }  // (a pixel of an edge tile outside the image gets no path; finalize_kernel zeroes it whatever the fold adds)
                 }
             }
             if (__ballot(alive) == 0ull) {
-                if (next >= pool && !more_units) break;
+                if (next >= pool && !more_units && r_cnt == 0) break;
                 continue;
             }
             // ---- one path segment: sample_ray's loop body, photon_mapper.rs:335-362 ----
@@ -877,10 +967,11 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
                     }
                 }
                 if (done) {
-                    double* dst = samples + 3 * (size_t)out_slot;
+                    double* dst = wring + 3 * (size_t)out_slot;
                     dst[0] = L.x;
                     dst[1] = L.y;
                     dst[2] = L.z;
+                    atomicSub(rmeta + 4 * (out_slot >> 9) + 2, 1u);  // one path less running in that ring slot (UNIT_SPP * 64 = 512 per slot)
                     alive = false;
                 }
             }
@@ -888,31 +979,6 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
     }
 }
 
-
-// per pixel: accum += samples in sample order (camera.rs:96-101). One thread per (tile, pixel).
-__global__ void reduce_kernel(const double* __restrict__ samples, double* __restrict__ accum, int64_t n_pix, int chunk_spp,
-                              int n_s, int first) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_pix) return;
-    int64_t lt = i >> 6;
-    int pix = (int)(i & 63);
-    double ax = 0., ay = 0., az = 0.;
-    if (!first) {
-        ax = accum[3 * i];
-        ay = accum[3 * i + 1];
-        az = accum[3 * i + 2];
-    }
-    const double* p = samples + ((size_t)lt * chunk_spp * TILE_PIX + pix) * 3;
-    for (int s = 0; s < n_s; s++) {
-        ax = ax + p[0];
-        ay = ay + p[1];
-        az = az + p[2];
-        p += TILE_PIX * 3;
-    }
-    accum[3 * i] = ax;
-    accum[3 * i + 1] = ay;
-    accum[3 * i + 2] = az;
-}
 // pixel_color /= spp (camera.rs:102); pixels of edge tiles that fall outside the image are zeroed
 __global__ void finalize_kernel(const double* __restrict__ accum, double* __restrict__ tiles, int64_t n_pix, int spp, int width,
                                 int height, int tiles_x, int rank, int world) {
@@ -1081,19 +1147,28 @@ static const DevInfo& dev_info(int dev) {
     if (di.lds_max > 160 * 1024) di.lds_max = 160 * 1024;
     return g_devinfo.emplace(dev, di).first->second;
 }
-// A workspace = the sample buffer, the accumulator and a small block {work counter, error flag, camera, stats}.
-// Kept for the life of the process and reused by later calls on the same device (grown when a call needs more).
+// A workspace = the waves' unit rings, the accumulator, the per-tile tickets and a small block {work counter, error flag}.
+// Kept for the life of the process and reused by later calls on the same device (grown when a call needs more);
+// rt_release_workspaces frees the idle ones.
 struct Workspace {
     int device = -1;
     bool busy = false;
-    void *samples = nullptr, *accum = nullptr, *small = nullptr;
-    size_t samples_bytes = 0, accum_bytes = 0;
+    void *ring = nullptr, *accum = nullptr, *tickets = nullptr, *small = nullptr;
+    size_t ring_bytes = 0, accum_bytes = 0, ticket_bytes = 0;
 };
 static std::vector<Workspace*> g_ws;
 static const size_t WS_SMALL = 1024;
+static void grow(void*& p, size_t& have, size_t need) {
+    if (have >= need) return;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    have = 0;
+    HIP_CHECK(hipMalloc(&p, need));
+    have = need;
+}
 struct WorkspaceLease {
     Workspace* w = nullptr;
-    WorkspaceLease(int dev, size_t need_samples, size_t need_accum) {
+    WorkspaceLease(int dev, size_t need_ring, size_t need_accum, size_t need_tickets) {
         {
             std::lock_guard<std::mutex> g(g_mu);
             for (Workspace* c : g_ws)
@@ -1110,22 +1185,9 @@ struct WorkspaceLease {
         }
         try {
             if (!w->small) HIP_CHECK(hipMalloc(&w->small, WS_SMALL));
-            if (tuning().ws_limit_mb > 0 && need_samples > ((size_t)tuning().ws_limit_mb << 20))  // rt_tuning test hook
-                throw RtError(RT_ERR_HIP, "sample buffer over rt_tuning.workspace_limit_mb");
-            if (w->samples_bytes < need_samples) {
-                if (w->samples) (void)hipFree(w->samples);
-                w->samples = nullptr;
-                w->samples_bytes = 0;
-                HIP_CHECK(hipMalloc(&w->samples, need_samples));
-                w->samples_bytes = need_samples;
-            }
-            if (w->accum_bytes < need_accum) {
-                if (w->accum) (void)hipFree(w->accum);
-                w->accum = nullptr;
-                w->accum_bytes = 0;
-                HIP_CHECK(hipMalloc(&w->accum, need_accum));
-                w->accum_bytes = need_accum;
-            }
+            grow(w->ring, w->ring_bytes, need_ring);
+            grow(w->accum, w->accum_bytes, need_accum);
+            grow(w->tickets, w->ticket_bytes, need_tickets);
         } catch (...) {
             std::lock_guard<std::mutex> g(g_mu);
             w->busy = false;
@@ -1137,8 +1199,29 @@ struct WorkspaceLease {
         w->busy = false;
     }
 };
+size_t release_workspaces() {  // frees every idle workspace (all devices); returns the bytes released
+    std::lock_guard<std::mutex> g(g_mu);
+    size_t freed = 0;
+    int cur = 0;
+    const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+    for (auto it = g_ws.begin(); it != g_ws.end();) {
+        Workspace* w = *it;
+        if (w->busy) {
+            ++it;
+            continue;
+        }
+        (void)hipSetDevice(w->device);
+        for (void* p : {w->ring, w->accum, w->tickets, w->small})
+            if (p) (void)hipFree(p);
+        freed += w->ring_bytes + w->accum_bytes + w->ticket_bytes + WS_SMALL;
+        delete w;
+        it = g_ws.erase(it);
+    }
+    if (have_cur) (void)hipSetDevice(cur);
+    return freed;
+}
 
-typedef void (*pt_fn)(FlatView, CamK, RenderK, double*, unsigned int*, int*);
+typedef void (*pt_fn)(FlatView, CamK, RenderK, double*, double*, unsigned int*, unsigned int*, int*);
 
 template <int ACCEL>
 static pt_fn pick_pt_kernel(bool lds, bool general, int integ) {
@@ -1150,7 +1233,7 @@ static pt_fn pick_pt_kernel(bool lds, bool general, int integ) {
 
 void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& plan_in, double* d_tiles, void* stream_, rt_stats* st) {
     if (!s.committed) throw RtError(RT_ERR_NOT_COMMITTED, "scene not committed");
-    RenderPlan plan = plan_in;  // the launch size may shrink below if the sample buffer cannot be allocated
+    const RenderPlan& plan = plan_in;
     hipStream_t stream = (hipStream_t)stream_;
     int dev = 0;
     HIP_CHECK(hipGetDevice(&dev));
@@ -1172,7 +1255,8 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
     if (kernel == 2 && !accel2_usable)
         throw RtError(RT_ERR_UNSUPPORTED, "kernel 2 requested but no usable accel for this scene/camera (unbounded item, depth overflow, stacks "
                                           "larger than LDS, negative t_min, or camera farther than 64x the scene extent); use kernel 0/1");
-    const size_t stack_bytes = (kernel == 2) ? stack2_bytes : 0;
+    const size_t ring_meta = (size_t)(PT_BLOCK / 64) * RING_UNITS * 4 * sizeof(uint32_t);  // per-wave ring bookkeeping, behind the stacks
+    const size_t stack_bytes = ((kernel == 2) ? stack2_bytes : 0) + ring_meta;
     const size_t hot_bytes = (kernel == 2) ? hot2 : hot1;
     const bool lds = hot_bytes > 0 && hot_bytes + stack_bytes <= lds_max && !tuning().no_lds;
     const int integ = plan.integrator;
@@ -1195,31 +1279,19 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
     const int grid = di.cus * blocks_per_cu;
 
     const int64_t n_pix = plan.tiles_owned * TILE_PIX;
-    // the sample buffer of one launch (make_plan budgets up to 12 GiB): on a GPU that cannot spare it, halve the launch
-    std::unique_ptr<WorkspaceLease> lease_p;
-    for (;;) {
-        try {
-            lease_p.reset(new WorkspaceLease(dev, std::max<size_t>(16, (size_t)n_pix * plan.spp_chunk * 3 * sizeof(double)),
-                                             std::max<size_t>(16, (size_t)n_pix * 3 * sizeof(double))));
-            break;
-        } catch (const RtError&) {
-            (void)hipGetLastError();
-            if (plan.spp_chunk <= 1) throw;
-            plan.spp_chunk = (plan.spp_chunk + 1) / 2;
-            plan.sub_spp = std::min(plan.sub_spp, plan.spp_chunk);
-        }
-    }
-    WorkspaceLease& lease = *lease_p;
+    // workspace: RING_UNITS unit buffers (12 KB) per resident wave -- independent of the image -- plus accumulator and tickets
+    const size_t ring_bytes = (size_t)grid * (PT_BLOCK / 64) * RING_UNITS * UNIT_DOUBLES * sizeof(double);
+    WorkspaceLease lease(dev, ring_bytes, std::max<size_t>(16, (size_t)n_pix * 3 * sizeof(double)),
+                         std::max<size_t>(16, (size_t)plan.tiles_owned * sizeof(unsigned int)));
     struct Ptr {
         void* p;
     };
     char* small = (char*)lease.w->small;
-    Ptr samples{lease.w->samples}, accum{lease.w->accum}, counter{small}, err{small + 16}, camk{small + 64};
+    Ptr ringp{lease.w->ring}, accum{lease.w->accum}, tickets{lease.w->tickets}, counter{small}, err{small + 16};
     HIP_CHECK(hipMemsetAsync(small, 0, WS_SMALL, stream));
     Events events;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> pt_ev, red_ev;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pt_ev;
     CamK ck = to_camk(cam);
-    HIP_CHECK(hipMemcpyAsync(camk.p, &ck, sizeof(CamK), hipMemcpyHostToDevice, stream));
     int launches = 0;
     for (int s0 = 0; s0 < plan.spp; s0 += plan.spp_chunk) {
         const int s1 = std::min(s0 + plan.spp_chunk, plan.spp);
@@ -1233,26 +1305,20 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
         if (units > 0x7FFFFFFF) throw RtError(RT_ERR_UNSUPPORTED, "too many work units per launch");
         rk.n_units = (int)units;
         rk.tiles_x = plan.tiles_x; rk.rank = plan.rank; rk.world = plan.world;
-        rk.chunk_spp = plan.spp_chunk;
+        rk.tiles_owned = (int)std::max<int64_t>(1, plan.tiles_owned);
         rk.sppm_est = plan.sppm_est;
         rk.n_top = n_top;
         HIP_CHECK(hipMemsetAsync(counter.p, 0, sizeof(unsigned int), stream));
-        hipEvent_t e0 = events.make(), e1 = events.make(), e2 = events.make();
+        HIP_CHECK(hipMemsetAsync(tickets.p, 0, std::max<size_t>(16, (size_t)plan.tiles_owned * sizeof(unsigned int)), stream));
+        hipEvent_t e0 = events.make(), e1 = events.make();
         HIP_CHECK(hipEventRecord(e0, stream));
         if (rk.n_units > 0) {
-            hipLaunchKernelGGL(fn, dim3(grid), dim3(PT_BLOCK), smem, stream, view, ck, rk, (double*)samples.p, (unsigned int*)counter.p,
-                               (int*)err.p);
+            hipLaunchKernelGGL(fn, dim3(grid), dim3(PT_BLOCK), smem, stream, view, ck, rk, (double*)ringp.p, (double*)accum.p,
+                               (unsigned int*)tickets.p, (unsigned int*)counter.p, (int*)err.p);
             HIP_CHECK(hipGetLastError());
         }
         HIP_CHECK(hipEventRecord(e1, stream));
-        if (n_pix > 0) {
-            hipLaunchKernelGGL(reduce_kernel, dim3((unsigned)((n_pix + 255) / 256)), dim3(256), 0, stream, (const double*)samples.p,
-                               (double*)accum.p, n_pix, plan.spp_chunk, s1 - s0, s0 == 0 ? 1 : 0);
-            HIP_CHECK(hipGetLastError());
-        }
-        HIP_CHECK(hipEventRecord(e2, stream));
         pt_ev.emplace_back(e0, e1);
-        red_ev.emplace_back(e1, e2);
         launches++;
     }
     if (n_pix > 0) {
@@ -1264,19 +1330,14 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
     HIP_CHECK(hipMemcpyAsync(&h_err, err.p, sizeof(int), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
     if (st) {
-        double kms = 0, rms = 0;
+        double kms = 0;
         for (auto& p : pt_ev) {
             float ms = 0;
             HIP_CHECK(hipEventElapsedTime(&ms, p.first, p.second));
             kms += ms;
         }
-        for (auto& p : red_ev) {
-            float ms = 0;
-            HIP_CHECK(hipEventElapsedTime(&ms, p.first, p.second));
-            rms += ms;
-        }
         st->kernel_ms = kms;
-        st->reduce_ms = rms;
+        st->reduce_ms = 0.;  // the ordered reduction happens inside pt_kernel
         st->launches = launches;
         st->kernel_used = kernel;
         st->scene_in_lds = lds ? 1 : 0;
@@ -1284,6 +1345,7 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
         st->grid_blocks = grid;
         st->spp_chunk = plan.spp_chunk;
         st->scene_bytes = s.flat.blob.size();
+        st->reserved[1] = (uint64_t)(ring_bytes + (size_t)n_pix * 3 * sizeof(double) + (size_t)plan.tiles_owned * sizeof(unsigned int));  // workspace bytes
     }
     if (h_err) throw RtError(RT_ERR_UNIT_ZERO, "unitizing zero vector (device)");
 }

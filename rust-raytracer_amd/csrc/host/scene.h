@@ -92,7 +92,7 @@ namespace rtamd {
 
 // rt_tuning_set's process-wide state (abi.cpp): the only thing besides the arguments that influences a render
 struct Tuning {
-    int no_lds = 0, n_top = -1, sub_spp = 0, sample_budget_mb = 0, ws_limit_mb = 0, max_leaf = 0, sppm_cap = 0, knn_cand = -1;
+    int no_lds = 0, n_top = -1, sub_spp = 0, max_leaf = 0, sppm_cap = 0, knn_cand = -1;
     double c_box = 0.;
 };
 const Tuning& tuning();

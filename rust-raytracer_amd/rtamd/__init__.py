@@ -47,7 +47,9 @@ class rt_stats(C.Structure):
                 ("grid_blocks", C.c_int32), ("spp_chunk", C.c_int32), ("scene_bytes", C.c_uint64), ("reserved", C.c_uint64 * 4)]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        d["workspace_bytes"] = int(self.reserved[1])
+        return d
 
 
 class rt_sppm_config(C.Structure):
@@ -56,9 +58,9 @@ class rt_sppm_config(C.Structure):
 
 
 class rt_tuning(C.Structure):
-    _fields_ = [("no_lds", C.c_int32), ("top_nodes", C.c_int32), ("sub_spp", C.c_int32), ("sample_budget_mb", C.c_int32),
-                ("workspace_limit_mb", C.c_int32), ("max_leaf", C.c_int32), ("sppm_photon_capacity", C.c_int32),
-                ("sppm_knn_candidates", C.c_int32), ("sah_box_cost", C.c_double)]
+    _fields_ = [("no_lds", C.c_int32), ("top_nodes", C.c_int32), ("sub_spp", C.c_int32), ("reserved", C.c_int32),
+                ("max_leaf", C.c_int32), ("sppm_photon_capacity", C.c_int32), ("sppm_knn_candidates", C.c_int32),
+                ("sah_box_cost", C.c_double)]
 
 
 class rt_object_desc(C.Structure):
@@ -89,6 +91,7 @@ _SIGS = [
     ("rt_device_count", C.c_int, []),
     ("rt_tuning_default", None, [C.POINTER(rt_tuning)]),
     ("rt_tuning_set", C.c_int, [C.POINTER(rt_tuning)]),
+    ("rt_release_workspaces", C.c_int64, []),
     ("rt_scene_create", C.c_int, [C.POINTER(C.c_void_p)]),
     ("rt_scene_destroy", None, [C.c_void_p]),
     ("rt_texture_constant", C.c_int, [C.c_void_p, _d3]),
@@ -457,6 +460,11 @@ def set_tuning(**fields):
             raise TypeError("unknown rt_tuning field %r" % k)
         setattr(t, k, v)
     _chk(lib().rt_tuning_set(C.byref(t)))
+
+
+def release_workspaces():
+    """rt_release_workspaces: free the idle per-device render workspaces; returns the bytes released."""
+    return int(lib().rt_release_workspaces())
 
 
 def tiles_owned(params):

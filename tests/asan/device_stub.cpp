@@ -16,4 +16,5 @@ void dev_free(void*) {}
 void dev_copy_to_host(void*, const void*, size_t) { none(); }
 void dev_set_device(int) { none(); }
 void free_device_copies(rt_scene&) {}
+size_t release_workspaces() { return 0; }
 }  // namespace rtamd

@@ -456,28 +456,44 @@ def test_degenerate_image_sizes_match_the_oracle(w, h):
         assert np.array_equal(img, exp, equal_nan=True), (kernel, img, exp)
 
 
-def test_launches_shrink_when_the_sample_buffer_cannot_be_allocated(tuning):
-    """make_plan budgets up to 12 GiB for the per-launch sample buffer; a device that cannot spare it gets smaller launches
-    (halved until the buffer fits) and, since samples are reduced in sample order, the same image."""
+def test_render_workspace_is_small_and_can_be_released():
+    """samples live in per-wave unit rings (6 x 12 KB per resident wave) and are folded into the accumulator inside the
+    kernel: the device workspace does not grow with spp, stays far below 1 GiB for a 1200 x 1200 frame, and
+    rt_release_workspaces gives it back."""
+    import rtamd
     world, cam, _ = _pair("scene_500.json")
-    w, h, spp = 256, 192, 40          # 40 spp x 48 Ki pixels x 24 B = 45 MiB in one launch
-    full, st = world.render(cam, width=w, height=h, spp=spp, seed=5)
-    assert st["launches"] == 1 and st["spp_chunk"] == spp
-    tuning(workspace_limit_mb=8)
-    small, st2 = world.render(cam, width=w, height=h, spp=spp, seed=5)
-    assert st2["spp_chunk"] == 5 and st2["launches"] == 8           # 40 -> 20 -> 10 -> 5 sample indices per launch
-    assert np.array_equal(small, full)
+    rtamd.release_workspaces()
+    _, a = world.render(cam, width=1200, height=1200, spp=2, seed=1)
+    _, b = world.render(cam, width=1200, height=1200, spp=24, seed=1)
+    assert a["workspace_bytes"] == b["workspace_bytes"] and a["launches"] == b["launches"] == 1
+    assert b["workspace_bytes"] < 512 * 1024 * 1024 and b["reduce_ms"] == 0.0
+    freed = rtamd.release_workspaces()
+    assert freed >= b["workspace_bytes"]
+    again, _ = world.render(cam, width=64, height=64, spp=2, seed=1)
+    assert again.max() > 0
 
 
 def test_image_does_not_depend_on_the_work_partition_knobs(tuning):
-    """work-unit size and launch size only change the schedule (which wave traces which path, in how many launches)."""
+    """work-unit size and launch size only change the schedule (which wave traces which path, which wave folds which unit,
+    in how many launches); units of one tile are folded in sample order through the per-tile tickets."""
     world, cam, _ = _pair("scene_500.json")
     w, h, spp = 96, 72, 24
     full, st = world.render(cam, width=w, height=h, spp=spp, seed=9)
-    tuning(sub_spp=3, sample_budget_mb=1)                       # 1 MiB: a few sample indices per launch
-    other, st2 = world.render(cam, width=w, height=h, spp=spp, seed=9)
-    assert st2["launches"] > st["launches"]
-    assert np.array_equal(other, full)
+    assert st["launches"] == 1
+    for sub, chunk in ((3, 0), (1, 7), (8, 24), (5, 11)):
+        tuning(sub_spp=sub)
+        other, st2 = world.render(cam, width=w, height=h, spp=spp, seed=9, spp_chunk=chunk)
+        assert st2["launches"] == (1 if chunk == 0 else -(-spp // chunk))
+        assert np.array_equal(other, full), (sub, chunk)
+
+
+def test_one_tile_many_units_fold_in_order():
+    """an 8 x 8 image is ONE tile: its 125 units (1000 spp) are traced by 125 different waves and must be folded strictly in
+    sample order through the tile's ticket; compare with the oracle's sequential sum."""
+    world, cam, ref = _pair("scene_10.json", aspect=1.0)
+    img, st = world.render(cam, width=8, height=8, spp=1000, seed=4)
+    exp, _ = ref.render(8, 8, 1000, seed=4)
+    _assert_same(img, exp, "one tile, 125 units")
 
 
 def test_negative_t_min_goes_through_the_reference_order_kernel():
