@@ -64,6 +64,17 @@ typedef struct rt_camera {
     double focus_dist;
 } rt_camera;
 
+/* The Camera struct as the reference STORES it (camera.rs:12-21: the derived frame, not the constructor arguments): a host
+ * that already owns a `Camera` hands these eight fields over as they are. */
+typedef struct rt_camera_frame {
+    double origin[3];
+    double lower_left_corner[3];
+    double horizontal[3];
+    double vertical[3];
+    double u[3], v[3], w[3];
+    double lens_radius;
+} rt_camera_frame;
+
 /* capture_image's compile-time constants made run-time (SURVEY.md s5 "Config / flags"). */
 typedef struct rt_params {
     int32_t width;       /* CONFIGS.width  (main.rs:34) default 800 */
@@ -136,6 +147,9 @@ int rt_material_lambertian(rt_scene* s, int albedo_tex);
 int rt_material_metal(rt_scene* s, int albedo_tex, double fuzz);
 int rt_material_dielectric(rt_scene* s, double ir, int albedo_tex);
 int rt_material_diffuse_light(rt_scene* s, int emit_tex);
+/* material.rs:213-231  Isotropic::new(albedo) -- commented out in the reference; the phase function of a ConstantMedium:
+ * scatter = (albedo, Ray(p, random_in_unit_sphere())); treated as a pass-through (Specular) interaction by every integrator */
+int rt_material_isotropic(rt_scene* s, int albedo_tex);
 
 /* objects/sphere.rs:9-13 */
 int rt_object_sphere(rt_scene* s, const double center[3], double radius, int material);
@@ -150,6 +164,11 @@ int rt_object_cube(rt_scene* s, const double box_min[3], const double box_max[3]
  * the photon power (flux * scale) of the SPPM pre-pass */
 int rt_object_sphere_light(rt_scene* s, const double center[3], double radius, const double flux[3], double scale);
 int rt_object_xz_rect_light(rt_scene* s, double x0, double z0, double x1, double z1, double y, const double flux[3], double scale);
+/* objects/medium.rs:16 ConstantMedium::new(d, boundary, phase_function): constant-density participating medium inside
+ * `boundary` (any Hitable with a box, not itself a medium).  Its hit() draws a random number (medium.rs:37-38), so scenes with a
+ * medium are rendered by the reference-order kernel only (kernel 2 and the SPPM pre-pass refuse them); the logarithm is the
+ * deterministic rtamd-ln-1 (csrc/common/detlog.h, < 1 ulp from libm). */
+int rt_object_constant_medium(rt_scene* s, double density, int boundary, int phase_material);
 /* objects/mesh.rs:149 Mesh::load_obj given parsed arrays: positions/normals n_vert*3, indices n_tri*3.
  * normals == NULL -> RT_ERR_NO_NORMALS unless synthesize_normals != 0 (area-weighted smooth normals). */
 int rt_object_mesh(rt_scene* s, int n_vert, const double* positions, const double* normals, int n_tri, const uint32_t* indices,
@@ -158,6 +177,14 @@ int rt_object_mesh(rt_scene* s, int n_vert, const double* positions, const doubl
 int rt_object_mesh_obj(rt_scene* s, const char* obj_path, int material, int synthesize_normals, uint64_t bvh_seed);
 /* objects/transform.rs:17 Transform::new(rotate_in_degree, scale, translate, obj): M = T*S*Rx*Ry*Rz */
 int rt_object_transform(rt_scene* s, const double rotate_deg[3], const double scale[3], const double translate[3], int object);
+/* Transform as the reference stores it (transform.rs:9-14: obj, trans, inverse_trans; row-major 4x4).  inverse_trans may be
+ * NULL (computed as try_inverse does; RT_ERR_SINGULAR if there is none). */
+int rt_object_transform_matrix(rt_scene* s, const double trans[16], const double* inverse_trans, int object);
+/* Triangle::new on shared vertex arrays (mesh.rs:8-53: a, b, c index Arc<Vec<Vec3>> positions / normals): rt_mesh_data registers
+ * the arrays once (returns a mesh id, not an object id), rt_object_triangle one triangle; the host keeps its own BVHNode tree
+ * over them (rt_object_bvh_node), e.g. Mesh.bvh as BVHNode::new really built it. */
+int rt_mesh_data(rt_scene* s, int n_vert, const double* positions, const double* normals);
+int rt_object_triangle(rt_scene* s, int mesh, uint32_t a, uint32_t b, uint32_t c, int material);
 /* impl Hitable for Vec<Arc<dyn Hitable>> (objects/hit.rs:56-93) */
 int rt_object_list(rt_scene* s, int n, const int* objects);
 /* BVHNode::construct(left,right) (bvh.rs:47-58) and BVHNode::new(src_objects) (bvh.rs:60-83; split axes from
@@ -172,10 +199,11 @@ int rt_object_bounding_box(const rt_scene* s, int object, double out_min_max[6])
  *   sphere:    v = {center[3], radius}                      (objects/sphere.rs:9-13)
  *   rect:      v = {a0, b0, a1, b1, k}, axis = constant axis (0: YZRectangle x=k, 1: XZRectangle y=k, 2: XYRectangle z=k)
  *   triangle:  v = {ia, ib, ic} vertex indices of its mesh  (objects/mesh.rs:8-14)
+ *   medium:    v = {density}, material = phase function, children = {boundary}   (objects/medium.rs:9-13)
  *   cube / list / mesh / transform / bvh: children only (cube: its 6 sides; mesh: its inner BVHNode; bvh: {left, right}) */
 typedef enum rt_object_type {
     RT_OBJ_SPHERE = 0, RT_OBJ_RECT = 1, RT_OBJ_CUBE = 2, RT_OBJ_TRIANGLE = 3, RT_OBJ_MESH = 4, RT_OBJ_TRANSFORM = 5,
-    RT_OBJ_LIST = 6, RT_OBJ_BVH = 7
+    RT_OBJ_LIST = 6, RT_OBJ_BVH = 7, RT_OBJ_MEDIUM = 8
 } rt_object_type;
 typedef struct rt_object_desc {
     int32_t type;        /* rt_object_type */
@@ -219,6 +247,9 @@ int rt_scene_info_get(const rt_scene* s, rt_scene_info* out);
  * row-major, y down, into caller-owned HOST memory out_rgb[height*width*3].  world > 1 renders only this
  * rank's tiles (others left 0). */
 int rt_render(const rt_scene* s, const rt_camera* cam, const rt_params* p, double* out_rgb, rt_stats* stats);
+/* the same for a host that owns a constructed Camera (its stored frame); rt_camera_frame_from = Camera::new (camera.rs:24-55) */
+int rt_render_camera_frame(const rt_scene* s, const rt_camera_frame* frame, const rt_params* p, double* out_rgb, rt_stats* stats);
+int rt_camera_frame_from(const rt_camera* cam, rt_camera_frame* out);
 
 /* The reference's main.rs:52-54 as it really is: SPPMIntegrator::new(world) (photon_mapper.rs:139-233: `iterations` x
  * {photons_per_iter photon paths -> global + caustic photon maps; one eye ray per pixel; progressive radius update}) followed
@@ -267,7 +298,7 @@ int rt_write_png(const char* path, int width, int height, const uint8_t* rgb);
 int rt_debug_rng_device(uint64_t seed, uint64_t pixel, uint64_t sample, int n, uint64_t* out_host);
 /* host-side restatement of the same stream (used by BVHNode::new's axis draws) */
 int rt_debug_rng_host(uint64_t seed, uint64_t pixel, uint64_t sample, int n, uint64_t* out_host);
-/* device f64 sqrt / divide, element-wise, for the correctly-rounded check: op 0 = sqrt(a), 1 = a/b */
+/* device f64 sqrt / divide / rtamd-ln-1, element-wise: op 0 = sqrt(a), 1 = a/b, 2 = det_ln(a) */
 int rt_debug_math_device(int op, size_t n, const double* a_host, const double* b_host, double* out_host);
 /* closest hit of explicit world-space rays through device traversal `kernel` (1 or 2): rays n*6 (orig,dir);
  * out n*12 = {hit, t, p[3], normal[3], front_face, u, v, leaf index in the reference-order program} */

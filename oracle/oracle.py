@@ -49,6 +49,12 @@ def lib():
     L.orc_mat_metal.argtypes = [C.c_void_p, C.c_int, C.c_double]
     L.orc_mat_dielectric.argtypes = [C.c_void_p, C.c_double, C.c_int]
     L.orc_mat_diffuse_light.argtypes = [C.c_void_p, C.c_int]
+    L.orc_mat_isotropic.argtypes = [C.c_void_p, C.c_int]
+    L.orc_constant_medium.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int]
+    L.orc_hit_rng.argtypes = [C.c_void_p, C.c_int, c_double_p, c_double_p, C.c_double, C.c_double, C.c_uint64, C.c_uint64, C.c_uint64,
+                              c_double_p, C.POINTER(C.c_int)]
+    L.orc_det_ln.argtypes = [C.c_double]
+    L.orc_det_ln.restype = C.c_double
     L.orc_sphere.argtypes = [C.c_void_p] + [C.c_double] * 4 + [C.c_int]
     L.orc_rect.argtypes = [C.c_void_p, C.c_int] + [C.c_double] * 5 + [C.c_int]
     L.orc_cube.argtypes = [C.c_void_p, c_double_p, c_double_p, C.c_int]
@@ -147,6 +153,12 @@ class Scene:
 
     def DiffuseLight(self, tex):
         return self._chk(self.L.orc_mat_diffuse_light(self.h, tex), "DiffuseLight")
+
+    def Isotropic(self, tex):
+        return self._chk(self.L.orc_mat_isotropic(self.h, tex), "Isotropic")
+
+    def ConstantMedium(self, density, boundary, phase_function):
+        return self._chk(self.L.orc_constant_medium(self.h, float(density), boundary, phase_function), "ConstantMedium")
 
     # hitables
     def Sphere(self, center, radius, mat):
@@ -248,9 +260,17 @@ class Scene:
         self._chk(rc, "render")
         return out, dict(zip(COUNTER_NAMES, [int(c) for c in cnt]))
 
-    def hit(self, orig, direction, t_min=1e-3, t_max=float("inf"), obj=-1):
+    def hit(self, orig, direction, t_min=1e-3, t_max=float("inf"), obj=-1, key=None):
+        """closest hit of `obj` (default: the root).  key = (seed, pixel, sample): the RNG stream a ConstantMedium draws from;
+        self.last_draws then holds how many numbers the query consumed."""
         out = (C.c_double * 12)()
-        self._chk(self.L.orc_hit(self.h, obj, _d3(orig), _d3(direction), float(t_min), float(t_max), out), "hit")
+        if key is None:
+            self._chk(self.L.orc_hit(self.h, obj, _d3(orig), _d3(direction), float(t_min), float(t_max), out), "hit")
+        else:
+            n = C.c_int(0)
+            self._chk(self.L.orc_hit_rng(self.h, obj, _d3(orig), _d3(direction), float(t_min), float(t_max), int(key[0]), int(key[1]),
+                                         int(key[2]), out, C.byref(n)), "hit")
+            self.last_draws = n.value
         if out[0] == 0.0:
             return None
         return dict(t=out[1], p=np.array(out[2:5]), normal=np.array(out[5:8]), front_face=bool(out[8]), uv=(out[9], out[10]),
@@ -311,6 +331,10 @@ def vec3_op(op, a, b=None, s=0.0):
 def aabb_hit(box_min, box_max, orig, direction, t_min, t_max):
     box = (C.c_double * 6)(*[float(x) for x in list(box_min) + list(box_max)])
     return bool(lib().orc_aabb_hit(box, _d3(orig), _d3(direction), float(t_min), float(t_max)))
+
+
+def det_ln(x):
+    return lib().orc_det_ln(float(x))
 
 
 def schlick(cosine, ref_idx):

@@ -10,7 +10,10 @@
 // PINNING STATUS
 //   * Vec3 arithmetic: pinned by the reference's own 24 #[test]s
 //     (raytracer/src/vec3.rs:425-564), replayed in tests/test_oracle_vec3.py.
-//   * Everything else (intersection, BVH, scatter, camera, tonemap, images):
+//   * Sphere::bounding_box, AABB::surrounding_box, BVHNode::construct and the scene-file tree wiring: pinned by the
+//     1 018 BVHNode boxes the upstream generator stored in data/scene_10.json / scene_500.json
+//     (tests/test_reference_bbox_pins.py: reproduced bit for bit in f32 arithmetic).
+//   * Everything else (intersection, BVH traversal, scatter, camera, tonemap, images):
 //     PARITY UNPINNED.  The reference cannot be compiled here (no Rust
 //     toolchain, 13 un-vendored crates), is not seedable (rand::thread_rng
 //     everywhere) and its tests hold no golden vector for this path
@@ -28,6 +31,9 @@
 //       of the SPPM photon-map lookup at :349-351.
 //   D3. BVHNode::new split axis comes from a seeded stream, not thread_rng.
 //   D4. Rust panics become an error flag (ORC_ERR_*), never an abort.
+//   D8. ConstantMedium::hit's `.ln()` is the deterministic algorithm rtamd-ln-1 (det_ln below; < 1 ulp from libm's log),
+//       and the phase function is the reference's commented-out Isotropic (material.rs:213-231) classified as a
+//       pass-through (Specular) interaction.
 //
 // Instrumentation: every AABB / primitive / transform test is counted so the
 // "algorithmic bytes per sample" of SURVEY.md s8d can be computed in the
@@ -394,6 +400,51 @@ struct DiffuseLight : Material {  // material.rs:190-212 ; Q10
     Vec3 emitted(const HitRecord& rec) const override { return emit->get_color(rec); }
 };
 
+// material.rs:213-231 (commented out in the reference): Isotropic phase function of a ConstantMedium.
+// scatter = (albedo colour, Ray(rec.p, random_in_unit_sphere())).  The old Option<(Vec3, Ray)> API has no Interaction;
+// it is classified Specular here (the path simply continues; no photon store, no light sampling at a volume event).
+struct Isotropic : Material {
+    const Texture* albedo;
+    explicit Isotropic(const Texture* a) : albedo(a) {}
+    Vec3 bsdf(Vec3, const HitRecord& rec) const override { return albedo->get_color(rec); }
+    ScatterResult scatter(const Ray& r, const HitRecord& rec, Ctx& cx) const override {
+        Ray s{rec.p, random_in_unit_sphere(cx.rng)};
+        return ScatterResult{Specular, true, true, s, bsdf(r.dir, rec)};
+    }
+};
+
+// rtamd-ln-1 (D8): natural logarithm by argument reduction x = 2^k (1 + f), sqrt(2)/2 < 1 + f < sqrt(2), s = f / (2 + f),
+// log(1 + f) = f - (f^2/2 - s (f^2/2 + R(s^2))) with the degree-14 polynomial R published for fdlibm's e_log.c.
+// Restated here independently of the product's csrc/common/detlog.h; tests/test_medium.py compares the two and numpy.
+static double det_ln(double x) {
+    static const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+    static const double LG[7] = {6.666666666666735130e-01, 3.999999999940941908e-01, 2.857142874366239149e-01, 2.222219843214978396e-01,
+                                 1.818357216161805012e-01, 1.531383769920937332e-01, 1.479819860511658591e-01};
+    if (x == 0.0) return -INF;
+    if (!(x > 0.0)) return std::numeric_limits<double>::quiet_NaN();
+    if (x == INF) return x;
+    int e = 0;
+    if (x < 2.2250738585072014e-308) {  // subnormal
+        x *= 18014398509481984.0;  // 2^54
+        e = -54;
+    }
+    int ex;
+    double m = 2.0 * std::frexp(x, &ex);  // m in [1, 2), x = m * 2^(ex - 1)
+    e += ex - 1;
+    if (m > 1.41421356237309504880) {
+        m = m * 0.5;
+        e += 1;
+    }
+    const double f = m - 1.0, dk = (double)e;
+    const double s = f / (2.0 + f);
+    const double z = s * s, w = z * z;
+    const double t1 = w * (LG[1] + w * (LG[3] + w * LG[5]));
+    const double t2 = z * (LG[0] + w * (LG[2] + w * (LG[4] + w * LG[6])));
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    return dk * LN2_HI - ((hfsq - (s * (hfsq + R) + dk * LN2_LO)) - f);
+}
+
 // ----------------------------------------------------------------------------
 // AABB -- raytracer/src/objects/aabb.rs:5-45
 // ----------------------------------------------------------------------------
@@ -642,6 +693,30 @@ struct Transform : Hitable {
 // ----------------------------------------------------------------------------
 // Camera -- raytracer/src/camera.rs:11-64
 // ----------------------------------------------------------------------------
+// ConstantMedium -- raytracer/src/objects/medium.rs:9-57 (dead code in the reference)
+struct ConstantMedium : Hitable {
+    const Hitable* boundary = nullptr;
+    const Material* phase_function = nullptr;
+    double neg_inv_density = 0.;  // -1 / d   (medium.rs:19)
+    bool hit(const Ray& r, double t_min, double t_max, HitRecord& out, Ctx& cx) const override {  // :25-53
+        HitRecord rec1, rec2;
+        if (!boundary->hit(r, -INF, INF, rec1, cx)) return false;
+        if (!boundary->hit(r, rec1.t + 0.0001, INF, rec2, cx)) return false;
+        rec1.t = std::fmax(rec1.t, t_min);
+        rec2.t = std::fmin(rec2.t, t_max);
+        if (rec1.t >= rec2.t) return false;
+        rec1.t = std::fmax(rec1.t, 0.);
+        const double ray_length = v_len(r.dir);
+        const double distance_inside_boundary = (rec2.t - rec1.t) * ray_length;
+        const double hit_distance = neg_inv_density * det_ln(cx.rng.gen_f64());  // the draw happens only here (:37-38)
+        if (hit_distance > distance_inside_boundary) return false;
+        const double t = rec1.t + hit_distance / ray_length;
+        out = HitRecord::make(t, Vec3(1., 0., 0.), r, phase_function, 0.0, 0.0, id);  // arbitrary normal (1,0,0), uv (0,0)
+        return true;
+    }
+    bool bounding_box(AABB& out) const override { return boundary->bounding_box(out); }  // :54-56
+};
+
 struct Camera {
     Vec3 origin, lower_left_corner, horizontal, vertical, u, v, w;
     double lens_radius = 0;
@@ -1311,6 +1386,14 @@ int orc_mat_diffuse_light(void* s, int t) {
     return (int)sc.materials.size() - 1;
 }
 
+int orc_mat_isotropic(void* s, int t) {
+    Scene& sc = *(Scene*)s;
+    if (!tex(sc, t)) return ORC_ERR_ARG;
+    sc.materials.emplace_back(new Isotropic(tex(sc, t)));
+    return (int)sc.materials.size() - 1;
+}
+double orc_det_ln(double x) { return det_ln(x); }
+
 int orc_sphere(void* s, double cx, double cy, double cz, double r, int m) {
     Scene& sc = *(Scene*)s;
     if (!mat(sc, m)) return ORC_ERR_ARG;
@@ -1350,6 +1433,16 @@ int orc_cube(void* s, const double* mn, const double* mx, int m) {  // cube.rs:1
     ids[5] = push_obj(sc, mk_rect(0, mn[1], mn[2], mx[1], mx[2], mx[0], mm));
     for (int i = 0; i < 6; i++) c->sides.items.push_back(sc.objects[ids[i]].get());
     return push_obj(sc, std::move(c));
+}
+// ConstantMedium::new(d, boundary, phase_function) -- medium.rs:16-22
+int orc_constant_medium(void* s, double density, int boundary, int phase) {
+    Scene& sc = *(Scene*)s;
+    if (!obj(sc, boundary) || !mat(sc, phase)) return ORC_ERR_ARG;
+    auto o = std::make_unique<ConstantMedium>();
+    o->boundary = obj(sc, boundary);
+    o->phase_function = mat(sc, phase);
+    o->neg_inv_density = -1. / density;
+    return push_obj(sc, std::move(o));
 }
 int orc_list(void* s, int n, const int* ids) {
     Scene& sc = *(Scene*)s;
@@ -1537,6 +1630,35 @@ int orc_hit(void* s, int o, const double* orig, const double* dir, double t_min,
     } catch (const UnitZero&) {
         return ORC_ERR_UNIT_ZERO;
     }
+    out12[0] = ok ? 1. : 0.;
+    if (ok) {
+        out12[1] = rec.t;
+        out12[2] = rec.p.x; out12[3] = rec.p.y; out12[4] = rec.p.z;
+        out12[5] = rec.normal.x; out12[6] = rec.normal.y; out12[7] = rec.normal.z;
+        out12[8] = rec.front_face ? 1. : 0.;
+        out12[9] = rec.u; out12[10] = rec.v;
+        out12[11] = (double)rec.prim_id;
+    }
+    return ORC_OK;
+}
+// The same with the RNG stream (seed, pixel, sample) in the context (ConstantMedium::hit draws from it); *draws = numbers consumed
+int orc_hit_rng(void* s, int o, const double* orig, const double* dir, double t_min, double t_max, uint64_t seed, uint64_t pixel, uint64_t sample,
+                double* out12, int* draws) {
+    Scene& sc = *(Scene*)s;
+    const Hitable* h = (o < 0) ? sc.root : obj(sc, o);
+    if (!h) return ORC_ERR_ARG;
+    Ctx cx;
+    cx.rng = Rng(seed, pixel, sample);
+    const uint64_t s0 = cx.rng.s;
+    HitRecord rec;
+    Ray r{Vec3(orig[0], orig[1], orig[2]), Vec3(dir[0], dir[1], dir[2])};
+    bool ok;
+    try {
+        ok = h->hit(r, t_min, t_max, rec, cx);
+    } catch (const UnitZero&) {
+        return ORC_ERR_UNIT_ZERO;
+    }
+    if (draws) *draws = (int)((cx.rng.s - s0) * 0xF1DE83E19937733DULL);  // the stream advances by 0x9E3779B97F4A7C15 per draw; this is its inverse mod 2^64
     out12[0] = ok ? 1. : 0.;
     if (ok) {
         out12[1] = rec.t;

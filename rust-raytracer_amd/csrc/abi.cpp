@@ -3,6 +3,7 @@
 // across the boundary.
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -148,6 +149,18 @@ int rt_material_dielectric(rt_scene* s, double ir, int tex) {
         return add_material(*s, MAT_DIELECTRIC, tex, ir);
     });
 }
+int rt_material_isotropic(rt_scene* s, int tex) {
+    return guard([&] {
+        not_committed_only(s);
+        return add_material(*s, MAT_ISOTROPIC, tex, 0.);
+    });
+}
+int rt_object_constant_medium(rt_scene* s, double density, int boundary, int phase_material) {
+    return guard([&] {
+        not_committed_only(s);
+        return add_medium(*s, density, boundary, phase_material);
+    });
+}
 int rt_material_diffuse_light(rt_scene* s, int tex) {
     return guard([&] {
         not_committed_only(s);
@@ -232,6 +245,25 @@ int rt_object_transform(rt_scene* s, const double rotate_deg[3], const double sc
         return add_transform(*s, rotate_deg, scale, translate, object);
     });
 }
+int rt_object_transform_matrix(rt_scene* s, const double trans[16], const double* inverse_trans, int object) {
+    return guard([&] {
+        not_committed_only(s);
+        REQUIRE(trans, "null matrix");
+        return add_transform_matrix(*s, trans, inverse_trans, object);
+    });
+}
+int rt_mesh_data(rt_scene* s, int n_vert, const double* positions, const double* normals) {
+    return guard([&] {
+        not_committed_only(s);
+        return add_mesh_data(*s, n_vert, positions, normals);
+    });
+}
+int rt_object_triangle(rt_scene* s, int mesh, uint32_t a, uint32_t b, uint32_t c, int material) {
+    return guard([&] {
+        not_committed_only(s);
+        return add_triangle(*s, mesh, a, b, c, material);
+    });
+}
 int rt_object_list(rt_scene* s, int n, const int* objects) {
     return guard([&] {
         not_committed_only(s);
@@ -280,7 +312,7 @@ int rt_object_describe(const rt_scene* s, int object, rt_object_desc* out) {
         const ObjectRec& o = s->objects[object];
         static_assert((int)OBJ_SPHERE == RT_OBJ_SPHERE && (int)OBJ_RECT == RT_OBJ_RECT && (int)OBJ_CUBE == RT_OBJ_CUBE &&
                       (int)OBJ_TRIANGLE == RT_OBJ_TRIANGLE && (int)OBJ_MESH == RT_OBJ_MESH && (int)OBJ_TRANSFORM == RT_OBJ_TRANSFORM &&
-                      (int)OBJ_LIST == RT_OBJ_LIST && (int)OBJ_BVH == RT_OBJ_BVH, "rt_object_type mirrors ObjType");
+                      (int)OBJ_LIST == RT_OBJ_LIST && (int)OBJ_BVH == RT_OBJ_BVH && (int)OBJ_MEDIUM == RT_OBJ_MEDIUM, "rt_object_type mirrors ObjType");
         std::memset(out, 0, sizeof(*out));
         out->type = o.type;
         out->material = (o.type == OBJ_SPHERE || o.type == OBJ_RECT || o.type == OBJ_TRIANGLE) ? o.material : -1;
@@ -292,6 +324,9 @@ int rt_object_describe(const rt_scene* s, int object, rt_object_desc* out) {
             out->v[0] = o.a0; out->v[1] = o.b0; out->v[2] = o.a1; out->v[3] = o.b1; out->v[4] = o.k;
         } else if (o.type == OBJ_TRIANGLE) {
             out->v[0] = (double)o.ia; out->v[1] = (double)o.ib; out->v[2] = (double)o.ic;
+        } else if (o.type == OBJ_MEDIUM) {
+            out->material = o.material;
+            out->v[0] = o.density;
         }
         return (int)RT_OK;
     });
@@ -512,15 +547,50 @@ int rt_assemble_frame_device(const rt_params* p, const double* d_gathered, int64
     });
 }
 
+static CameraDev camera_from_frame(const rt_camera_frame& f) {
+    CameraDev d;
+    for (int i = 0; i < 3; i++) {
+        d.origin[i] = f.origin[i]; d.llc[i] = f.lower_left_corner[i]; d.horizontal[i] = f.horizontal[i];
+        d.vertical[i] = f.vertical[i]; d.u[i] = f.u[i]; d.v[i] = f.v[i]; d.w[i] = f.w[i];
+    }
+    d.lens_radius = f.lens_radius;
+    return d;
+}
+int rt_camera_frame_from(const rt_camera* cam, rt_camera_frame* out) {
+    return guard([&] {
+        REQUIRE(cam && out, "null argument");
+        const CameraDev d = make_camera(*cam);
+        for (int i = 0; i < 3; i++) {
+            out->origin[i] = d.origin[i]; out->lower_left_corner[i] = d.llc[i]; out->horizontal[i] = d.horizontal[i];
+            out->vertical[i] = d.vertical[i]; out->u[i] = d.u[i]; out->v[i] = d.v[i]; out->w[i] = d.w[i];
+        }
+        out->lens_radius = d.lens_radius;
+        return (int)RT_OK;
+    });
+}
+static int render_host(const rt_scene* s, const CameraDev& cd, const rt_params* p, double* out_rgb, rt_stats* stats);
+int rt_render_camera_frame(const rt_scene* s, const rt_camera_frame* frame, const rt_params* p, double* out_rgb, rt_stats* stats) {
+    return guard([&] {
+        REQUIRE(s && frame && p && out_rgb, "null argument");
+        for (const double* v : {frame->origin, frame->lower_left_corner, frame->horizontal, frame->vertical, frame->u, frame->v, frame->w})
+            for (int i = 0; i < 3; i++) REQUIRE(std::isfinite(v[i]), "camera frame must be finite");
+        REQUIRE(std::isfinite(frame->lens_radius), "camera frame must be finite");
+        return render_host(s, camera_from_frame(*frame), p, out_rgb, stats);
+    });
+}
 int rt_render(const rt_scene* s, const rt_camera* cam, const rt_params* p, double* out_rgb, rt_stats* stats) {
     return guard([&] {
         REQUIRE(s && cam && p && out_rgb, "null argument");
+        return render_host(s, make_camera(*cam), p, out_rgb, stats);
+    });
+}
+static int render_host(const rt_scene* s, const CameraDev& cd, const rt_params* p, double* out_rgb, rt_stats* stats) {
+    {
         if (!s->committed) throw RtError(RT_ERR_NOT_COMMITTED, "rt_scene_commit has not been called");
         if (device_count() < 1) throw RtError(RT_ERR_NO_DEVICE, "no HIP device: librtamd has no CPU fallback");
         auto t0 = std::chrono::steady_clock::now();
         if (p->device >= 0) dev_set_device(p->device);
         RenderPlan pl = make_plan(p);
-        CameraDev cd = make_camera(*cam);
         if (stats) std::memset(stats, 0, sizeof(*stats));
         struct Buf {
             void* p = nullptr;
@@ -564,7 +634,7 @@ int rt_render(const rt_scene* s, const rt_camera* cam, const rt_params* p, doubl
             stats->samples = px * (uint64_t)pl.spp;
         }
         return (int)RT_OK;
-    });
+    }
 }
 
 void rt_default_sppm_config(rt_sppm_config* c) {
@@ -651,7 +721,7 @@ int rt_debug_rng_host(uint64_t seed, uint64_t pixel, uint64_t sample, int n, uin
 }
 int rt_debug_math_device(int op, size_t n, const double* a_host, const double* b_host, double* out_host) {
     return guard([&] {
-        REQUIRE(n > 0 && a_host && out_host && (op == 0 || (op == 1 && b_host)), "bad argument");
+        REQUIRE(n > 0 && a_host && out_host && (op == 0 || op == 2 || (op == 1 && b_host)), "bad argument");
         if (device_count() < 1) throw RtError(RT_ERR_NO_DEVICE, "no HIP device");
         debug_math_device(op, n, a_host, b_host, out_host);
         return (int)RT_OK;

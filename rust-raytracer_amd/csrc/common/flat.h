@@ -24,14 +24,25 @@ enum NodeKind : uint32_t {
     NK_RECT_XY = 4,      // constant axis 2 (XYRectangle)
     NK_TRI = 5,          // Triangle::hit; payload = triangle index
     NK_XFORM_BEGIN = 6,  // Transform::hit entry: ray -> object space (transform.rs:153-156); payload = xform index
-    NK_XFORM_END = 7     // leave the Transform: restore the world ray
+    NK_XFORM_END = 7,    // leave the Transform: restore the world ray
+    // 8 = NK_INSTANCE (accel items only, below)
+    // ConstantMedium::hit (medium.rs:25-53) = two closest-hit queries on the boundary, then one random draw.  The boundary's
+    // subtree is emitted TWICE between three brackets; payload = medium index:
+    NK_MEDIUM_BEGIN = 9,  // save the outer best hit; query A: boundary.hit(r, -inf, +inf)
+    NK_MEDIUM_MID = 10,   // A missed -> jump to END (skip link); else query B: boundary.hit(r, t_A + 0.0001, +inf)
+    NK_MEDIUM_END = 11    // restore the outer state; clip [t_A, t_B] to [t_min, best], draw, accept t = t_A + dist / |dir| or nothing
 };
 static const uint32_t NK_BITS = 4;
 static const uint32_t NK_MASK = 15;
 
 // per node: meta[2*n] = kind | payload << 4 ; meta[2*n+1] = skip
-struct MatDev {   // material.rs:88-212
-    int32_t type;  // 0 Lambertian, 1 Metal, 2 Dielectric, 3 DiffuseLight
+struct MediumDev {  // objects/medium.rs:9-13
+    double neg_inv_density;  // -1 / d
+    int32_t mat;             // phase function (an Isotropic material)
+    int32_t pad;
+};
+struct MatDev {   // material.rs:88-212 (+ :213-231, the commented-out Isotropic)
+    int32_t type;  // 0 Lambertian, 1 Metal, 2 Dielectric, 3 DiffuseLight, 4 Isotropic
     int32_t tex;   // albedo / emit texture
     double param;  // Metal.fuzz | Dielectric.ir
     // Dielectric only, computed on the host with the reference's operations (the same IEEE results, once instead of per hit):
@@ -86,6 +97,7 @@ struct FlatView {  // by-value kernel argument
     const char* base;
     uint32_t off_meta, off_boxes, off_spheres, off_sphere_mat, off_rects, off_rect_mat, off_tris, off_xforms;
     uint32_t off_mats, off_texs, off_vpos, off_vnrm, off_texels;
+    uint32_t off_media;    // cold part: MediumDev per ConstantMedium
     uint32_t n_nodes;
     uint32_t stage_bytes;  // kernel 1 stages bytes [0, stage_bytes) into LDS: [meta|boxes|spheres|rects|tris|xforms|vpos]
     uint32_t kinds_mask;   // bit k set if some node has kind k

@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "../common/flat.h"
+#include "../common/detlog.h"
 #include "../common/rng.h"
 #include "device.h"
 
@@ -135,6 +136,7 @@ struct Acc {  // typed views into the blob (LDS or global; the address space is 
     uint32_t root2;
     const uint2* lights;     // {NK_SPHERE | NK_RECT_XZ, payload}
     uint32_t n_lights;
+    const MediumDev* media;  // always global
 };
 template <class P>
 DEV Acc make_acc(P hot, const char* gbase, const FlatView& v) {  // hot: LDS copy or the global blob; cold part always global
@@ -163,6 +165,7 @@ DEV Acc make_acc(P hot, const char* gbase, const FlatView& v) {  // hot: LDS cop
     a.root2 = v.root2;
     a.lights = (const uint2*)(gbase + v.off_lights);
     a.n_lights = v.n_lights;
+    a.media = (const MediumDev*)(gbase + v.off_media);
     return a;
 }
 
@@ -273,8 +276,11 @@ struct Hit {
 // World::hit -> BVHNode::hit / Vec::hit / Transform::hit, flattened (common/flat.h).
 // Visits nodes in the reference's own order; a leaf is accepted when t_min <= t <= best
 // (inclusive, so a later leaf wins an exact tie -- sphere.rs:36, rectangle.rs:20, mesh.rs:96).
-template <bool GENERAL>
-DEV Hit traverse(const Acc& A, D3 wo, D3 wd, double t_min, double t_max) {
+// MEDIA: the program contains ConstantMedium brackets (NK_MEDIUM_*, common/flat.h): between BEGIN and END the walk answers the
+// two boundary queries of ConstantMedium::hit (medium.rs:26-27) in a scratch hit with its own range [lo, +inf), then END
+// restores the outer best hit and makes the medium's one random draw from the path's stream.
+template <bool GENERAL, bool MEDIA = false>
+DEV Hit traverse(const Acc& A, D3 wo, D3 wd, double t_min, double t_max, Rng* rng = nullptr) {
     D3 o = wo, d = wd;
     D3 inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
     double a = sqlen(d);
@@ -286,11 +292,52 @@ DEV Hit traverse(const Acc& A, D3 wo, D3 wd, double t_min, double t_max) {
     int cur_xf = -1;
     uint32_t n = 0;
     const uint32_t N = A.n_nodes;
+    const double t_min_outer = t_min;
+    Hit h_outer = h;      // MEDIA: the outer best hit while a boundary query runs
+    double t_a = 0.;      // MEDIA: t of boundary query A
     while (n < N) {
         uint2 m = A.meta[n];
         uint32_t kind = m.x & NK_MASK, pl = m.x >> NK_BITS;
         if (kind == NK_BOX) {
             n = aabb_hit(A.boxes + 3 * pl, o, inv, t_min, h.t) ? n + 1 : m.y;
+        } else if (MEDIA && kind == NK_MEDIUM_BEGIN) {  // rec1 = boundary.hit(r, -inf, +inf), medium.rs:26
+            h_outer = h;
+            h.t = INFINITY;
+            h.node = -1;
+            t_min = -INFINITY;
+            n++;
+        } else if (MEDIA && kind == NK_MEDIUM_MID) {  // rec2 = boundary.hit(r, rec1.t + 0.0001, +inf), medium.rs:27
+            if (h.node < 0) {
+                n = m.y;  // no rec1: straight to END, which then restores and returns None
+            } else {
+                t_a = h.t;
+                t_min = h.t + 0.0001;
+                h.t = INFINITY;
+                h.node = -1;
+                n++;
+            }
+        } else if (MEDIA && kind == NK_MEDIUM_END) {  // medium.rs:28-50
+            const bool both = h.node >= 0;  // reached with rec1 AND rec2 (a missing rec1 jumped here with node < 0 as well)
+            const double t_b = h.t;
+            h = h_outer;
+            t_min = t_min_outer;
+            if (both) {
+                double r1 = fmax(t_a, t_min);
+                const double r2 = fmin(t_b, h.t);
+                if (!(r1 >= r2)) {
+                    r1 = fmax(r1, 0.);
+                    const double ray_length = sqrt(a);
+                    const double distance_inside_boundary = (r2 - r1) * ray_length;
+                    const double hit_distance = A.media[pl].neg_inv_density * det_ln(rng->gen_f64());  // the only draw, medium.rs:37-38
+                    if (!(hit_distance > distance_inside_boundary)) {
+                        h.t = r1 + hit_distance / ray_length;
+                        h.node = (int)n;
+                        h.xf = cur_xf;
+                        h.kp = m.x;
+                    }
+                }
+            }
+            n++;
         } else if (kind == NK_SPHERE) {
             double t;
             if (sphere_hit(A.spheres + 2 * pl, o, d, a, t_min, h.t, t)) {
@@ -579,6 +626,9 @@ DEV Rec materialize(const Acc& A, const Hit& h, D3 wo, D3 wd, int* err) {
         outward = divs(sub(p, mk(c0.x, c0.y, c1.x)), c1.y);
         want_uv = A.texs[A.mats[rec.mat].tex].type == 2;
         if (want_uv) sphere_uv(outward, rec.u, rec.v);  // get_uv, sphere.rs:16-20 (only an ImageTexture reads it)
+    } else if (GENERAL && kind == NK_MEDIUM_END) {  // ConstantMedium: arbitrary normal (1,0,0), uv (0,0), phase function (medium.rs:43-49)
+        rec.mat = A.media[pl].mat;
+        outward = mk(1., 0., 0.);
     } else if (GENERAL && kind != NK_TRI) {  // rectangles
         int axis = (int)kind - (int)NK_RECT_YZ;
         double2 r0 = A.rects[3 * pl], r1 = A.rects[3 * pl + 1];
@@ -641,6 +691,10 @@ DEV bool shade(const Acc& A, const Rec& rec, D3 rdir, Rng& rng, D3& emitted, D3&
         D3 dir = add(rec.normal, u);
         if (near_zero(dir)) dir = rec.normal;
         out_dir = dir;
+        return true;
+    }
+    if (type == 4) {  // Isotropic (material.rs:213-231, commented out in the reference): Ray(p, random_in_unit_sphere()), albedo
+        out_dir = rs;
         return true;
     }
     if (type == 1) {  // Metal, material.rs:126-139
@@ -807,7 +861,7 @@ __device__ __attribute__((noinline)) int fold_units(const uint32_t* rmeta, const
     return folded;
 }
 
-template <bool LDS, bool GENERAL, int ACCEL, int INTEG>
+template <bool LDS, bool GENERAL, int ACCEL, int INTEG, bool MEDIA = false>
 __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, RenderK rk, double* __restrict__ ring, double* accum,
                                                       unsigned int* tickets, unsigned int* __restrict__ counter, int* __restrict__ err) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -938,7 +992,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
             // ---- one path segment: sample_ray's loop body, photon_mapper.rs:335-362 ----
             if (alive) {
                 Hit h = (ACCEL == 2) ? traverse2<GENERAL>(A, stk, stk_stride, o, d, rk.t_min, INFINITY)
-                                     : traverse<GENERAL>(A, o, d, rk.t_min, INFINITY);
+                                     : traverse<GENERAL, MEDIA>(A, o, d, rk.t_min, INFINITY, &rng);
                 bool done = true;
                 if (h.node >= 0 && depth > 0) {  // Q12: depth test after the hit, before emission
                     depth -= 1;
@@ -1023,7 +1077,7 @@ __global__ void rng_kernel(uint64_t seed, uint64_t pixel, uint64_t sample, int n
 __global__ void math_kernel(int op, size_t n, const double* a, const double* b, double* out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    out[i] = (op == 0) ? sqrt(a[i]) : a[i] / b[i];
+    out[i] = (op == 0) ? sqrt(a[i]) : (op == 2) ? det_ln(a[i]) : a[i] / b[i];
 }
 __global__ void hit_kernel(FlatView sv, int accel, size_t n, const double* rays, double t_min, double t_max, double* out, int* err) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1250,6 +1304,7 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
     const size_t stack2_bytes = (size_t)view.stack2 * PT_BLOCK * sizeof(uint32_t);
     const size_t hot1 = (size_t)view.stage_bytes, hot2 = (size_t)(view.stage2_end - view.stage2_begin);
     const bool accel2_usable = view.accel_ok && camera_ok && stack2_bytes <= lds_max;  // per-lane stacks live in LDS
+    const bool media = (view.kinds_mask & (1u << NK_MEDIUM_BEGIN)) != 0;               // flatten.cpp: such scenes have no accel
     int kernel = plan.kernel;
     if (kernel == 0) kernel = accel2_usable ? 2 : 1;
     if (kernel == 2 && !accel2_usable)
@@ -1262,7 +1317,11 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
     const int integ = plan.integrator;
     if (integ == 1 && view.n_lights == 0) throw RtError(RT_ERR_ARG, "integrator 1 (light importance sampling) needs rt_scene_set_lights");
     if (integ == 2 && !plan.sppm_est) throw RtError(RT_ERR_ARG, "integrator 2 (SPPM) is reached through rt_render_sppm");
+    if (media && integ != 0)
+        throw RtError(RT_ERR_UNSUPPORTED, "scenes with a ConstantMedium render with integrator 0 only (the medium's random draw is part of the "
+                                          "reference-order walk; light sampling and SPPM have no volume events)");
     pt_fn fn = (kernel == 2) ? pick_pt_kernel<2>(lds, general, integ) : pick_pt_kernel<1>(lds, general, integ);
+    if (media) fn = lds ? pt_kernel<true, true, 1, 0, true> : pt_kernel<false, true, 1, 0, true>;
     // scene too large for LDS: spend what is left after the stacks on the shallowest BVH levels (the Node2 array is depth-sorted)
     int n_top = 0;
     if (kernel == 2 && !lds && lds_max > stack_bytes) {
@@ -1453,6 +1512,8 @@ void render_sppm(const rt_scene& s, const CameraDev& cam, RenderPlan plan, const
                  void* stream_, rt_stats* st, uint64_t* totals2) {
     if (!s.committed) throw RtError(RT_ERR_NOT_COMMITTED, "scene not committed");
     if (s.lights.empty()) throw RtError(RT_ERR_ARG, "SPPM needs lights (rt_scene_set_lights)");
+    if (s.flat.view.kinds_mask & (1u << NK_MEDIUM_BEGIN))
+        throw RtError(RT_ERR_UNSUPPORTED, "the SPPM pre-pass does not support ConstantMedium (volume events have no photon-map estimate)");
     if (cfg.iterations < 1 || cfg.photons_per_iter < 1 || cfg.k_global < 1 || cfg.k_caustic < 1 || cfg.max_bounces < 1 || !(cfg.alpha > 0.))
         throw RtError(RT_ERR_ARG, "bad rt_sppm_config");
     hipStream_t stream = (hipStream_t)stream_;
@@ -1673,6 +1734,8 @@ void debug_hit_device(const rt_scene& s, int kernel, size_t n, const double* ray
     HIP_CHECK(hipMemcpy(dr.p, rays, n * 48, hipMemcpyHostToDevice));
     if (kernel == 2 && !view.accel_ok) throw RtError(RT_ERR_UNSUPPORTED, "no accel for this scene");
     if (kernel == 2 && !(t_min >= 0.)) throw RtError(RT_ERR_UNSUPPORTED, "kernel 2 needs t_min >= 0 (box32)");
+    if (view.kinds_mask & (1u << NK_MEDIUM_BEGIN))
+        throw RtError(RT_ERR_UNSUPPORTED, "closest-hit queries on a scene with a ConstantMedium need the path's random stream");
     const size_t smem = (kernel == 2) ? view.stack2 * 64 * sizeof(uint32_t) : 0;
     hipLaunchKernelGGL(hit_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), smem, 0, view,
                        kernel, n, (const double*)dr.p, t_min, t_max, (double*)dout.p, (int*)err.p);

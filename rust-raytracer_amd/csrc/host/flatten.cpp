@@ -27,6 +27,9 @@ struct Builder {
     std::vector<int32_t> sphere_mat, rect_mat;
     std::vector<uint32_t> tris;
     std::vector<double> tripre;  // per triangle: pa, e0 = pb - pa, e1 = pc - pa, pad (10 doubles = 80 B)
+    std::vector<MediumDev> media;
+    std::map<int, uint32_t> medium_of;
+    int medium_depth = 0;
     std::map<int, uint32_t> sphere_of, rect_of, tri_of, xform_of;
     std::vector<uint32_t> mesh_base;
     uint32_t kinds = 0;
@@ -167,6 +170,26 @@ struct Builder {
                 ctx_stack.pop_back();
                 node(NK_XFORM_END, it->second);
                 meta[2 * n + 1] = (uint32_t)(meta.size() / 2);
+                break;
+            }
+            case OBJ_MEDIUM: {
+                // ConstantMedium::hit consumes a random number INSIDE hit (medium.rs:37-38), so what the path draws depends on
+                // the order in which the reference visits objects: only the reference-order program (kernel 1) is valid.
+                accel_ok = false;
+                if (medium_depth > 0) throw RtError(RT_ERR_UNSUPPORTED, "a ConstantMedium inside the boundary of a ConstantMedium is not supported");
+                auto it = medium_of.find(id);
+                if (it == medium_of.end()) {
+                    it = medium_of.emplace(id, (uint32_t)media.size()).first;
+                    media.push_back(MediumDev{-1. / o.density, o.material, 0});
+                }
+                medium_depth++;
+                node(NK_MEDIUM_BEGIN, it->second);
+                emit(o.children[0]);
+                uint32_t mid = node(NK_MEDIUM_MID, it->second);
+                emit(o.children[0]);
+                uint32_t end = node(NK_MEDIUM_END, it->second);
+                meta[2 * mid + 1] = end;
+                medium_depth--;
                 break;
             }
             default:
@@ -387,6 +410,7 @@ void flatten(rt_scene& s) {
     v.off_rect_mat = append(f.blob, b.rect_mat);
     v.off_mats = append(f.blob, mats);
     v.off_texs = append(f.blob, texs);
+    v.off_media = append(f.blob, b.media);
     v.off_lights = append(f.blob, lights);
     v.n_lights = (uint32_t)(lights.size() / 2);
     v.off_vpos = append(f.blob, b.vpos);  // kept for introspection; the kernels read tripre instead

@@ -171,6 +171,25 @@ int add_list(rt_scene& s, int n, const int* objs) {
     return push(s, std::move(l));
 }
 
+// ConstantMedium::new(d, boundary, phase_function), medium.rs:16-22 ; bounding_box = the boundary's (medium.rs:54-56)
+int add_medium(rt_scene& s, double density, int boundary, int phase_material) {
+    check_obj(s, boundary);
+    check_mat(s, phase_material);
+    require_finite(&density, 1, "medium density");
+    if (!(density > 0.)) throw RtError(RT_ERR_ARG, "medium density must be positive");
+    const int bt = s.objects[boundary].type;
+    if (bt == OBJ_MEDIUM) throw RtError(RT_ERR_UNSUPPORTED, "a ConstantMedium as the boundary of a ConstantMedium is not supported");
+    ObjectRec m;
+    m.type = OBJ_MEDIUM;
+    m.material = phase_material;
+    m.density = density;
+    m.children = {boundary};
+    Box b;
+    m.has_box = bounding_box(s, boundary, b);
+    if (m.has_box) m.box = b;
+    return push(s, std::move(m));
+}
+
 // BVHNode::construct, bvh.rs:47-58
 int add_bvh_node(rt_scene& s, int left, int right) {
     Box bl, br;
@@ -240,6 +259,39 @@ void synthesize_normals(int n_vert, const double* pos, int n_tri, const uint32_t
             n[0] /= l; n[1] /= l; n[2] /= l;
         }
     }
+}
+
+// The vertex arrays a mesh's triangles share (Arc<Vec<Vec3>> positions / normals, mesh.rs:12-13): returns a mesh id
+int add_mesh_data(rt_scene& s, int n_vert, const double* pos, const double* nrm) {
+    if (n_vert <= 0 || !pos) throw RtError(RT_ERR_ARG, "empty vertex array");
+    if (!nrm) throw RtError(RT_ERR_NO_NORMALS, "mesh has no vertex normals (the reference indexes normals[a] unconditionally, mesh.rs:62)");
+    require_finite(pos, (size_t)n_vert * 3, "mesh positions");
+    require_finite(nrm, (size_t)n_vert * 3, "mesh normals");
+    auto md = std::make_unique<MeshData>();
+    md->pos.assign(pos, pos + (size_t)n_vert * 3);
+    md->nrm.assign(nrm, nrm + (size_t)n_vert * 3);
+    s.meshes.push_back(std::move(md));
+    return (int)s.meshes.size() - 1;
+}
+// Triangle::new (mesh.rs:19-53) on a mesh id: the host keeps its own BVHNode tree over the triangles (rt_object_bvh_node)
+int add_triangle(rt_scene& s, int mesh, uint32_t a, uint32_t b, uint32_t c, int mat) {
+    check_mat(s, mat);
+    if (mesh < 0 || mesh >= (int)s.meshes.size()) throw RtError(RT_ERR_ARG, "unknown mesh id");
+    const size_t nv = s.meshes[mesh]->pos.size() / 3;
+    if (a >= nv || b >= nv || c >= nv) throw RtError(RT_ERR_ARG, "triangle index out of range");
+    ObjectRec o;
+    o.type = OBJ_TRIANGLE;
+    o.material = mat;
+    o.mesh = mesh;
+    o.ia = a; o.ib = b; o.ic = c;
+    const double* P = s.meshes[mesh]->pos.data();
+    const double *pa = P + 3 * a, *pb = P + 3 * b, *pc = P + 3 * c;
+    o.has_box = true;
+    for (int i = 0; i < 3; i++) {  // mesh.rs:33-42 : +-0.1 in object space (Q9)
+        o.box.mx[i] = std::fmax(std::fmax(pa[i], pb[i]), pc[i]) + 0.1;
+        o.box.mn[i] = std::fmin(std::fmin(pa[i], pb[i]), pc[i]) - 0.1;
+    }
+    return push(s, std::move(o));
 }
 
 // Mesh::load_obj's construction half (mesh.rs:160-198) + Triangle::new (mesh.rs:19-53)
@@ -331,6 +383,7 @@ static void xf_point(const double* t, const double* p, double* o) {  // vec3.rs:
     for (int i = 0; i < 3; i++) o[i] = t[i * 4 + 0] * p[0] + t[i * 4 + 1] * p[1] + t[i * 4 + 2] * p[2] + t[i * 4 + 3] * 1.;
 }
 
+static int finish_transform(rt_scene& s, ObjectRec&& t, int obj, const double* inverse_trans);
 // Transform::new, transform.rs:17-148 : M = T*S*Rx*Ry*Rz ; box = 8 transformed corners
 int add_transform(rt_scene& s, const double rot_deg[3], const double scale[3], const double translate[3], int obj) {
     check_obj(s, obj);
@@ -351,6 +404,21 @@ int add_transform(rt_scene& s, const double rot_deg[3], const double scale[3], c
     mat_mul(a, RX, b);
     mat_mul(b, RY, a);
     mat_mul(a, RZ, t.M);
+    return finish_transform(s, std::move(t), obj, nullptr);
+}
+// Transform as the reference STORES it (transform.rs:9-14: obj, trans, inverse_trans): the composed matrix itself
+int add_transform_matrix(rt_scene& s, const double trans[16], const double* inverse_trans, int obj) {
+    check_obj(s, obj);
+    require_finite(trans, 16, "transform matrix");
+    if (inverse_trans) require_finite(inverse_trans, 16, "inverse transform matrix");
+    ObjectRec t;
+    t.type = OBJ_TRANSFORM;
+    t.children = {obj};
+    for (int i = 0; i < 16; i++) t.M[i] = trans[i];
+    return finish_transform(s, std::move(t), obj, inverse_trans);
+}
+// box = the 8 transformed corners (transform.rs:110-136); inverse = try_inverse (transform.rs:138-146) unless the host hands its own
+static int finish_transform(rt_scene& s, ObjectRec&& t, int obj, const double* inverse_trans) {
     Box bb;
     if (bounding_box(s, obj, bb)) {
         const double INF = std::numeric_limits<double>::infinity();
@@ -374,7 +442,11 @@ int add_transform(rt_scene& s, const double rot_deg[3], const double scale[3], c
             t.box.mx[c] = mx[c];
         }
     }
-    if (!mat_inverse(t.M, t.Minv)) throw RtError(RT_ERR_SINGULAR, "Invalid transform matrix");
+    if (inverse_trans) {
+        for (int i = 0; i < 16; i++) t.Minv[i] = inverse_trans[i];
+    } else if (!mat_inverse(t.M, t.Minv)) {
+        throw RtError(RT_ERR_SINGULAR, "Invalid transform matrix");
+    }
     return push(s, std::move(t));
 }
 

@@ -32,14 +32,14 @@ struct TextureRec {
     int w = 0, h = 0;
     std::vector<uint8_t> rgb;
 };
-enum MatType { MAT_LAMBERTIAN = 0, MAT_METAL = 1, MAT_DIELECTRIC = 2, MAT_DIFFUSE_LIGHT = 3 };
+enum MatType { MAT_LAMBERTIAN = 0, MAT_METAL = 1, MAT_DIELECTRIC = 2, MAT_DIFFUSE_LIGHT = 3, MAT_ISOTROPIC = 4 };
 struct MaterialRec {
     int type = MAT_LAMBERTIAN;
     int tex = -1;
     double param = 0;
 };
 
-enum ObjType { OBJ_SPHERE, OBJ_RECT, OBJ_CUBE, OBJ_TRIANGLE, OBJ_MESH, OBJ_TRANSFORM, OBJ_LIST, OBJ_BVH };
+enum ObjType { OBJ_SPHERE, OBJ_RECT, OBJ_CUBE, OBJ_TRIANGLE, OBJ_MESH, OBJ_TRANSFORM, OBJ_LIST, OBJ_BVH, OBJ_MEDIUM };
 struct MeshData {
     std::vector<double> pos, nrm;  // 3 per vertex
 };
@@ -49,7 +49,8 @@ struct ObjectRec {
     double c[3] = {0, 0, 0}, r = 0;             // sphere
     int axis = 0;                               // rect: constant axis (0 YZ, 1 XZ, 2 XY)
     double a0 = 0, b0 = 0, a1 = 0, b1 = 0, k = 0;
-    std::vector<int> children;                  // cube: 6 rects; list: items; bvh: {left,right}; mesh: {bvh}; transform: {obj}
+    std::vector<int> children;                  // cube: 6 rects; list: items; bvh: {left,right}; mesh: {bvh}; transform: {obj}; medium: {boundary}
+    double density = 0;                         // medium: d of ConstantMedium::new (neg_inv_density = -1 / d); material = phase function
     int mesh = -1;                              // triangle / mesh: index into Scene::meshes
     uint32_t ia = 0, ib = 0, ic = 0;            // triangle vertex indices
     double M[16], Minv[16];                     // transform (row-major)
@@ -108,7 +109,11 @@ int add_cube(rt_scene& s, const double mn[3], const double mx[3], int mat);
 int add_mesh(rt_scene& s, int n_vert, const double* pos, const double* nrm, int n_tri, const uint32_t* idx, int mat,
              bool synth_normals, uint64_t bvh_seed);
 int add_transform(rt_scene& s, const double rot_deg[3], const double scale[3], const double translate[3], int obj);
+int add_transform_matrix(rt_scene& s, const double trans[16], const double* inverse_trans, int obj);
+int add_mesh_data(rt_scene& s, int n_vert, const double* pos, const double* nrm);
+int add_triangle(rt_scene& s, int mesh, uint32_t a, uint32_t b, uint32_t c, int mat);
 int add_list(rt_scene& s, int n, const int* objs);
+int add_medium(rt_scene& s, double density, int boundary, int phase_material);
 int add_bvh_node(rt_scene& s, int left, int right);
 int add_bvh_build(rt_scene& s, std::vector<int> objs, uint64_t bvh_seed);
 void check_obj(const rt_scene& s, int o);

@@ -116,6 +116,11 @@ struct DiffuseLight : Material {
     explicit DiffuseLight(TexturePtr t) : emit_tex(std::move(t)) {}
     int emit(Emitter& e) const override;
 };
+struct Isotropic : Material {  // material.rs:213-231 (commented out in the reference): phase function of a ConstantMedium
+    TexturePtr albedo;
+    explicit Isotropic(TexturePtr a) : albedo(std::move(a)) {}
+    int emit(Emitter& e) const override;
+};
 
 // objects/hit.rs:51-54
 struct Hitable {
@@ -199,6 +204,13 @@ struct Transform : Hitable {  // transform.rs:17-22
     Transform(Vec3 r, Vec3 s, Vec3 t, HitablePtr o) : rotate_in_degree(r), scale(s), translate(t), obj(std::move(o)) {}
     int emit(Emitter& e) const override;
 };
+struct ConstantMedium : Hitable {  // medium.rs:9-22
+    double density;
+    HitablePtr boundary;
+    MaterialPtr phase_function;
+    ConstantMedium(double d, HitablePtr b, MaterialPtr p) : density(d), boundary(std::move(b)), phase_function(std::move(p)) {}
+    int emit(Emitter& e) const override;
+};
 struct XZRectLight : Hitable {  // light.rs:127-146 (as a Hitable; `scale` only feeds SPPM photon power)
     std::pair<double, double> xz0, xz1;
     double y;
@@ -238,6 +250,10 @@ inline int Lambertian::emit(Emitter& e) const { return check(rt_material_lambert
 inline int Metal::emit(Emitter& e) const { return check(rt_material_metal(e.s, e.once(albedo.get()), fuzz)); }
 inline int Dielectric::emit(Emitter& e) const { return check(rt_material_dielectric(e.s, ir, e.once(albedo.get()))); }
 inline int DiffuseLight::emit(Emitter& e) const { return check(rt_material_diffuse_light(e.s, e.once(emit_tex.get()))); }
+inline int Isotropic::emit(Emitter& e) const { return check(rt_material_isotropic(e.s, e.once(albedo.get()))); }
+inline int ConstantMedium::emit(Emitter& e) const {
+    return check(rt_object_constant_medium(e.s, density, e.once(boundary.get()), e.once(phase_function.get())));
+}
 inline int Sphere::emit(Emitter& e) const { return check(rt_object_sphere(e.s, center.data(), radius, e.once(material.get()))); }
 inline int XYRectangle::emit(Emitter& e) const {
     return check(rt_object_rect_xy(e.s, xy0.first, xy0.second, xy1.first, xy1.second, z, e.once(material.get())));

@@ -35,6 +35,11 @@ class rt_camera(C.Structure):
                 ("aspect", C.c_double), ("aperture", C.c_double), ("focus_dist", C.c_double)]
 
 
+class rt_camera_frame(C.Structure):
+    _fields_ = [("origin", C.c_double * 3), ("lower_left_corner", C.c_double * 3), ("horizontal", C.c_double * 3),
+                ("vertical", C.c_double * 3), ("u", C.c_double * 3), ("v", C.c_double * 3), ("w", C.c_double * 3), ("lens_radius", C.c_double)]
+
+
 class rt_params(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("spp", C.c_int32), ("max_depth", C.c_int32), ("t_min", C.c_double),
                 ("seed", C.c_uint64), ("rank", C.c_int32), ("world", C.c_int32), ("spp_chunk", C.c_int32), ("kernel", C.c_int32),
@@ -67,7 +72,7 @@ class rt_object_desc(C.Structure):
     _fields_ = [("type", C.c_int32), ("material", C.c_int32), ("n_children", C.c_int32), ("axis", C.c_int32), ("v", C.c_double * 8)]
 
 
-OBJECT_TYPES = ("Sphere", "Rect", "Cube", "Triangle", "Mesh", "Transform", "HitableList", "BVHNode")
+OBJECT_TYPES = ("Sphere", "Rect", "Cube", "Triangle", "Mesh", "Transform", "HitableList", "BVHNode", "ConstantMedium")
 
 
 class rt_scene_info(C.Structure):
@@ -101,6 +106,8 @@ _SIGS = [
     ("rt_material_metal", C.c_int, [C.c_void_p, C.c_int, C.c_double]),
     ("rt_material_dielectric", C.c_int, [C.c_void_p, C.c_double, C.c_int]),
     ("rt_material_diffuse_light", C.c_int, [C.c_void_p, C.c_int]),
+    ("rt_material_isotropic", C.c_int, [C.c_void_p, C.c_int]),
+    ("rt_object_constant_medium", C.c_int, [C.c_void_p, C.c_double, C.c_int, C.c_int]),
     ("rt_object_sphere", C.c_int, [C.c_void_p, _d3, C.c_double, C.c_int]),
     ("rt_object_rect_xy", C.c_int, [C.c_void_p] + [C.c_double] * 5 + [C.c_int]),
     ("rt_object_rect_xz", C.c_int, [C.c_void_p] + [C.c_double] * 5 + [C.c_int]),
@@ -111,6 +118,9 @@ _SIGS = [
     ("rt_object_mesh", C.c_int, [C.c_void_p, C.c_int, _dp, _dp, C.c_int, C.POINTER(C.c_uint32), C.c_int, C.c_int, C.c_uint64]),
     ("rt_object_mesh_obj", C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_uint64]),
     ("rt_object_transform", C.c_int, [C.c_void_p, _d3, _d3, _d3, C.c_int]),
+    ("rt_object_transform_matrix", C.c_int, [C.c_void_p, C.c_double * 16, C.POINTER(C.c_double), C.c_int]),
+    ("rt_mesh_data", C.c_int, [C.c_void_p, C.c_int, _dp, _dp]),
+    ("rt_object_triangle", C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]),
     ("rt_object_list", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     ("rt_object_bvh_node", C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     ("rt_object_bvh_build", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_uint64]),
@@ -126,6 +136,8 @@ _SIGS = [
     ("rt_scene_commit", C.c_int, [C.c_void_p]),
     ("rt_scene_info_get", C.c_int, [C.c_void_p, C.POINTER(rt_scene_info)]),
     ("rt_render", C.c_int, [C.c_void_p, C.POINTER(rt_camera), C.POINTER(rt_params), _dp, C.POINTER(rt_stats)]),
+    ("rt_render_camera_frame", C.c_int, [C.c_void_p, C.POINTER(rt_camera_frame), C.POINTER(rt_params), _dp, C.POINTER(rt_stats)]),
+    ("rt_camera_frame_from", C.c_int, [C.POINTER(rt_camera), C.POINTER(rt_camera_frame)]),
     ("rt_default_sppm_config", None, [C.POINTER(rt_sppm_config)]),
     ("rt_render_sppm", C.c_int, [C.c_void_p, C.POINTER(rt_camera), C.POINTER(rt_params), C.POINTER(rt_sppm_config), _dp, _dp,
                                  C.POINTER(C.c_uint64), C.POINTER(rt_stats)]),
@@ -223,6 +235,12 @@ class Camera:
         self.c = c
         return self
 
+    def frame(self):
+        """the Camera struct's stored fields (camera.rs:12-21) as an rt_camera_frame: rt_camera_frame_from = Camera::new"""
+        f = rt_camera_frame()
+        _chk(lib().rt_camera_frame_from(C.byref(self.c), C.byref(f)))
+        return f
+
     def with_aspect(self, aspect):
         c = rt_camera.from_buffer_copy(self.c)
         c.aspect = float(aspect)
@@ -277,6 +295,9 @@ class World:
     def DiffuseLight(self, emit):
         return _chk(self.L.rt_material_diffuse_light(self.h, emit))
 
+    def Isotropic(self, albedo):
+        return _chk(self.L.rt_material_isotropic(self.h, albedo))
+
     # --- hitables (objects/*.rs, light.rs) ---
     def Sphere(self, center, radius, material):
         return _chk(self.L.rt_object_sphere(self.h, _arr3(center), float(radius), material))
@@ -300,6 +321,9 @@ class World:
         return _chk(self.L.rt_object_xz_rect_light(self.h, float(xz0[0]), float(xz0[1]), float(xz1[0]), float(xz1[1]), float(y),
                                                    _arr3(flux), float(scale)))
 
+    def ConstantMedium(self, density, boundary, phase_function):
+        return _chk(self.L.rt_object_constant_medium(self.h, float(density), boundary, phase_function))
+
     def Mesh(self, positions, normals, indices, material, synthesize_normals=False, bvh_seed=1):
         p = np.ascontiguousarray(positions, dtype=np.float64).reshape(-1, 3)
         i = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1, 3)
@@ -316,6 +340,24 @@ class World:
 
     def Transform(self, rotate_in_degree, scale, translate, obj):
         return _chk(self.L.rt_object_transform(self.h, _arr3(rotate_in_degree), _arr3(scale), _arr3(translate), obj))
+
+    def Transform_from_matrix(self, trans, obj, inverse_trans=None):
+        """Transform as the reference stores it: the composed 4x4 (row-major) and optionally its inverse."""
+        m = (C.c_double * 16)(*[float(x) for x in np.asarray(trans, dtype=np.float64).reshape(16)])
+        inv = None
+        if inverse_trans is not None:
+            inv = (C.c_double * 16)(*[float(x) for x in np.asarray(inverse_trans, dtype=np.float64).reshape(16)])
+        return _chk(self.L.rt_object_transform_matrix(self.h, m, inv, obj))
+
+    def MeshData(self, positions, normals):
+        """the shared vertex arrays of a mesh (returns a mesh id for Triangle)"""
+        p = np.ascontiguousarray(positions, dtype=np.float64).reshape(-1, 3)
+        n = np.ascontiguousarray(normals, dtype=np.float64).reshape(-1, 3)
+        assert n.shape == p.shape
+        return _chk(self.L.rt_mesh_data(self.h, p.shape[0], p.ctypes.data_as(_dp), n.ctypes.data_as(_dp)))
+
+    def Triangle(self, mesh, a, b, c, material):
+        return _chk(self.L.rt_object_triangle(self.h, mesh, int(a), int(b), int(c), material))
 
     def HitableList(self, objects):
         arr = (C.c_int * len(objects))(*objects)
@@ -380,6 +422,15 @@ class World:
         out = np.zeros((height, width, 3), dtype=np.float64)
         st = rt_stats()
         _chk(self.L.rt_render(self.h, C.byref(camera.c), C.byref(p), out.ctypes.data_as(_dp), C.byref(st)))
+        return out, st.as_dict()
+
+    def render_camera_frame(self, frame, **kw):
+        """rt_render_camera_frame: `frame` is an rt_camera_frame (the Camera struct's stored fields)."""
+        width, height = kw.get("width", 800), kw.get("height", 800)
+        p = default_params(**kw)
+        out = np.zeros((height, width, 3), dtype=np.float64)
+        st = rt_stats()
+        _chk(self.L.rt_render_camera_frame(self.h, C.byref(frame), C.byref(p), out.ctypes.data_as(_dp), C.byref(st)))
         return out, st.as_dict()
 
     def render_sppm(self, camera, width=800, height=800, spp=256, iterations=50, photons_per_iter=500000, alpha=0.7, k_global=100,

@@ -23,6 +23,51 @@ def test_header_and_binding_agree():
     assert sorted(rtamd.ABI_SYMBOLS) == declared_symbols()
 
 
+def test_rust_binding_declares_every_symbol_and_describes_every_reference_type():
+    """rust-raytracer_amd/rust/rtamd_ffi.rs cannot be compiled here (no rustc): at least its extern block must list exactly the
+    header's symbols with the header's argument counts, its #[repr(C)] structs the header's fields in order, and every Hitable /
+    Material / Texture of the reference must have its Describe impl."""
+    rs = open(os.path.join(ROOT, "rust-raytracer_amd", "rust", "rtamd_ffi.rs")).read()
+    ext = rs[rs.index('extern "C" {'):]
+    ext = ext[:ext.index("\n}\n")]
+    rust_fns = dict((m.group(1), m.group(2)) for m in re.finditer(r"pub fn (rt_[a-z0-9_]+)\((.*?)\)", ext, flags=re.S))
+    assert sorted(rust_fns) == declared_symbols()
+    header = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    for name, args in rust_fns.items():
+        m = re.search(r"\b%s\s*\((.*?)\)\s*;" % name, header, flags=re.S)
+        c_args = [a for a in m.group(1).split(",") if a.strip() not in ("", "void")]
+        r_args = [a for a in args.split(",") if a.strip()]
+        assert len(c_args) == len(r_args), (name, c_args, r_args)
+
+    def c_fields(struct):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), header, flags=re.S).group(1)
+        names = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            for part in decl.split(","):
+                names.append(re.sub(r"\[.*?\]", "", part.strip().split()[-1]).lstrip("*"))
+        return names
+
+    def rs_fields(struct):
+        body = re.search(r"pub struct %s \{(.*?)\n\}" % struct, rs, flags=re.S).group(1)
+        return [m.group(1).rstrip("_") for m in re.finditer(r"pub ([a-z_0-9]+):", body)]
+    for st in ("rt_camera", "rt_camera_frame", "rt_params", "rt_stats", "rt_sppm_config", "rt_tuning", "rt_object_desc", "rt_scene_info"):
+        assert rs_fields(st) == c_fields(st), st
+    for ty in ("ConstantTexture", "CheckerTexture", "ImageTexture"):
+        assert "impl DescribeTexture for %s" % ty in rs
+    for ty in ("Lambertian", "Metal", "Dielectric", "DiffuseLight"):
+        assert re.search(r"impl<T: Texture \+ 'static> DescribeMaterial for %s<T>" % ty, rs)
+    for ty in ("Sphere", "XYRectangle", "XZRectangle", "YZRectangle", "Cube", "Vec<Arc<dyn Hitable>>", "BVHNode", "Triangle", "Mesh", "Transform",
+               "ConstantMedium", "SphereDiffuseLight", "XZRectLight"):
+        assert "impl DescribeHitable for %s" % ty in rs, ty
+    builder = rs[rs.index("impl SceneBuilder {"):rs.index("impl Drop for SceneBuilder")]
+    for sym in declared_symbols():
+        if sym.startswith(("rt_texture_", "rt_material_", "rt_object_")) and sym not in ("rt_object_describe", "rt_object_children"):
+            assert sym + "(" in builder, "SceneBuilder has no method over %s" % sym
+
+
 def test_library_exports_every_declared_symbol():
     import rtamd
     L = ctypes.CDLL(rtamd.LIB_PATH)

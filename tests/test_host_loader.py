@@ -194,3 +194,87 @@ def test_graph_introspection_matches_what_was_built():
     assert w.root() == lst
     with pytest.raises(rtamd.RtError):
         w.describe(10 ** 6)
+
+
+def test_host_graph_entry_points_for_stored_fields_match_the_constructors():
+    """A host that already OWNS the reference's objects hands over what they store: Transform's composed matrix (transform.rs:9-14),
+    Triangles on shared vertex arrays under its own BVHNode tree (mesh.rs:8-16,144-146), Camera's derived frame (camera.rs:12-21).
+    Built that way, a scene flattens to the same bytes as through the constructor-style entry points."""
+    import oracle
+    import rtamd
+    P, N, I = oracle.load_obj(scene_path("cube.obj"))
+
+    def build(via_stored_fields):
+        w = rtamd.World()
+        m = w.Lambertian(w.ConstantTexture((0.7, 0.7, 0.2)))
+        mesh = w.Mesh(P, N, I, m, bvh_seed=4)
+        if not via_stored_fields:
+            t = w.Transform((20.0, 35.0, 10.0), (0.7, 1.1, 0.5), (2.5, 1.2, 2.0), mesh)
+            root = w.HitableList([t, w.Sphere((0, 0, 0), 1, m)])
+            return w, w.set_root(root) and root
+        # walk the mesh's own BVH as a Describe visitor would and rebuild it from explicit triangles on a registered vertex array
+        md = w.MeshData(P, N)
+
+        seen = {}     # a shared node (Arc clone: BVHNode::new puts a lone object into BOTH children, Q14) is emitted once
+
+        def clone(o):
+            if o in seen:
+                return seen[o]
+            kind, d = w.describe(o)
+            if kind == "Triangle":
+                a, b, c = (int(x) for x in d["v"][:3])
+                seen[o] = w.Triangle(md, a, b, c, d["material"])
+            else:
+                assert kind == "BVHNode"
+                seen[o] = w.BVHNode_construct(clone(d["children"][0]), clone(d["children"][1]))
+            return seen[o]
+        kind, d = w.describe(mesh)
+        assert kind == "Mesh"
+        inner = clone(d["children"][0])
+        # the composed matrix T*S*Rx*Ry*Rz of the constructor-built Transform, read back through its bounding box is not enough:
+        # compose it here exactly as transform.rs:28-106 does (k-ascending products)
+        import math
+        rx, ry, rz = (math.radians(v) for v in (20.0, 35.0, 10.0))
+        T = np.array([[1, 0, 0, 2.5], [0, 1, 0, 1.2], [0, 0, 1, 2.0], [0, 0, 0, 1.0]])
+        S = np.diag([0.7, 1.1, 0.5, 1.0])
+        RX = np.array([[1, 0, 0, 0], [0, math.cos(rx), -math.sin(rx), 0], [0, math.sin(rx), math.cos(rx), 0], [0, 0, 0, 1.0]])
+        RY = np.array([[math.cos(ry), 0, math.sin(ry), 0], [0, 1, 0, 0], [-math.sin(ry), 0, math.cos(ry), 0], [0, 0, 0, 1.0]])
+        RZ = np.array([[math.cos(rz), -math.sin(rz), 0, 0], [math.sin(rz), math.cos(rz), 0, 0], [0, 0, 1, 0], [0, 0, 0, 1.0]])
+
+        def mm(a, b):
+            c = np.zeros((4, 4))
+            for i in range(4):
+                for j in range(4):
+                    acc = a[i, 0] * b[0, j]
+                    for k in range(1, 4):
+                        acc = acc + a[i, k] * b[k, j]
+                    c[i, j] = acc
+            return c
+        M = mm(mm(mm(mm(T, S), RX), RY), RZ)
+        t = w.Transform_from_matrix(M, inner)
+        root = w.HitableList([t, w.Sphere((0, 0, 0), 1, m)])
+        w.set_root(root)
+        return w, root
+
+    wa, ra = build(False)
+    wb, rb = build(True)
+    ka, da = wa.describe(wa.describe(ra)[1]["children"][0])
+    kb, db = wb.describe(wb.describe(rb)[1]["children"][0])
+    assert ka == kb == "Transform"
+    assert np.array_equal(wa.bounding_box(wa.describe(ra)[1]["children"][0]), wb.bounding_box(wb.describe(rb)[1]["children"][0]))
+    ia, ib = wa.info(), wb.info()
+    for k in ("n_nodes", "n_boxes", "n_tris", "n_xforms", "accel_nodes", "accel_items", "accel_instances"):
+        assert ia[k] == ib[k], k
+    # Camera: the stored frame equals Camera::new's, field by field (oracle's camera_basis is the independent restatement)
+    cam = rtamd.Camera(((13.0, 2.0, 3.0), (0.0, 0.5, 0.0)), (0, 1, 0), 20.0, 1.5, 0.1, 10.0)
+    f = cam.frame()
+    o = oracle.Scene()
+    o.Camera((13.0, 2.0, 3.0), (0.0, 0.5, 0.0), (0, 1, 0), 20.0, 1.5, 0.1, 10.0)
+    basis = o.camera_basis()      # origin, lower_left_corner, horizontal, vertical, u, v, w (3 each), lens_radius
+    for i, name in enumerate(("origin", "lower_left_corner", "horizontal", "vertical", "u", "v", "w")):
+        assert tuple(getattr(f, name)) == tuple(basis[3 * i:3 * i + 3]), name
+    assert f.lens_radius == basis[21] == 0.05
+    with pytest.raises(rtamd.RtError) as e:
+        wa2 = rtamd.World()
+        wa2.Transform_from_matrix(np.zeros((4, 4)), wa2.Sphere((0, 0, 0), 1, wa2.Lambertian(wa2.ConstantTexture((1, 1, 1)))))
+    assert e.value.code == -4

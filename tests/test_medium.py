@@ -1,0 +1,183 @@
+"""ConstantMedium + Isotropic (objects/medium.rs:9-57, material.rs:213-231 -- dead / commented-out code in the
+reference, so parity is against the oracle's restatement only, D8 in oracle/rt_oracle.cpp).
+
+CPU: the oracle's medium against closed forms (Beer-Lambert transmittance, mean free path, clipping to [t_min, t_max], RNG draw
+only when the boundary is crossed), rtamd-ln-1 against numpy's log, host description / flattening of the product.
+GPU: HIP == oracle bit for bit on scenes with media (sphere and box boundaries, inside a BVH, under a Transform, next to glass);
+the device's det_ln == the oracle's == numpy within 1 ulp."""
+import numpy as np
+import pytest
+
+from conftest import scene_path
+
+
+def _ray_through_sphere_medium(density, n, radius=1.0, t_min=1e-3, t_max=float("inf")):
+    """n rays along a diameter of a sphere-bounded medium, each with its own RNG stream; returns hit ts (nan = passed through)."""
+    import oracle
+    o = oracle.Scene()
+    iso = o.Isotropic(o.ConstantTexture((1.0, 1.0, 1.0)))
+    s = o.Sphere((0.0, 0.0, 0.0), radius, iso)
+    med = o.ConstantMedium(density, s, iso)
+    ts = np.full(n, np.nan)
+    for i in range(n):
+        rec = o.hit((0.0, 0.0, -5.0), (0.0, 0.0, 2.0), t_min, t_max, obj=med, key=(7, i, 0))   # |dir| = 2: t is in units of 2
+        if rec is not None:
+            ts[i] = rec["t"]
+    return ts
+
+
+def test_det_ln_is_within_one_ulp_of_log_and_exact_on_its_special_values():
+    import oracle
+    rng = np.random.default_rng(3)
+    xs = np.concatenate([rng.integers(1, 1 << 53, size=50000).astype(np.float64) / 2.0 ** 53,          # gen::<f64>() values
+                         np.ldexp(rng.random(20000) + 0.5, rng.integers(-300, 300, 20000)), [2.0 ** -53, 1.0 - 2.0 ** -53, 0.5, 2.0]])
+    d = np.array([oracle.det_ln(x) for x in xs])
+    ref = np.log(xs)
+    assert np.all(np.abs(d - ref) <= np.spacing(np.abs(ref)))
+    assert oracle.det_ln(1.0) == 0.0 and oracle.det_ln(0.0) == -np.inf and np.isnan(oracle.det_ln(-1.0))
+    assert oracle.det_ln(np.inf) == np.inf and oracle.det_ln(np.exp(1.0)) == pytest.approx(1.0, abs=2e-16)
+
+
+def test_oracle_medium_obeys_beer_lambert():
+    """P(no scattering along a chord of length L) = exp(-d L); scattering depths are exponentially distributed."""
+    n = 20000
+    for density, radius in ((0.4, 1.0), (1.5, 0.75)):
+        ts = _ray_through_sphere_medium(density, n, radius)
+        chord = 2.0 * radius
+        passed = np.isnan(ts).mean()
+        expect = np.exp(-density * chord)
+        assert abs(passed - expect) < 4.0 * np.sqrt(expect * (1 - expect) / n), (density, passed, expect)
+        depth = (ts[~np.isnan(ts)] - (5.0 - radius) / 2.0) * 2.0            # distance inside the boundary (|dir| = 2)
+        assert depth.min() >= 0.0 and depth.max() <= chord
+        # mean of an exponential truncated to [0, chord]
+        lam = density
+        mean_trunc = 1.0 / lam - chord * np.exp(-lam * chord) / (1.0 - np.exp(-lam * chord))
+        assert depth.mean() == pytest.approx(mean_trunc, rel=0.03)
+
+
+def test_oracle_medium_clipping_and_rng_discipline():
+    import oracle
+    o = oracle.Scene()
+    iso = o.Isotropic(o.ConstantTexture((0.9, 0.8, 0.7)))
+    s = o.Sphere((0.0, 0.0, 0.0), 1.0, iso)
+    med = o.ConstantMedium(1e6, s, iso)                      # so dense that every crossing scatters at once
+    inf = float("inf")
+    # from outside: scatters right at the entry point t1 = 4 (unit direction); the arbitrary normal (1,0,0) is perpendicular to
+    # this ray, so front_face = (dir . n < 0) is False and HitRecord::new flips it (hit.rs:24-33)
+    rec = o.hit((0.0, 0.0, -5.0), (0.0, 0.0, 1.0), 1e-3, inf, obj=med, key=(1, 2, 3))
+    assert rec["t"] == pytest.approx(4.0, abs=1e-5) and tuple(rec["normal"]) == (-1.0, 0.0, 0.0) and rec["front_face"] is False
+    assert rec["uv"] == (0.0, 0.0) and rec["prim_id"] == med
+    rec = o.hit((5.0, 0.0, 0.0), (-1.0, 0.0, 0.0), 1e-3, inf, obj=med, key=(1, 2, 3))
+    assert tuple(rec["normal"]) == (1.0, 0.0, 0.0) and rec["front_face"] is True
+    # from inside: the entry is clipped to t_min, then to 0 (medium.rs:28,33)
+    rec = o.hit((0.0, 0.0, 0.0), (0.0, 0.0, 1.0), 1e-3, inf, obj=med, key=(1, 2, 3))
+    assert 1e-3 <= rec["t"] < 1e-3 + 1e-5
+    # t_max in front of the boundary: None, and NO random number is drawn (medium.rs:30-32 returns before :37)
+    assert o.hit((0.0, 0.0, -5.0), (0.0, 0.0, 1.0), 1e-3, 3.5, obj=med, key=(4, 5, 6)) is None and o.last_draws == 0
+    assert o.hit((0.0, 3.0, -5.0), (0.0, 0.0, 1.0), 1e-3, inf, obj=med, key=(4, 5, 6)) is None and o.last_draws == 0   # misses the boundary
+    assert o.hit((0.0, 0.0, -5.0), (0.0, 0.0, 1.0), 1e-3, inf, obj=med, key=(4, 5, 6)) is not None and o.last_draws == 1
+    thin = o.ConstantMedium(1e-9, s, iso)                     # crossed, one draw, but the free flight is longer than the chord
+    assert o.hit((0.0, 0.0, -5.0), (0.0, 0.0, 1.0), 1e-3, inf, obj=thin, key=(4, 5, 6)) is None and o.last_draws == 1
+    # bounding box = the boundary's
+    assert np.array_equal(o.bounding_box(med), o.bounding_box(s))
+
+
+def test_isotropic_scatter_is_uniform_on_the_sphere():
+    import oracle
+    o = oracle.Scene()
+    iso = o.Isotropic(o.ConstantTexture((0.2, 0.4, 0.6)))
+    dirs = []
+    for i in range(4000):
+        r = o.scatter(iso, (0, 0, 0), (0, 0, 1), (1.0, 2.0, 3.0), (1.0, 0.0, 0.0), True, key=(9, i, 0))
+        assert r["kind"] == 1 and r["scattered"]                              # Interaction::Specular (pass-through), D8
+        assert tuple(r["attenuation"]) == (0.2, 0.4, 0.6) and tuple(r["orig"]) == (1.0, 2.0, 3.0) and not r["emitted"].any()
+        dirs.append(r["dir"])
+    dirs = np.array(dirs)
+    assert np.allclose(np.linalg.norm(dirs, axis=1), 1.0, atol=1e-12)          # random_in_unit_sphere: ON the sphere (Q3)
+    assert np.all(np.abs(dirs.mean(axis=0)) < 0.05) and np.allclose((dirs ** 2).mean(axis=0), 1.0 / 3.0, atol=0.02)
+
+
+def _smoke_scene(B, seed_arg):
+    """book-2 style: a ground, a light, a glass ball, a dense smoke ball inside a BVH, a thin fog box under a Transform."""
+    ground = B.Lambertian(B.CheckerTexture(B.ConstantTexture((0.2, 0.3, 0.1)), B.ConstantTexture((0.9, 0.9, 0.9))))
+    white = B.Lambertian(B.ConstantTexture((0.73, 0.73, 0.73)))
+    light = B.DiffuseLight(B.ConstantTexture((7.0, 7.0, 7.0)))
+    smoke = B.Isotropic(B.ConstantTexture((0.1, 0.1, 0.1)))
+    fog = B.Isotropic(B.ConstantTexture((0.9, 0.95, 1.0)))
+    glass = B.Dielectric(1.5, B.ConstantTexture((1.0, 1.0, 1.0)))
+    ball = B.Sphere((0.0, 1.0, 0.0), 1.0, white)
+    box = B.Cube((-1.0, -1.0, -1.0), (1.0, 1.0, 1.0), white)
+    items = [
+        B.XZRectangle((-20.0, -20.0), (20.0, 20.0), 0.0, ground),
+        B.XZRectangle((-3.0, -3.0), (3.0, 3.0), 6.0, light),
+        B.Sphere((2.6, 1.0, 0.5), 1.0, glass),
+        B.ConstantMedium(1.2, ball, smoke),
+        B.ConstantMedium(0.15, B.Transform((0.0, 30.0, 0.0), (1.5, 1.0, 1.5), (-3.0, 1.01, 0.5), box), fog),
+        B.Sphere((-0.5, 0.4, -2.2), 0.4, B.Metal(B.ConstantTexture((0.8, 0.8, 0.9)), 0.05)),
+    ]
+    return items
+
+
+def test_product_describes_and_flattens_media():
+    import rtamd
+    w = rtamd.World()
+    items = _smoke_scene(w, 1)
+    w.new(items, bvh_seed=1)
+    info = w.info()
+    assert info["accel_ok"] == 0                      # RNG inside hit(): reference order only
+    kind, d = w.describe(items[3])
+    assert kind == "ConstantMedium" and d["v"][0] == 1.2 and len(d["children"]) == 1 and w.describe(d["children"][0])[0] == "Sphere"
+    with pytest.raises(rtamd.RtError) as e:
+        w2 = rtamd.World()
+        m = w2.Isotropic(w2.ConstantTexture((1, 1, 1)))
+        inner = w2.ConstantMedium(1.0, w2.Sphere((0, 0, 0), 1, m), m)
+        w2.ConstantMedium(1.0, inner, m)
+    assert e.value.code == -10
+    with pytest.raises(rtamd.RtError) as e:
+        w3 = rtamd.World()
+        m = w3.Isotropic(w3.ConstantTexture((1, 1, 1)))
+        w3.ConstantMedium(0.0, w3.Sphere((0, 0, 0), 1, m), m)
+    assert e.value.code == -1
+
+
+@pytest.mark.gpu
+def test_device_det_ln_equals_the_oracles():
+    import oracle
+    import rtamd
+    rng = np.random.default_rng(11)
+    xs = np.concatenate([rng.integers(1, 1 << 53, size=200000).astype(np.float64) / 2.0 ** 53, [2.0 ** -53, 1.0 - 2.0 ** -53, 0.5, 0.0]])
+    dev = rtamd.debug_math(2, xs)
+    ora = np.array([oracle.det_ln(x) for x in xs])
+    assert np.array_equal(dev, ora)
+    ref = np.log(xs[:-1])
+    assert np.all(np.abs(dev[:-1] - ref) <= np.spacing(np.abs(ref)))
+
+
+@pytest.mark.gpu
+def test_hip_media_bit_exact_vs_oracle():
+    import oracle
+    import rtamd
+    w = rtamd.World()
+    w.new(_smoke_scene(w, 1), bvh_seed=5)
+    o = oracle.Scene()
+    o.World(_smoke_scene(o, 1), 5)
+    o.Camera((0.0, 2.5, -9.0), (0.0, 1.0, 0.0), (0, 1, 0), 40.0, 1.5, 0.02, 9.0)
+    cam = rtamd.Camera(((0.0, 2.5, -9.0), (0.0, 1.0, 0.0)), (0, 1, 0), 40.0, 1.5, 0.02, 9.0)
+    img, st = w.render(cam, width=96, height=64, spp=16, seed=3)
+    exp, _ = o.render(96, 64, 16, seed=3)
+    assert st["kernel_used"] == 1
+    assert np.array_equal(img, exp), np.abs(img - exp).max()
+    assert img.max() > 0.5
+    # the fog really scatters: the same scene without the two media renders differently
+    w2 = rtamd.World()
+    items = _smoke_scene(w2, 1)
+    w2.new([it for i, it in enumerate(items) if i not in (3, 4)], bvh_seed=5)
+    clear, _ = w2.render(cam, width=96, height=64, spp=16, seed=3)
+    assert not np.array_equal(clear, img)
+    # kernel 2, light sampling and the closest-hit diagnostic refuse scenes with media
+    for kw in (dict(kernel=2), dict(integrator=1)):
+        with pytest.raises(rtamd.RtError) as e:
+            w.render(cam, width=8, height=8, spp=1, **kw)
+        assert e.value.code in (-10, -1)
+    with pytest.raises(rtamd.RtError):
+        w.debug_hit(np.zeros((1, 6)) + 1.0, kernel=1)
