@@ -180,7 +180,8 @@ struct RenderK {
     int s_begin, s_end;  // sample indices of this launch
     int sub_spp, subs_per_tile, n_units;
     int tiles_x, rank, world;
-    int tiles_owned;  // units are dealt sample-major: unit u = (tile u % tiles_owned, sample block u / tiles_owned)
+    int tiles_owned;  // jobs are dealt sample-major: job j = (tile j % tiles_owned, sample blocks [j / tiles_owned * job_units, + job_units))
+    int job_units;    // consecutive units of one tile a wave takes at a time (one ticket hand-off per job); n_units counts JOBS
     const double* sppm_est;  // INTEG 2: per pixel {caustic estimate[3], global estimate[3]}, index y*width + x
     int n_top;               // kernel 2 with the scene in L2/HBM: number of (depth-sorted) Node2 cached in LDS
 };
@@ -801,64 +802,187 @@ DEV bool mixture_step(const Acc& A, const Rec& rec, Rng& rng, D3 att, D3& beta, 
 // <= UNIT_SPP consecutive sample indices).  A wave owns a small RING of unit buffers in global memory (RING_UNITS x 12 KB);
 // finished paths store their radiance there, an LDS counter per ring slot tells when a unit is complete, and the wave then
 // FOLDS it: lane = pixel, accum += the unit's samples in index order.  Units of one tile are folded in order across waves
-// through a per-tile ticket (= number of units folded).  Units are dealt sample-major (all tiles' unit 0, then all tiles'
-// unit 1, ...), so a unit's predecessor on the same tile was handed out thousands of units earlier and is normally long folded;
-// when it is not, the wave keeps tracing its newer units and retries (it only waits when its ring is full).  No deadlock: the
-// unfolded unit with the smallest index is at the head of its wave's ring and its predecessor is folded.
+// through a per-tile ticket (= number of sample blocks folded).  A wave takes JOBS of JOB_UNITS consecutive units of one tile, so
+// only every JOB_UNITS-th fold crosses waves; jobs are dealt sample-major (all tiles' job 0, then all tiles' job 1, ...), so a
+// job's predecessor on the same tile was handed out thousands of jobs earlier and is normally long folded; when it is not, the
+// wave keeps tracing its newer units and retries (it only waits when it has nothing else to do).  No deadlock: the unfolded job
+// with the smallest index is at the head of its wave's ring and its predecessor is folded.
 // Accumulator and ticket cross waves on different XCDs (L2s are not coherent): both are accessed ONLY with 8-/4-byte agent-scope
 // atomics (served at the memory side), the folding wave drains its stores (s_waitcnt vmcnt(0)) before it advances the ticket.
 static const int REGEN_MIN = 8;
 static const int UNIT_SPP = 8;                              // sample indices per work unit, at most
 #ifndef RING_UNITS
-#define RING_UNITS 6                                         // unit buffers per wave
+#define RING_UNITS 10                                        // unit buffers per wave (two jobs of 4 units and some slack)
 #endif
 static const int UNIT_DOUBLES = UNIT_SPP * TILE_PIX * 3;    // 12 KB per unit
+#ifndef JOB_UNITS
+#define JOB_UNITS 4                                          // consecutive units of one tile per job (one accumulator hand-off per job)
+#endif
 DEV uint64_t ld_agent(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 DEV void st_agent(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// Fold the wave's completed units, oldest first, into the accumulator (see "Where the samples go" below).  Returns how many
-// units were folded.  `idle`: the wave has nothing else to do, so it waits for the tile's previous unit instead of returning.
-__device__ __attribute__((noinline)) int fold_units(const uint32_t* rmeta, const double* wring, double* accum, unsigned int* tickets, int tiles_owned,
-                                                    bool first_launch, int r_head, int r_cnt, bool idle, int lane) {
+// Fold the wave's completed units, oldest first, into the accumulator (see "Where the samples go" above).  Returns how many
+// units were folded.  `idle`: the wave has nothing else to do, so it waits for the tile's previous job instead of returning.
+// Units of one JOB (consecutive sample blocks of one tile, traced by this wave) sit next to each other in the ring: the tile's
+// ticket is looked at once per job (its first unit), the accumulator is loaded once and stored once per run of the job's
+// units, and the ticket moves after the job's last unit -- the ~3 memory round trips of a fold are paid per job, not per unit.
+// rmeta per ring slot: {tile (local), first sample block of the unit within the launch, samples | first << 8 | last << 9, paths running}
+#ifdef RT_FOLD_STATS  // tools-only build: {calls, cycles in fold_units, units folded, returns on a ticket mismatch, sleeps}
+__device__ unsigned long long g_fold_stats[8];
+#endif
+__device__ __attribute__((noinline)) int fold_units(const uint32_t* rmeta, const double* wring, double* accum, unsigned int* tickets, bool first_launch,
+                                                    int r_head, int r_cnt, bool idle, int lane) {
+#ifdef RT_FOLD_STATS
+    const unsigned long long t_in = __builtin_amdgcn_s_memtime();
+    unsigned long long n_mis = 0, n_sleep = 0;
+#endif
     int folded = 0;
+    bool have = false;
+    uint32_t cur_tile = 0;
+    double ax = 0., ay = 0., az = 0.;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's sample stores are in L2
     while (r_cnt > 0) {
         const uint32_t* m = rmeta + 4 * r_head;
-        if (__hip_atomic_load(&m[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) break;  // paths still running
-        const uint32_t unit = m[0], ns = m[1];
-        const uint32_t ult = unit % (uint32_t)tiles_owned, usub = unit / (uint32_t)tiles_owned;
-        const uint32_t tk = __hip_atomic_load(&tickets[ult], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (tk != usub) {  // the tile's previous unit is not folded yet (rare): trace on unless nothing else is left to do
-            if (!idle) break;
-            __builtin_amdgcn_s_sleep(4);
-            continue;
+        if (__hip_atomic_load(&m[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) break;  // paths still running
+        const uint32_t tile = m[0], blk = m[1], ns = m[2] & 0xffu;
+        const bool first = (m[2] & 0x100u) != 0u, last = (m[2] & 0x200u) != 0u;
+        if (first) {
+            const uint32_t tk = __hip_atomic_load(&tickets[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tk != blk) {  // the tile's previous job is not folded yet (rare): trace on unless nothing else is left to do
+#ifdef RT_FOLD_STATS
+                if (!idle) n_mis++;
+                else n_sleep++;
+#endif
+                if (!idle) break;
+                __builtin_amdgcn_s_sleep(4);
+                continue;
+            }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's sample stores are in L2
-        {
-            uint64_t* acc = (uint64_t*)accum + ((size_t)ult * TILE_PIX + (size_t)lane) * 3;
-            double ax = 0., ay = 0., az = 0.;
-            if (!(usub == 0u && first_launch)) {
+        uint64_t* acc = (uint64_t*)accum + ((size_t)tile * TILE_PIX + (size_t)lane) * 3;
+        if (!have) {
+            ax = 0.; ay = 0.; az = 0.;
+            if (!(blk == 0u && first_launch)) {
                 ax = __longlong_as_double(ld_agent(acc));
                 ay = __longlong_as_double(ld_agent(acc + 1));
                 az = __longlong_as_double(ld_agent(acc + 2));
             }
-            const uint64_t* p = (const uint64_t*)wring + ((size_t)r_head * UNIT_SPP * TILE_PIX + (size_t)lane) * 3;
-            for (uint32_t si = 0; si < ns; si++) {  // pixel_color += sample, in sample order (camera.rs:96-101)
-                ax = ax + __longlong_as_double(ld_agent(p));
-                ay = ay + __longlong_as_double(ld_agent(p + 1));
-                az = az + __longlong_as_double(ld_agent(p + 2));
-                p += TILE_PIX * 3;
-            }
-            st_agent(acc, __double_as_longlong(ax));
-            st_agent(acc + 1, __double_as_longlong(ay));
-            st_agent(acc + 2, __double_as_longlong(az));
+            have = true;
+            cur_tile = tile;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // accumulator stores done before the ticket moves
-        if (lane == 0) __hip_atomic_store(&tickets[ult], usub + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint64_t* p = (const uint64_t*)wring + ((size_t)r_head * UNIT_SPP * TILE_PIX + (size_t)lane) * 3;
+        for (uint32_t si = 0; si < ns; si++) {  // pixel_color += sample, in sample order (camera.rs:96-101)
+            ax = ax + __longlong_as_double(ld_agent(p));
+            ay = ay + __longlong_as_double(ld_agent(p + 1));
+            az = az + __longlong_as_double(ld_agent(p + 2));
+            p += TILE_PIX * 3;
+        }
         r_head = (r_head + 1 == RING_UNITS) ? 0 : r_head + 1;
         r_cnt--;
         folded++;
+        // the next unit continues this job iff it exists, is complete and is not the first of another job
+        bool more = false;
+        if (!last && r_cnt > 0) {
+            const uint32_t* n = rmeta + 4 * r_head;
+            more = __hip_atomic_load(&n[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u;
+        }
+        if (!more) {
+            st_agent(acc, __double_as_longlong(ax));
+            st_agent(acc + 1, __double_as_longlong(ay));
+            st_agent(acc + 2, __double_as_longlong(az));
+            have = false;
+            if (last) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // accumulator stores done before the ticket moves
+                if (lane == 0) __hip_atomic_store(&tickets[cur_tile], blk + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                break;  // the job's next unit still runs: come back later (it needs no ticket)
+            }
+        }
     }
+#ifdef RT_FOLD_STATS
+    if (lane == 0) {
+        atomicAdd(&g_fold_stats[0], 1ull);
+        atomicAdd(&g_fold_stats[1], (unsigned long long)__builtin_amdgcn_s_memtime() - t_in);
+        atomicAdd(&g_fold_stats[2], (unsigned long long)folded);
+        atomicAdd(&g_fold_stats[3], n_mis);
+        atomicAdd(&g_fold_stats[4], n_sleep);
+    }
+#endif
     return folded;
+}
+
+// What a wave does when its pool is exhausted and lanes are free: fold completed units, then start the next unit of its job or
+// fetch the next job.  Everything it needs lives in LDS (per-wave state `wst`, launch constants `cfg`), so that the hot loop
+// carries only {pool, next, s0, tx, ty, cur_slot, finished} for all of this; out of line for the same reason (it runs about once
+// per 512 paths).
+//   wst: {r_head, r_cnt, job_tile, job_blk0, job_n, job_k, more_jobs, -}      cfg: see CFG_* below
+enum { CFG_N_JOBS, CFG_TILES_OWNED, CFG_JOB_UNITS, CFG_SUBS_PER_TILE, CFG_WORLD, CFG_RANK, CFG_TILES_X, CFG_S_BEGIN, CFG_S_END, CFG_SUB_SPP,
+       CFG_WIDTH, CFG_HEIGHT, CFG_WORDS = 16 };
+struct UnitInfo {
+    int pool;      // paths of the unit that was started (0: none was)
+    int s0, tx, ty, cur_slot;
+    int finished;  // no job left, every unit folded: the wave may exit once its lanes are dead
+};
+__device__ __attribute__((noinline)) UnitInfo next_unit(uint32_t* wst, uint32_t* rmeta, const int* cfg, const double* wring, double* accum,
+                                                        unsigned int* tickets, unsigned int* counter, bool all_dead, int lane) {
+    int r_head = (int)wst[0], r_cnt = (int)wst[1], job_tile = (int)wst[2], job_blk0 = (int)wst[3], job_n = (int)wst[4], job_k = (int)wst[5];
+    bool more_jobs = wst[6] != 0u;
+    UnitInfo u;
+    u.pool = 0; u.s0 = 0; u.tx = 0; u.ty = 0; u.cur_slot = 0; u.finished = 0;
+    if (r_cnt > 0 && __hip_atomic_load(&rmeta[4 * r_head + 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) {
+        const bool idle = all_dead && (r_cnt == RING_UNITS || (job_k >= job_n && !more_jobs));  // nothing can be started: wait for the ticket
+#ifdef RT_NOFOLD_TEST  // timing experiment only: results are wrong
+        const int folded = 1;
+        (void)idle;
+#else
+        const int folded = fold_units(rmeta, wring, accum, tickets, cfg[CFG_S_BEGIN] == 0, r_head, r_cnt, idle, lane);
+#endif
+        r_head += folded;
+        if (r_head >= RING_UNITS) r_head -= RING_UNITS;
+        r_cnt -= folded;
+    }
+    if (r_cnt < RING_UNITS && (job_k < job_n || more_jobs)) {
+        if (job_k >= job_n) {  // next job: job_units consecutive sample blocks of one tile
+            unsigned int job = 0;
+            if (lane == 0) job = atomicAdd(counter, 1u);
+            job = __builtin_amdgcn_readfirstlane(job);
+            if (job >= (unsigned)cfg[CFG_N_JOBS]) {
+                more_jobs = false;  // every wave gets here: the counter only grows
+            } else {
+                job_tile = (int)(job % (unsigned)cfg[CFG_TILES_OWNED]);  // sample-major: all tiles' job k before any tile's job k+1
+                job_blk0 = (int)(job / (unsigned)cfg[CFG_TILES_OWNED]) * cfg[CFG_JOB_UNITS];
+                job_n = min(cfg[CFG_JOB_UNITS], cfg[CFG_SUBS_PER_TILE] - job_blk0);
+                job_k = 0;
+            }
+        }
+        if (job_k < job_n) {  // start the job's next unit
+            const int tile = job_tile * cfg[CFG_WORLD] + cfg[CFG_RANK];
+            u.tx = tile % cfg[CFG_TILES_X];
+            u.ty = tile / cfg[CFG_TILES_X];
+            const int sub_i = job_blk0 + job_k;
+            u.s0 = cfg[CFG_S_BEGIN] + sub_i * cfg[CFG_SUB_SPP];
+            const int s1 = min(u.s0 + cfg[CFG_SUB_SPP], cfg[CFG_S_END]);
+            u.pool = (s1 - u.s0) * TILE_PIX;
+            u.cur_slot = r_head + r_cnt;
+            if (u.cur_slot >= RING_UNITS) u.cur_slot -= RING_UNITS;
+            r_cnt++;
+            if (lane == 0) {
+                uint32_t* m = rmeta + 4 * u.cur_slot;
+                m[0] = (uint32_t)job_tile;
+                m[1] = (uint32_t)sub_i;
+                m[2] = (uint32_t)(s1 - u.s0) | (job_k == 0 ? 0x100u : 0u) | (job_k + 1 == job_n ? 0x200u : 0u);
+                // paths the unit will run: its pixels inside the image (edge tiles are partial) x its sample indices
+                const int w_in = min(TILE_W, cfg[CFG_WIDTH] - u.tx * TILE_W), h_in = min(TILE_H, cfg[CFG_HEIGHT] - u.ty * TILE_H);
+                __hip_atomic_store(&m[3], (uint32_t)((s1 - u.s0) * w_in * h_in), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            job_k++;
+        }
+    }
+    u.finished = (u.pool == 0 && !more_jobs && job_k >= job_n && r_cnt == 0) ? 1 : 0;
+    if (lane == 0) {
+        wst[0] = (uint32_t)r_head; wst[1] = (uint32_t)r_cnt; wst[2] = (uint32_t)job_tile; wst[3] = (uint32_t)job_blk0;
+        wst[4] = (uint32_t)job_n; wst[5] = (uint32_t)job_k; wst[6] = more_jobs ? 1u : 0u;
+    }
+    return u;
 }
 
 template <bool LDS, bool GENERAL, int ACCEL, int INTEG, bool MEDIA = false>
@@ -895,17 +1019,28 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
     const int lane = threadIdx.x & 63;
     const uint64_t lanemask_lt = (1ull << lane) - 1ull;
     const int wave = threadIdx.x >> 6;
-    // ring bookkeeping of this wave in LDS: unit index, its sample count, paths still running
-    uint32_t* rmeta = (uint32_t*)(smem + staged) + (size_t)((ACCEL == 2) ? sv.stack2 : 0u) * PT_BLOCK + (size_t)wave * RING_UNITS * 4;
+    // bookkeeping in LDS behind the stacks: per wave RING_UNITS x {tile, sample block, samples | flags, paths still running} and
+    // 8 words of job / ring state; per block the launch constants next_unit() reads
+    uint32_t* book = (uint32_t*)(smem + staged) + (size_t)((ACCEL == 2) ? sv.stack2 : 0u) * PT_BLOCK;
+    uint32_t* rmeta = book + (size_t)wave * RING_UNITS * 4;
+    uint32_t* wst = book + (size_t)(PT_BLOCK / 64) * RING_UNITS * 4 + (size_t)wave * 8;
+    int* cfg = (int*)(book + (size_t)(PT_BLOCK / 64) * (RING_UNITS * 4 + 8));
+    if (lane < 8) wst[lane] = (lane == 6) ? 1u : 0u;  // nothing in flight, no job yet, jobs left
+    if (threadIdx.x == 0) {
+        cfg[CFG_N_JOBS] = rk.n_units; cfg[CFG_TILES_OWNED] = rk.tiles_owned; cfg[CFG_JOB_UNITS] = rk.job_units;
+        cfg[CFG_SUBS_PER_TILE] = rk.subs_per_tile; cfg[CFG_WORLD] = rk.world; cfg[CFG_RANK] = rk.rank; cfg[CFG_TILES_X] = rk.tiles_x;
+        cfg[CFG_S_BEGIN] = rk.s_begin; cfg[CFG_S_END] = rk.s_end; cfg[CFG_SUB_SPP] = rk.sub_spp; cfg[CFG_WIDTH] = rk.width;
+        cfg[CFG_HEIGHT] = rk.height;
+    }
+    __syncthreads();
     double* wring = ring + ((size_t)blockIdx.x * (PT_BLOCK / 64) + (size_t)wave) * RING_UNITS * UNIT_DOUBLES;
-    int r_head = 0, r_cnt = 0;  // oldest unit in flight, units in flight (wave-uniform)
 
     // current work unit (wave-uniform); `pool` paths, of which `next` have been handed out.  A wave does not drain a unit
-    // before it takes the next one: as soon as the pool is empty and a lane is free the next unit is fetched, so the lanes
+    // before it takes the next one: as soon as the pool is empty and a lane is free the next unit is started, so the lanes
     // still finishing long paths of the old unit run beside fresh paths of the new one (a finished path knows where its
     // sample goes: out_slot is per lane).  Only the end of the launch has a tail.
     int tx = 0, ty = 0, s0 = 0, pool = 0, next = 0, cur_slot = 0;
-    bool more_units = true;
+    bool finished = false;
 
     bool alive = false;
     D3 o = mk(0, 0, 0), d = mk(0, 0, 1), beta = mk(1, 1, 1), L = mk(0, 0, 0);
@@ -921,44 +1056,18 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
             // the regeneration code runs for the whole wave however few lanes need it: wait until REGEN_MIN lanes are free
             // (measured: 1 -> 2142, 4 -> 2174, 8 -> 2228, 12 -> 2210, 16 -> 2189, 24 -> 2094 Msamples/s)
             if ((int)__popcll(dead) < REGEN_MIN && dead != ~0ull) dead = 0ull;
-            // ---- fold completed units, oldest first: looked at only when the wave is about to fetch a unit (or has run out of them),
-            // i.e. about once per unit; out of line, so that its registers stay out of the hot loop ----
-            if (dead != 0ull && next >= pool && r_cnt > 0 &&
-                __hip_atomic_load(&rmeta[4 * r_head + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) {
-                const bool idle = dead == ~0ull && (r_cnt == RING_UNITS || !more_units);
-                const int folded = fold_units(rmeta, wring, accum, tickets, rk.tiles_owned, rk.s_begin == 0, r_head, r_cnt, idle, lane);
-                r_head += folded;
-                if (r_head >= RING_UNITS) r_head -= RING_UNITS;
-                r_cnt -= folded;
-            }
-            if (dead != 0ull && next >= pool && more_units && r_cnt < RING_UNITS) {
-                unsigned int unit = 0;
-                if (lane == 0) unit = atomicAdd(counter, 1u);
-                unit = __builtin_amdgcn_readfirstlane(unit);
-                if (unit >= (unsigned)rk.n_units) {
-                    more_units = false;  // every wave gets here: the counter only grows
-                } else {
-                    const int ult = (int)(unit % (unsigned)rk.tiles_owned);  // sample-major: all tiles' unit k before any tile's unit k+1
-                    const int sub_i = (int)(unit / (unsigned)rk.tiles_owned);
-                    const int tile = ult * rk.world + rk.rank;
-                    tx = tile % rk.tiles_x;
-                    ty = tile / rk.tiles_x;
-                    s0 = rk.s_begin + sub_i * rk.sub_spp;
-                    const int s1 = min(s0 + rk.sub_spp, rk.s_end);
-                    pool = (s1 - s0) * TILE_PIX;
+            // ---- pool exhausted: fold what is complete, start the next unit (next_unit, out of line) ----
+            if (dead != 0ull && next >= pool && !finished) {
+                const UnitInfo u = next_unit(wst, rmeta, cfg, wring, accum, tickets, counter, dead == ~0ull, lane);
+                if (u.pool > 0) {
+                    pool = u.pool;
                     next = 0;
-                    cur_slot = r_head + r_cnt;
-                    if (cur_slot >= RING_UNITS) cur_slot -= RING_UNITS;
-                    r_cnt++;
-                    if (lane == 0) {
-                        uint32_t* m = rmeta + 4 * cur_slot;
-                        m[0] = unit;
-                        m[1] = (uint32_t)(s1 - s0);
-                        // paths the unit will run: its pixels inside the image (edge tiles are partial) x its sample indices
-                        const int w_in = min(TILE_W, rk.width - tx * TILE_W), h_in = min(TILE_H, rk.height - ty * TILE_H);
-                        __hip_atomic_store(&m[2], (uint32_t)((s1 - s0) * w_in * h_in), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
+                    s0 = u.s0;
+                    tx = u.tx;
+                    ty = u.ty;
+                    cur_slot = u.cur_slot;
                 }
+                finished = u.finished != 0;
             }
             if (dead != 0ull && next < pool) {
                 int k = next + __popcll(dead & lanemask_lt);
@@ -986,7 +1095,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
                 }
             }
             if (__ballot(alive) == 0ull) {
-                if (next >= pool && !more_units && r_cnt == 0) break;
+                if (next >= pool && finished) break;
                 continue;
             }
             // ---- one path segment: sample_ray's loop body, photon_mapper.rs:335-362 ----
@@ -1025,7 +1134,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
                     dst[0] = L.x;
                     dst[1] = L.y;
                     dst[2] = L.z;
-                    atomicSub(rmeta + 4 * (out_slot >> 9) + 2, 1u);  // one path less running in that ring slot (UNIT_SPP * 64 = 512 per slot)
+                    atomicSub(rmeta + 4 * (out_slot >> 9) + 3, 1u);  // one path less running in that ring slot (UNIT_SPP * 64 = 512 per slot)
                     alive = false;
                 }
             }
@@ -1310,7 +1419,7 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
     if (kernel == 2 && !accel2_usable)
         throw RtError(RT_ERR_UNSUPPORTED, "kernel 2 requested but no usable accel for this scene/camera (unbounded item, depth overflow, stacks "
                                           "larger than LDS, negative t_min, or camera farther than 64x the scene extent); use kernel 0/1");
-    const size_t ring_meta = (size_t)(PT_BLOCK / 64) * RING_UNITS * 4 * sizeof(uint32_t);  // per-wave ring bookkeeping, behind the stacks
+    const size_t ring_meta = ((size_t)(PT_BLOCK / 64) * (RING_UNITS * 4 + 8) + CFG_WORDS) * sizeof(uint32_t);  // ring / job bookkeeping, behind the stacks
     const size_t stack_bytes = ((kernel == 2) ? stack2_bytes : 0) + ring_meta;
     const size_t hot_bytes = (kernel == 2) ? hot2 : hot1;
     const bool lds = hot_bytes > 0 && hot_bytes + stack_bytes <= lds_max && !tuning().no_lds;
@@ -1360,7 +1469,9 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
         rk.s_begin = s0; rk.s_end = s1;
         rk.sub_spp = plan.sub_spp;
         rk.subs_per_tile = (s1 - s0 + plan.sub_spp - 1) / plan.sub_spp;
-        int64_t units = plan.tiles_owned * rk.subs_per_tile;
+        rk.job_units = std::max(1, std::min(JOB_UNITS, rk.subs_per_tile));
+        const int jobs_per_tile = (rk.subs_per_tile + rk.job_units - 1) / rk.job_units;
+        int64_t units = plan.tiles_owned * jobs_per_tile;
         if (units > 0x7FFFFFFF) throw RtError(RT_ERR_UNSUPPORTED, "too many work units per launch");
         rk.n_units = (int)units;
         rk.tiles_x = plan.tiles_x; rk.rank = plan.rank; rk.world = plan.world;
@@ -1406,6 +1517,15 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
         st->scene_bytes = s.flat.blob.size();
         st->reserved[1] = (uint64_t)(ring_bytes + (size_t)n_pix * 3 * sizeof(double) + (size_t)plan.tiles_owned * sizeof(unsigned int));  // workspace bytes
     }
+#ifdef RT_FOLD_STATS
+    {
+        unsigned long long hs[8], z[8] = {0};
+        HIP_CHECK(hipMemcpyFromSymbol(hs, HIP_SYMBOL(g_fold_stats), sizeof(hs)));
+        fprintf(stderr, "[fold stats] calls %llu  cycles %llu (%.0f per call)  units folded %llu  ticket mismatches %llu  sleeps %llu\n", hs[0], hs[1],
+                hs[0] ? (double)hs[1] / (double)hs[0] : 0., hs[2], hs[3], hs[4]);
+        HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_fold_stats), z, sizeof(z)));
+    }
+#endif
     if (h_err) throw RtError(RT_ERR_UNIT_ZERO, "unitizing zero vector (device)");
 }
 

@@ -457,8 +457,8 @@ def test_degenerate_image_sizes_match_the_oracle(w, h):
 
 
 def test_render_workspace_is_small_and_can_be_released():
-    """samples live in per-wave unit rings (6 x 12 KB per resident wave) and are folded into the accumulator inside the
-    kernel: the device workspace does not grow with spp, stays far below 1 GiB for a 1200 x 1200 frame, and
+    """samples live in per-wave unit rings (10 x 12 KB per resident wave) and are folded into the accumulator inside the
+    kernel: the device workspace does not grow with spp, stays well below 1 GiB for a 1200 x 1200 frame, and
     rt_release_workspaces gives it back."""
     import rtamd
     world, cam, _ = _pair("scene_500.json")
@@ -466,7 +466,7 @@ def test_render_workspace_is_small_and_can_be_released():
     _, a = world.render(cam, width=1200, height=1200, spp=2, seed=1)
     _, b = world.render(cam, width=1200, height=1200, spp=24, seed=1)
     assert a["workspace_bytes"] == b["workspace_bytes"] and a["launches"] == b["launches"] == 1
-    assert b["workspace_bytes"] < 512 * 1024 * 1024 and b["reduce_ms"] == 0.0
+    assert b["workspace_bytes"] < 640 * 1024 * 1024 and b["reduce_ms"] == 0.0
     freed = rtamd.release_workspaces()
     assert freed >= b["workspace_bytes"]
     again, _ = world.render(cam, width=64, height=64, spp=2, seed=1)
@@ -535,3 +535,11 @@ def test_coordinates_beyond_2_pow_36_use_the_reference_order_kernel():
     exp, _ = o.render(48, 32, 4, seed=1)
     _assert_same(img, exp, "huge coordinates")
     assert img.max() > 0
+
+
+def test_render_from_the_stored_camera_frame_equals_render_from_the_constructor_arguments():
+    """rt_render_camera_frame (a host that owns a constructed Camera, camera.rs:12-21) == rt_render (Camera::new's arguments)."""
+    world, cam, _ = _pair("scene_10.json", aspect=1.5)
+    a, _ = world.render(cam, width=60, height=40, spp=5, seed=8)
+    b, _ = world.render_camera_frame(cam.frame(), width=60, height=40, spp=5, seed=8)
+    assert np.array_equal(a, b) and a.max() > 0

@@ -1,0 +1,34 @@
+#!/bin/bash
+# Round-2 profiles of the bench workload (headline: scene_500 1200x1200) and of C4, for profiles/r02/ and profiles/pt_kernel_model.json.
+# PMC passes are separate runs (SQ set, GRBM, FETCH_SIZE, WRITE_SIZE); --kernel-trace/--stats in their own run.
+set -o pipefail
+cd "$(dirname "$0")/.."
+export TMPDIR=/tmp
+OUT=gpurun_out/r02_prof; rm -rf $OUT; mkdir -p $OUT
+SPP=${SPP:-96}
+echo "== bench default" | tee $OUT/log.txt
+timeout -k 10 400 python3 bench.py > $OUT/bench_default.json 2>>$OUT/err.log || exit 1
+tail -c 600 $OUT/bench_default.json | tee -a $OUT/log.txt
+echo "== kernel trace of the same command" | tee -a $OUT/log.txt
+timeout -k 10 500 rocprofv3 --kernel-trace --stats -d $OUT/trace --output-format csv -- python3 bench.py --cpu-spp 0 > $OUT/bench_under_rocprof.json 2>>$OUT/err.log || exit 1
+for SET in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES" \
+           "GRBM_GUI_ACTIVE SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_IFETCH SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
+           "FETCH_SIZE" "WRITE_SIZE"; do
+  N=$(echo $SET | cut -d' ' -f1)
+  echo "== pmc $N" | tee -a $OUT/log.txt
+  timeout -k 10 400 rocprofv3 --pmc $SET -d $OUT/pmc_$N --output-format csv -- python3 bench.py --steps 1 --warmup 0 --spp $SPP --cpu-spp 0 > $OUT/pmc_$N.json 2>>$OUT/err.log || exit 1
+done
+python3 tools/pmc_summary.py $OUT/pmc_* > $OUT/pmc_summary_headline.csv
+python3 tools/make_pt_model.py --samples $((1200*1200*SPP)) --source "profiles/r02/pmc_summary_headline.csv (rocprofv3 --pmc, separate passes, bench.py --steps 1 --warmup 0 --spp $SPP --cpu-spp 0)" --out $OUT/pt_kernel_model.json $OUT/pmc_* | tee -a $OUT/log.txt
+echo "== C4" | tee -a $OUT/log.txt
+timeout -k 10 300 python3 tools/c4_bench.py 64 2>>$OUT/err.log | cut -c1-120 | tee -a $OUT/log.txt
+for SET in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum"; do
+  N=$(echo $SET | cut -d' ' -f1)
+  timeout -k 10 400 rocprofv3 --pmc $SET -d $OUT/c4pmc_$N --output-format csv -- python3 tools/c4_bench.py 16 > $OUT/c4pmc_$N.log 2>>$OUT/err.log || exit 1
+done
+python3 tools/pmc_summary.py $OUT/c4pmc_* > $OUT/pmc_summary_c4.csv
+python3 tools/make_pt_model.py --samples $((1200*1200*18)) --source "C4 (2 + 16 spp), profiles/r02/pmc_summary_c4.csv" --out $OUT/c4_model.json $OUT/c4pmc_* | tee -a $OUT/log.txt
+echo "== configs" | tee -a $OUT/log.txt
+timeout -k 10 600 python3 tools/config_bench.py > $OUT/config_bench.log 2>>$OUT/err.log || exit 1
+cp gpurun_out/config_bench.json $OUT/ 2>/dev/null
+tail -8 $OUT/config_bench.log | cut -c1-200
