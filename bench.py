@@ -18,7 +18,8 @@ single-GPU run.
 
 Extra objects on the JSON line (definitions and formulas: DESIGN.md s5):
   roofline          -- the bound that binds pt_kernel: VALU issue.  achieved = VALU wave-instructions/s,
-                       peak = SIMDs x clock / mean issue cycles per VALU instruction; lane_utilisation beside it.
+                       peak = SIMDs x clock / minimum issue cycles per instruction of the kernel's own mix (f32 2, f64 4,
+                       transcendental 8 / 16 cycles per wave64 on a SIMD-32); lane_utilisation beside it.
                        Per-sample instruction counts come from the PMC passes committed under profiles/ (model
                        file named in `source`); the kernel time is measured live (HIP events on the launch stream).
   roofline_contract -- SURVEY s8d: algorithmic bytes per sample in the REFERENCE's traversal order / kernel time
@@ -120,7 +121,7 @@ def roofline_objects(stats_acc, dt_kernel_s, clock_note=None):
     hbm = None
     if model:
         ipc = model["valu_insts_per_sample"]            # VALU wave-instructions per sample (SQ_INSTS_VALU / samples)
-        cyc = model["valu_issue_cycles_per_inst"]       # SQ_ACTIVE_INST_VALU * 4 / SQ_INSTS_VALU (f64 and 64-bit integer ops issue slower than f32)
+        cyc = model["valu_issue_cycles_per_inst"]       # minimum SIMD cycles per wave64 instruction of the kernel's own mix (f32 2, f64 4, transcendental 8 / 16, ...: tools/make_pt_model.py)
         clk = model["clock_ghz"]                        # GRBM_GUI_ACTIVE / 8 / kernel time of the PMC pass
         achieved = sps * ipc / 1e9
         peak = N_SIMDS * clk / cyc
@@ -128,6 +129,7 @@ def roofline_objects(stats_acc, dt_kernel_s, clock_note=None):
         roof.update({"achieved": achieved, "peak": peak, "frac": frac, "lane_utilisation": model["lane_utilisation"],
                      "useful_frac": frac * model["lane_utilisation"] if frac else None,
                      "valu_insts_per_sample": ipc, "valu_issue_cycles_per_inst": cyc, "clock_ghz": clk,
+                     "valu_mix_per_sample": model.get("valu_mix_per_sample"),
                      "source": "per-sample counts carried over from %s; kernel time measured in this run" % model.get("source", "profiles/")})
         if frac is not None and not (0.0 < frac <= 1.05):
             roof.update({"frac": None, "useful_frac": None,

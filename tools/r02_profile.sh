@@ -13,6 +13,8 @@ echo "== kernel trace of the same command" | tee -a $OUT/log.txt
 timeout -k 10 500 rocprofv3 --kernel-trace --stats -d $OUT/trace --output-format csv -- python3 bench.py --cpu-spp 0 > $OUT/bench_under_rocprof.json 2>>$OUT/err.log || exit 1
 for SET in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES" \
            "GRBM_GUI_ACTIVE SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_IFETCH SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
+           "SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64" \
+           "SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT" \
            "FETCH_SIZE" "WRITE_SIZE"; do
   N=$(echo $SET | cut -d' ' -f1)
   echo "== pmc $N" | tee -a $OUT/log.txt
@@ -22,7 +24,9 @@ python3 tools/pmc_summary.py $OUT/pmc_* > $OUT/pmc_summary_headline.csv
 python3 tools/make_pt_model.py --samples $((1200*1200*SPP)) --source "profiles/r02/pmc_summary_headline.csv (rocprofv3 --pmc, separate passes, bench.py --steps 1 --warmup 0 --spp $SPP --cpu-spp 0)" --out $OUT/pt_kernel_model.json $OUT/pmc_* | tee -a $OUT/log.txt
 echo "== C4" | tee -a $OUT/log.txt
 timeout -k 10 300 python3 tools/c4_bench.py 64 2>>$OUT/err.log | cut -c1-120 | tee -a $OUT/log.txt
-for SET in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum"; do
+for SET in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum" \
+           "SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64" \
+           "SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT"; do
   N=$(echo $SET | cut -d' ' -f1)
   timeout -k 10 400 rocprofv3 --pmc $SET -d $OUT/c4pmc_$N --output-format csv -- python3 tools/c4_bench.py 16 > $OUT/c4pmc_$N.log 2>>$OUT/err.log || exit 1
 done
