@@ -8,7 +8,8 @@ every render then prints to stderr
   PHASE  share of wave time (s_memtime) in regeneration / traversal (leaf part) / materialize+shade+store
   EV     per outer-loop iteration: how often the WAVE executed a block, how many LANES took part, utilisation
 for the inner-node step, leaf item tests, the rejection loops, the material branches and regeneration.
-Numbers of round 1 (scene_500): 26.9 inner steps per iteration at 33 % lane utilisation, 5.8 leaf items at 38 %.
+Numbers of round 1 (scene_500): 26.9 inner steps per iteration at 33 % lane utilisation, 5.8 leaf items at 38 %; round 2: DESIGN.md s5.
+(works on the ACCEL == 2 kernels; scenes that fall back to kernel 1 are not instrumented)
 """
 import os
 import re
@@ -66,11 +67,11 @@ rep("DEV bool shade(const Acc& A, const Rec& rec, D3 rdir, Rng& rng, D3& emitted
     "DEV bool shade(const Acc& A, const Rec& rec, D3 rdir, Rng& rng, D3& emitted, D3& att, D3& out_dir, bool& diffuse, int* err, unsigned long long* ph = nullptr) {")
 rep("    if (type != 2) rs = random_in_unit_sphere(rng);",
     "    if (ph && lamb) cntev(ph, 10);\n    if (ph && type == 1) cntev(ph, 11);\n    if (ph && type == 2) cntev(ph, 12);\n    if (type != 2) rs = random_in_unit_sphere(rng, ph ? ph + 9 : nullptr);")
-# pt_kernel (first occurrence of each pattern = pt_kernel, not the diagnostic kernel 3)
-rep("""    int lt = 0, tx = 0, ty = 0, s0 = 0, pool = 0, next = 0;
-    bool more_units = true;
-""", """    int lt = 0, tx = 0, ty = 0, s0 = 0, pool = 0, next = 0;
-    bool more_units = true;
+# pt_kernel
+rep("""    int tx = 0, ty = 0, s0 = 0, pool = 0, next = 0, cur_slot = 0;
+    bool finished = false;
+""", """    int tx = 0, ty = 0, s0 = 0, pool = 0, next = 0, cur_slot = 0;
+    bool finished = false;
     unsigned long long ph[32];
     for (int i = 0; i < 32; i++) ph[i] = 0;
 """)
@@ -87,7 +88,7 @@ rep("                        D3 rd = muls(random_in_unit_disk(rng), cam.lens_rad
 rep("""            // ---- one path segment: sample_ray's loop body, photon_mapper.rs:335-362 ----
             if (alive) {
                 Hit h = (ACCEL == 2) ? traverse2<GENERAL>(A, stk, stk_stride, o, d, rk.t_min, INFINITY)
-                                     : traverse<GENERAL>(A, o, d, rk.t_min, INFINITY);
+                                     : traverse<GENERAL, MEDIA>(A, o, d, rk.t_min, INFINITY, &rng);
                 bool done = true;""", """            unsigned long long t1 = PH_NOW();
             ph[0] += t1 - t0;
             ph[6] += 1;
@@ -109,20 +110,14 @@ rep("""                    Rec rec = materialize<GENERAL>(A, h, o, d, err);
                     unsigned long long t5 = PH_NOW();
                     ph[2] += t4 - t3;
                     ph[3] += t5 - t4;""")
-rep("""                if (done) {
-                    samples[out_idx] = L.x;
-                    samples[out_idx + 1] = L.y;
-                    samples[out_idx + 2] = L.z;
+rep("""                    atomicSub(rmeta + 4 * (out_slot >> 9) + 3, 1u);  // one path less running in that ring slot (UNIT_SPP * 64 = 512 per slot)
                     alive = false;
                 }
             }
         }
     }
 }
-""", """                if (done) {
-                    samples[out_idx] = L.x;
-                    samples[out_idx + 1] = L.y;
-                    samples[out_idx + 2] = L.z;
+""", """                    atomicSub(rmeta + 4 * (out_slot >> 9) + 3, 1u);
                     alive = false;
                 }
             }
@@ -135,7 +130,7 @@ rep("""                if (done) {
 """)
 rep("""    HIP_CHECK(hipStreamSynchronize(stream));
     if (st) {
-        double kms = 0, rms = 0;""", """    HIP_CHECK(hipStreamSynchronize(stream));
+        double kms = 0;""", """    HIP_CHECK(hipStreamSynchronize(stream));
     {
         unsigned long long hp[32] = {0};
         HIP_CHECK(hipMemcpyFromSymbol(hp, HIP_SYMBOL(g_phase), sizeof(hp)));
@@ -150,7 +145,7 @@ rep("""    HIP_CHECK(hipStreamSynchronize(stream));
         HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z)));
     }
     if (st) {
-        double kms = 0, rms = 0;""")
+        double kms = 0;""")
 open(DST, "w").write(s)
 os.makedirs(os.path.join(PKG, "variants"), exist_ok=True)
 hipcc = "/opt/rocm/bin/hipcc"
