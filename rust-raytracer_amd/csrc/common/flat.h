@@ -113,6 +113,9 @@ struct FlatView {  // by-value kernel argument
     uint32_t off_tripre2;     // accel: triangle records {pa, e0, e1, pad} in ITEM order (leaf-contiguous)
     uint32_t n_nodes2;        // Node2 count; the array is sorted by depth, so a prefix of it = the top of every BVH
     double origin_limit2;     // accel boxes are padded for ray origins with max-abs coordinate <= this (camera checked per render)
+    uint32_t n_inst2;            // instances (object-space BVHs under a Transform)
+    uint32_t max_inst_nodes2;    // Node2 count of the largest instance BVH
+    uint32_t inst_depth2;        // depth of the deepest instance BVH (stack entries a suspended object-space walk can hold)
 };
 
 }  // namespace rtamd

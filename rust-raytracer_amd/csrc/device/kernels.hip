@@ -442,8 +442,10 @@ DEV bool box32(float lox, float loy, float loz, float hix, float hiy, float hiz,
 // "while-while" form (all lanes descend inner nodes until each holds a leaf, then all test leaves).
 // Primitive tests, ranges and the tie rule are the reference's (see traverse<> above); only the order in which
 // primitives are met differs, which cannot change the result.
-template <bool GENERAL>
-DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, double t_min, double t_max) {
+// DEFER (cooperative kernel 5): an instance item is not entered; its index is recorded in *pend and its object-space BVH is
+// walked later by whichever wave serves the workgroup's request ring (coop_serve), starting from this walk's result.
+template <bool GENERAL, bool DEFER = false>
+DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, double t_min, double t_max, uint32_t* pend = nullptr) {
     D3 o = wo, d = wd;
     D3 inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
     double a = sqlen(d);
@@ -504,6 +506,8 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
                     } else if (kind == NK_TRI) {
                         double b1, b2;
                         got = tri_hit(A.tripre2 + 5 * (first + i), o, d, t_min, h.t, t, b1, b2);
+                    } else if (DEFER) {  // NK_INSTANCE, deferred (at most 32 instances, checked on the host)
+                        *pend |= 1u << pl;
                     } else {  // NK_INSTANCE: descend into its object-space BVH after the remaining items
                         enter = pl;
                     }
@@ -517,7 +521,7 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
                     r.best = ray32_best(t);
                 }
             }
-            if (GENERAL && enter != REF_DONE) {  // Transform::hit, transform.rs:153-156
+            if (GENERAL && !DEFER && enter != REF_DONE) {  // Transform::hit, transform.rs:153-156
                 uint2 in = A.inst2[enter];
                 const double* Minv = A.xforms + 32 * in.x;
                 o = xf_point(Minv, wo);
@@ -1142,6 +1146,705 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
     }
 }
 
+// ------------------------------------------------------- pt_kernel_coop (kernel 5) ---
+// Path tracer for scenes whose mesh instances are LARGE (object-space BVHs far outside LDS; BASELINE config C4).
+// On the plain kernel a third of a wave's rays reach the instance and walk 35..100 dependent steps while the other lanes
+// wait (lane utilisation 0.15, profiles/r02/pmc_summary_c4.csv).  Here those walks are re-packed ACROSS the waves of a
+// workgroup, and the workgroup has more paths in flight than lanes so that no lane waits:
+//   * a lane walks the world-space BVH to the end with instance items DEFERRED (traverse2<.., DEFER>: a bit per instance);
+//   * a path with a deferred instance is PARKED: its whole state plus the request -- object-space ray (Transform::hit's
+//     M^-1 * ray, transform.rs:153-156), best t and tie-break order so far, root of the instance's BVH -- goes to a slot of a
+//     per-workgroup pool in global memory (written through to L2), the slot id to the request ring RQ in LDS; the lane is free;
+//   * when a wave's worth of requests waits, a wave SERVES: 64 lanes take 64 requests, walk the object-space BVH and refill
+//     from RQ as lanes finish; when it runs thin with nothing to refill from it SUSPENDS the remaining walks (stack to the
+//     slot, id back to RQ) instead of dragging a sparse tail; answers go to the slot, its id to the answer ring AQ;
+//   * free lanes ADOPT answered paths right before shading and generate new paths right before the walk, so both phases run
+//     with (almost) every lane; the answer is merged with the reference's acceptance rule (smaller t, or equal t and later
+//     in reference order) -- what the inline walk does when it reaches the instance last.
+// What a path computes is unchanged: every primitive still sees the reference's f64 test with [t_min, best-so-far], the
+// closest hit does not depend on the order in which candidates are met (tie rule by `order`), RNG streams belong to the
+// path, and a finished path stores its sample into the ring slot of the wave that generated it (any wave of the workgroup
+// may finish it; the unit's LDS counter is decremented one iteration later, behind a drained store).  Bit-identical images.
+#ifndef COOP_POOL
+#define COOP_POOL 2048      // parked paths per workgroup (power of two)
+#endif
+#ifndef COOP_BATCH
+#define COOP_BATCH 64       // a wave starts serving once this many requests wait
+#endif
+#ifndef COOP_REFILL_TH
+#define COOP_REFILL_TH 48   // a serving wave goes back for more requests when fewer lanes than this still walk
+#endif
+#ifndef COOP_SUSPEND_TH
+#define COOP_SUSPEND_TH 20  // ... and suspends its walks when fewer than this are left and no request waits
+#endif
+static const int COOP_MAX_INST = 32;     // one pending bit per instance
+static const int COOP_STACK_MAX = 40;    // stack entries a suspended walk can save (scenes with deeper BVHs use kernel 2)
+static const int COOP_REC = 26 + COOP_STACK_MAX / 2;  // u64 per pool slot:
+//   request  [0..5] object-space ray o, d   [6] best t so far   [7] node to continue at (initially the instance's root) << 32 | order of the best hit so far
+//            [8] (xform of the best hit so far + 1) << 32 | depth << 8 | instance index
+//   answer   [9] t   [10] kind|payload << 32 | order     (order unchanged = nothing closer inside the instance)
+//   path     [11..16] o, d (world)   [17..19] beta   [20..22] L   [23] rng   [24] kind|payload of the best hit so far << 32 | pix_id
+//            [25] instances still deferred << 32 | stack entries saved << 16 | owner wave << 12 | sample slot in the owner's ring
+//   walk     [26..] the saved stack of a suspended walk (two entries per word); [9], [10] then hold the walk's best t / kp|order
+
+#ifdef RTAMD_COOP_STATS  // tools-only build (tools/build_variant.sh stats -DRTAMD_COOP_STATS): schedule counters of pt_kernel_coop
+__device__ unsigned long long g_coop_stats[16];
+struct CoopStats {
+    unsigned long long ev[6] = {0, 0, 0, 0, 0, 0}, ln[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = 0;  // shader-clock cycles per phase of the main loop
+};
+__device__ unsigned long long g_coop_time[8];
+#define COOP_TIME(i)                                                      \
+    do {                                                                  \
+        const unsigned long long t_now = __builtin_amdgcn_s_memtime();    \
+        cs.tm[i] += t_now - cs.t_last;                                    \
+        cs.t_last = t_now;                                                \
+    } while (0)
+#define COOP_STATS_ARG , CoopStats& cs
+#define COOP_STATS_PASS , cs
+#define COOP_STAT(i, lanes_mask)                                        \
+    do {                                                                \
+        cs.ev[i] += 1ull;                                               \
+        cs.ln[i] += (unsigned long long)__popcll(lanes_mask);           \
+    } while (0)
+#else
+#define COOP_STATS_ARG
+#define COOP_STATS_PASS
+#define COOP_STAT(i, lanes_mask) \
+    do {                         \
+    } while (0)
+#define COOP_TIME(i) \
+    do {             \
+    } while (0)
+#endif
+
+DEV D3 rcp3(D3 d) { return mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z); }
+struct CoopRing {  // multi-producer multi-consumer ring of slot ids in LDS; entries are id + 1, 0 = not yet written
+    volatile uint32_t* buf;
+    uint32_t* ht;  // {head, tail}: monotonic counters
+};
+DEV uint64_t ld_sc1(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }  // L2, never this CU's L1
+DEV uint32_t lds_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+DEV uint32_t ring_len(const CoopRing& R) { return lds_load(&R.ht[1]) - lds_load(&R.ht[0]); }
+// push the ids of the flagged lanes; `drain`: their records were just stored and must be in L2 before the ids are visible
+DEV void ring_push(const CoopRing& R, bool push, uint32_t id, int lane, uint64_t lanemask_lt, bool drain) {
+    const uint64_t m = __ballot(push);
+    if (m == 0ull) return;
+    const int leader = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(&R.ht[1], (uint32_t)__popcll(m));
+    base = __shfl(base, leader);
+    if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (push) R.buf[(base + (uint32_t)__popcll(m & lanemask_lt)) & (COOP_POOL - 1)] = id + 1u;
+}
+// pop up to popcount(want) ids; lanes of `want` that get one return it, the others return -1
+DEV int ring_pop(const CoopRing& R, uint64_t want, int lane, uint64_t lanemask_lt) {
+    if (want == 0ull) return -1;
+    uint32_t h0 = 0, k = 0;
+    if (lane == 0) {
+        for (;;) {
+            const uint32_t hd = lds_load(&R.ht[0]), tl = lds_load(&R.ht[1]);
+            if (hd == tl) break;
+            const uint32_t n = min((uint32_t)__popcll(want), tl - hd);
+            if (atomicCAS(&R.ht[0], hd, hd + n) == hd) {
+                h0 = hd;
+                k = n;
+                break;
+            }
+        }
+    }
+    h0 = __builtin_amdgcn_readfirstlane(h0);
+    k = __builtin_amdgcn_readfirstlane(k);
+    const int rank = __popcll(want & lanemask_lt);
+    int id = -1;
+    if (((want >> lane) & 1ull) != 0ull && rank < (int)k) {
+        const uint32_t slot = (h0 + (uint32_t)rank) & (COOP_POOL - 1);
+        uint32_t v;
+        do { v = R.buf[slot]; } while (v == 0u);  // its producer reserved the slot and writes it within a few instructions
+        R.buf[slot] = 0u;
+        id = (int)v - 1;
+    }
+    return id;
+}
+
+struct CoopLds {
+    CoopRing rq, aq, fq;  // requests, answers, free pool slots
+    uint32_t* n_parked;   // paths currently in the pool
+};
+
+// One while-while pass of the object-space walk for the lanes with `act`: descend to a leaf, test its items (traverse2's
+// node and leaf steps; no instances below an instance).  cur == REF_DONE afterwards means the walk is complete.
+DEV void blas_pass(const Acc& A, bool act, uint32_t* stk, const int stride, D3 o, D3 d, double a, double t_min, Ray32& r, double& ht, int& hnode,
+                   uint32_t& hkp, uint32_t& cur, int& sp, int* err) {
+    while (act && (cur >> REF_TAG_SHIFT) == 0u) {  // inner node: both children, conservative f32 boxes
+        float4 q0, q1, q2, q3;
+        if (cur < A.n2_top_count) {
+            const float4* p = A.n2_top + NODE2_F4 * cur;
+            q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
+        } else {
+            const float4* p = A.n2 + NODE2_F4 * cur;
+            q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
+        }
+        float e0, e1;
+        const bool h0 = box32(q0.x, q0.z, q1.x, q1.z, q2.x, q2.z, r, e0);
+        const bool h1 = box32(q0.y, q0.w, q1.y, q1.w, q2.y, q2.w, r, e1);
+        const uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
+        if (h0 && h1) {
+            const bool swap = e1 < e0;
+            stk[sp] = swap ? c0 : c1;
+            sp += stride;
+            cur = swap ? c1 : c0;
+        } else if (h0) {
+            cur = c0;
+        } else if (h1) {
+            cur = c1;
+        } else if (sp > 0) {
+            sp -= stride;
+            cur = stk[sp];
+        } else {
+            cur = REF_DONE;
+        }
+    }
+    if (act && cur != REF_DONE) {  // leaf: the reference's f64 primitive tests (tie rule as in traverse2)
+        const uint32_t first = cur & REF_LEAF_FIRST_MASK, cnt = ((cur >> REF_LEAF_COUNT_SHIFT) & 7u) + 1u;
+        for (uint32_t i = 0; i < cnt; i++) {
+            const uint2 it = A.items2[first + i];
+            const uint32_t kind = it.x & NK_MASK, pl = it.x >> NK_BITS;
+            double t = 0.;
+            bool got = false;
+            if (kind == NK_SPHERE) {
+                got = sphere_hit(A.spheres + 2 * pl, o, d, a, t_min, ht, t);
+            } else if (kind == NK_RECT_YZ || kind == NK_RECT_XZ || kind == NK_RECT_XY) {
+                got = rect_hit(A.rects + 3 * pl, (int)kind - (int)NK_RECT_YZ, o, d, t_min, ht, t);
+            } else if (kind == NK_TRI) {
+                double b1, b2;
+                got = tri_hit(A.tripre2 + 5 * (first + i), o, d, t_min, ht, t, b1, b2);
+            } else {
+                atomicOr(err, 2);  // an instance below an instance: flatten.cpp refuses such scenes
+            }
+            if (got && (t < ht || (int)it.y > hnode || !(t == t))) {
+                ht = t;
+                hnode = (int)it.y;
+                hkp = it.x;
+                r.best = ray32_best(t);
+            }
+        }
+        if (sp > 0) {
+            sp -= stride;
+            cur = stk[sp];
+        } else {
+            cur = REF_DONE;
+        }
+    }
+}
+
+
+// Out-of-line pieces of pt_kernel_coop get what they need from a block in LDS (written once per workgroup): a call passes
+// arguments in VGPRs, these are wave-uniform and belong in SGPRs, and the pointers keep their address spaces this way.
+struct CoopArgs {
+    const char* base;  // scene blob (global)
+    uint64_t* pool;    // this workgroup's parked-path records
+    int* err;
+    double t_min;
+    uint32_t off_n2, off_items2, off_tripre2, off_spheres, off_rects, off_inst2, off_xforms, n_top;
+    uint32_t lds_top, lds_coop;  // byte offsets of the Node2 cache and of the rings within the workgroup's LDS
+};
+#define AS_GLOBAL(T, p) ((T*)(__attribute__((address_space(1))) T*)(p))
+#define AS_LDS(T, p) ((T*)(__attribute__((address_space(3))) T*)(p))
+DEV uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+DEV uint64_t rfl64(uint64_t v) { return ((uint64_t)rfl((uint32_t)(v >> 32)) << 32) | (uint64_t)rfl((uint32_t)v); }
+struct CoopCtx {
+    Acc A;  // only the fields the object-space walk reads
+    CoopLds C;
+    uint64_t* pool;
+    int* err;
+    double t_min;
+};
+DEV CoopCtx coop_ctx(const CoopArgs* args_generic, char* lds0_generic) {  // lds0: start of the workgroup's dynamic LDS
+    const CoopArgs* ga = AS_LDS(const CoopArgs, args_generic);
+    char* lds0 = AS_LDS(char, lds0_generic);
+    CoopCtx X;
+    const char* base = AS_GLOBAL(const char, (const char*)rfl64((uint64_t)ga->base));
+    X.pool = AS_GLOBAL(uint64_t, (uint64_t*)rfl64((uint64_t)ga->pool));
+    X.err = AS_GLOBAL(int, (int*)rfl64((uint64_t)ga->err));
+    X.t_min = __longlong_as_double((long long)rfl64((uint64_t)__double_as_longlong(ga->t_min)));
+    X.A.n2 = (const float4*)(base + rfl(ga->off_n2));
+    X.A.items2 = (const uint2*)(base + rfl(ga->off_items2));
+    X.A.tripre2 = (const double2*)(base + rfl(ga->off_tripre2));
+    X.A.spheres = (const double2*)(base + rfl(ga->off_spheres));
+    X.A.rects = (const double2*)(base + rfl(ga->off_rects));
+    X.A.inst2 = (const uint2*)(base + rfl(ga->off_inst2));
+    X.A.xforms = (const double*)(base + rfl(ga->off_xforms));
+    X.A.n2_top = (const float4*)(lds0 + rfl(ga->lds_top));
+    X.A.n2_top_count = rfl(ga->n_top);
+    uint32_t* cb = (uint32_t*)(lds0 + rfl(ga->lds_coop));
+    X.C.rq.buf = cb;
+    X.C.aq.buf = cb + COOP_POOL;
+    X.C.fq.buf = cb + 2 * COOP_POOL;
+    uint32_t* cnt = cb + 3 * COOP_POOL;
+    X.C.rq.ht = cnt;
+    X.C.aq.ht = cnt + 2;
+    X.C.fq.ht = cnt + 4;
+    X.C.n_parked = cnt + 6;
+    return X;
+}
+
+// Serve the request ring with this wave: walk, refill, suspend the tail.  `may_suspend`: the wave has other work to go back to.
+// Out of line: the caller's paths stay in callee-saved registers (saved once per call) instead of squeezing the walk's loop.
+__device__ __attribute__((noinline)) void coop_serve(const CoopArgs* args, char* lds0, uint32_t* stk_generic, bool may_suspend COOP_STATS_ARG) {
+    const CoopCtx X = coop_ctx(args, lds0);
+    const CoopLds& C = X.C;
+    const Acc& A = X.A;
+    uint64_t* pool = X.pool;
+    int* err = X.err;
+    const double t_min = X.t_min;
+    uint32_t* stk = AS_LDS(uint32_t, stk_generic);
+    const int stride = PT_BLOCK;
+    const int lane = (int)(threadIdx.x & 63u);
+    const uint64_t lanemask_lt = (1ull << lane) - 1ull;
+    may_suspend = __ballot(may_suspend) != 0ull;
+    int rid = -1;
+    D3 o = mk(0, 0, 0), d = mk(0, 0, 1);
+    double a = 1.;
+    Ray32 r = make_ray32(o, mk(1, 1, 1), t_min, 0.);
+    double ht = 0.;
+    int hnode = -1;
+    uint32_t hkp = 0, cur = REF_DONE;
+    int sp = 0;
+    for (;;) {
+        // ---- refill: idle lanes take requests (fresh ones start at the instance's root, suspended ones where they stopped) ----
+        const int got = ring_pop(C.rq, __ballot(rid < 0), lane, lanemask_lt);
+        if (got >= 0) {
+            rid = got;
+            const uint64_t* q = pool + (size_t)COOP_REC * (size_t)rid;
+            o = mk(__longlong_as_double(ld_sc1(q + 0)), __longlong_as_double(ld_sc1(q + 1)), __longlong_as_double(ld_sc1(q + 2)));
+            d = mk(__longlong_as_double(ld_sc1(q + 3)), __longlong_as_double(ld_sc1(q + 4)), __longlong_as_double(ld_sc1(q + 5)));
+            const uint64_t w7 = ld_sc1(q + 7), w25 = ld_sc1(q + 25);
+            cur = (uint32_t)(w7 >> 32);
+            const int n_saved = (int)((w25 >> 16) & 0xffffu);
+            a = sqlen(d);
+            if (n_saved == 0) {  // fresh request
+                ht = __longlong_as_double(ld_sc1(q + 6));
+                hnode = (int)(uint32_t)w7;
+                hkp = 0u;
+                sp = 0;
+            } else {  // suspended walk: best hit so far in [9], [10]; the stack comes back into this lane's LDS stack
+                ht = __longlong_as_double(ld_sc1(q + 9));
+                const uint64_t w10 = ld_sc1(q + 10);
+                hnode = (int)(uint32_t)w10;
+                hkp = (uint32_t)(w10 >> 32);
+                const int n = n_saved - 1;  // saved count is biased by one so that an empty stack still marks "suspended"
+                for (int i = 0; i < n; i += 2) {
+                    const uint64_t w = ld_sc1(q + 26 + (i >> 1));
+                    stk[i * stride] = (uint32_t)w;
+                    if (i + 1 < n) stk[(i + 1) * stride] = (uint32_t)(w >> 32);
+                }
+                sp = n * stride;
+            }
+            r = make_ray32(o, rcp3(d), t_min, ht);
+        }
+        if (__ballot(rid >= 0) == 0ull) return;
+        COOP_STAT(0, __ballot(rid >= 0));  // serve rounds: lanes holding a request at the start of a round
+        bool thin = false;
+        for (;;) {
+            COOP_STAT(1, __ballot(rid >= 0));  // serve passes: busy lanes
+            blas_pass(A, rid >= 0, stk, stride, o, d, a, t_min, r, ht, hnode, hkp, cur, sp, err);
+            const bool fin = rid >= 0 && cur == REF_DONE;
+            if (fin) {
+                uint64_t* w = pool + (size_t)COOP_REC * (size_t)rid + 9;
+                w[0] = __double_as_longlong(ht);
+                w[1] = ((uint64_t)hkp << 32) | (uint64_t)(uint32_t)hnode;
+            }
+            ring_push(C.aq, fin, (uint32_t)rid, lane, lanemask_lt, true);
+            if (fin) rid = -1;
+            const int busy = __popcll(__ballot(rid >= 0));
+            if (busy == 0) break;
+            if (busy < COOP_REFILL_TH) {
+                if (ring_len(C.rq) != 0u) break;  // more requests wait: refill the idle lanes
+                if (may_suspend && busy < COOP_SUSPEND_TH) {
+                    thin = true;
+                    break;
+                }
+            }
+        }
+        if (thin) {  // hand the remaining walks back: a denser batch will continue them
+            const bool sus = rid >= 0;
+            COOP_STAT(4, __ballot(sus));
+            if (sus) {
+                uint64_t* q = pool + (size_t)COOP_REC * (size_t)rid;
+                const int n = sp / stride;
+                q[7] = ((uint64_t)cur << 32) | (uint64_t)(uint32_t)ld_sc1(q + 7);  // low half: the request's original best order stays for the adopter
+                q[9] = __double_as_longlong(ht);
+                q[10] = ((uint64_t)hkp << 32) | (uint64_t)(uint32_t)hnode;
+                for (int i = 0; i < n; i += 2) {
+                    const uint64_t lo = stk[i * stride], hi = (i + 1 < n) ? stk[(i + 1) * stride] : 0u;
+                    q[26 + (i >> 1)] = lo | (hi << 32);
+                }
+                const uint64_t w25 = ld_sc1(q + 25);
+                q[25] = (w25 & ~(0xffffull << 16)) | ((uint64_t)(n + 1) << 16);
+            }
+            ring_push(C.rq, sus, (uint32_t)rid, lane, lanemask_lt, true);
+            return;
+        }
+    }
+}
+
+// A path whose deferred instances cannot be parked (pool exhausted; rare): walk them here, as the plain kernel would.
+__device__ __attribute__((noinline)) Hit coop_walk_inline(const CoopArgs* args, char* lds0, uint32_t* stk_generic, D3 o, D3 d, Hit h, uint32_t pend) {
+    const CoopCtx X = coop_ctx(args, lds0);
+    const Acc& A = X.A;
+    uint32_t* stk = AS_LDS(uint32_t, stk_generic);
+    while (pend != 0u) {
+        const uint32_t ni = (uint32_t)(__ffs((int)pend) - 1);
+        pend &= pend - 1u;
+        const uint2 in = A.inst2[ni];
+        const double* Minv = A.xforms + 32 * in.x;
+        const D3 oo = xf_point(Minv, o), dd = xf_dir(Minv, d);
+        const double a = sqlen(dd);
+        Ray32 r = make_ray32(oo, rcp3(dd), X.t_min, h.t);
+        double ht = h.t;
+        int hnode = h.node, sp = 0;
+        uint32_t hkp = 0u, cur = in.y;
+        while (cur != REF_DONE) blas_pass(A, true, stk, PT_BLOCK, oo, dd, a, X.t_min, r, ht, hnode, hkp, cur, sp, X.err);
+        if (hnode != h.node) {
+            h.t = ht;
+            h.node = hnode;
+            h.kp = hkp;
+            h.xf = (int)in.x;
+        }
+    }
+    return h;
+}
+
+template <int INTEG>
+__global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam, RenderK rk, double* __restrict__ ring, double* accum,
+                                                           unsigned int* tickets, unsigned int* __restrict__ counter, int* __restrict__ err, uint64_t* coop) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // LDS map: [top-of-BVH Node2 cache][stacks: stack2 x PT_BLOCK words][ring / job bookkeeping as in pt_kernel]
+    //          [RQ, AQ, FQ: COOP_POOL words each][8 counters][CoopArgs]          (the scene itself stays in L2 / HBM)
+    uint32_t staged = 0;
+    Acc A = make_acc(sv.base, sv.base, sv);
+    if (rk.n_top > 0) {
+        const uint4* src = (const uint4*)(sv.base + sv.off_n2);
+        uint4* dst = (uint4*)smem;
+        for (uint32_t i = threadIdx.x; i < (uint32_t)rk.n_top * NODE2_F4; i += blockDim.x) dst[i] = src[i];
+        A.n2_top = (const float4*)smem;
+        A.n2_top_count = (uint32_t)rk.n_top;
+        staged = (uint32_t)rk.n_top * (uint32_t)sizeof(Node2);
+    }
+    uint32_t* stk = (uint32_t*)(smem + staged) + threadIdx.x;
+    const int stk_stride = (int)blockDim.x;
+    const int lane = threadIdx.x & 63;
+    const uint64_t lanemask_lt = (1ull << lane) - 1ull;
+    const int wave = threadIdx.x >> 6;
+    uint32_t* book = (uint32_t*)(smem + staged) + (size_t)sv.stack2 * PT_BLOCK;
+    uint32_t* rmeta = book + (size_t)wave * RING_UNITS * 4;
+    uint32_t* wst = book + (size_t)(PT_BLOCK / 64) * RING_UNITS * 4 + (size_t)wave * 8;
+    int* cfg = (int*)(book + (size_t)(PT_BLOCK / 64) * (RING_UNITS * 4 + 8));
+    uint32_t* coop_base = (uint32_t*)(cfg + CFG_WORDS);
+    CoopArgs* cargs = (CoopArgs*)(coop_base + 3 * COOP_POOL + 8);
+    CoopLds C;
+    C.rq.buf = coop_base;
+    C.aq.buf = coop_base + COOP_POOL;
+    C.fq.buf = coop_base + 2 * COOP_POOL;
+    uint32_t* cnt = coop_base + 3 * COOP_POOL;
+    C.rq.ht = cnt;
+    C.aq.ht = cnt + 2;
+    C.fq.ht = cnt + 4;
+    C.n_parked = cnt + 6;
+    for (uint32_t i = threadIdx.x; i < (uint32_t)COOP_POOL; i += blockDim.x) {
+        C.rq.buf[i] = 0u;
+        C.aq.buf[i] = 0u;
+        C.fq.buf[i] = i + 1u;  // every pool slot is free
+    }
+    if (threadIdx.x < 8) cnt[threadIdx.x] = (threadIdx.x == 5) ? (uint32_t)COOP_POOL : 0u;  // FQ tail = COOP_POOL
+    if (lane < 8) wst[lane] = (lane == 6) ? 1u : 0u;
+    if (threadIdx.x == 0) {
+        cfg[CFG_N_JOBS] = rk.n_units; cfg[CFG_TILES_OWNED] = rk.tiles_owned; cfg[CFG_JOB_UNITS] = rk.job_units;
+        cfg[CFG_SUBS_PER_TILE] = rk.subs_per_tile; cfg[CFG_WORLD] = rk.world; cfg[CFG_RANK] = rk.rank; cfg[CFG_TILES_X] = rk.tiles_x;
+        cfg[CFG_S_BEGIN] = rk.s_begin; cfg[CFG_S_END] = rk.s_end; cfg[CFG_SUB_SPP] = rk.sub_spp; cfg[CFG_WIDTH] = rk.width;
+        cfg[CFG_HEIGHT] = rk.height;
+        cargs->base = sv.base;
+        cargs->pool = coop + (size_t)blockIdx.x * COOP_POOL * COOP_REC;
+        cargs->err = err;
+        cargs->t_min = rk.t_min;
+        cargs->off_n2 = sv.off_n2; cargs->off_items2 = sv.off_items2; cargs->off_tripre2 = sv.off_tripre2;
+        cargs->off_spheres = sv.off_spheres; cargs->off_rects = sv.off_rects; cargs->off_inst2 = sv.off_inst2;
+        cargs->off_xforms = sv.off_xforms;
+        cargs->n_top = (uint32_t)rk.n_top;
+        cargs->lds_top = 0u;
+        cargs->lds_coop = (uint32_t)((char*)coop_base - smem);
+    }
+    __syncthreads();
+    double* bring = ring + (size_t)blockIdx.x * (PT_BLOCK / 64) * RING_UNITS * UNIT_DOUBLES;  // the workgroup's rings, wave-major
+    double* wring = bring + (size_t)wave * RING_UNITS * UNIT_DOUBLES;
+    uint64_t* pool_mem = coop + (size_t)blockIdx.x * COOP_POOL * COOP_REC;
+
+    int tx = 0, ty = 0, s0 = 0, pool = 0, next = 0, cur_slot = 0;
+    bool finished = false;
+
+    bool alive = false;   // the lane holds a path
+    bool ready = false;   // ... whose closest hit is known (shade next); otherwise it needs its world-space walk
+    D3 o = mk(0, 0, 0), d = mk(0, 0, 1), beta = mk(1, 1, 1), L = mk(0, 0, 0);
+    int depth = 0, pix_id = 0;
+    uint32_t out_slot = 0;  // owner wave << 12 | (ring slot * UNIT_SPP + sample within the unit) * 64 + pixel
+    uint32_t pend = 0u;
+    int dec_slot = -1;      // a finished path whose unit counter still has to be decremented (owner wave << 12 | slot index)
+    Rng rng;
+    rng.s = 0;
+    Hit h;
+    h.t = INFINITY; h.node = -1; h.xf = -1; h.kp = 0;
+#ifdef RTAMD_COOP_STATS
+    CoopStats cs;
+    cs.t_last = __builtin_amdgcn_s_memtime();
+#endif
+
+    for (;;) {
+        // ---- unit counters of the paths finished last iteration: their sample stores have completed by now ----
+        if (__ballot(dec_slot >= 0) != 0ull) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (dec_slot >= 0) {
+                atomicSub(book + (size_t)(dec_slot >> 12) * RING_UNITS * 4 + 4 * ((dec_slot & 0xfff) >> 9) + 3, 1u);
+                dec_slot = -1;
+            }
+        }
+        // ---- free lanes generate new paths right before the walk ----
+        uint64_t dead = __ballot(!alive);
+        if ((int)__popcll(dead) < REGEN_MIN && dead != ~0ull) dead = 0ull;
+        if (dead != 0ull && next >= pool && !finished) {
+            const UnitInfo u = next_unit(wst, rmeta, cfg, wring, accum, tickets, counter, false, lane);
+            if (u.pool > 0) {
+                pool = u.pool;
+                next = 0;
+                s0 = u.s0;
+                tx = u.tx;
+                ty = u.ty;
+                cur_slot = u.cur_slot;
+            }
+            finished = u.finished != 0;
+        }
+        if (dead != 0ull && next < pool) {
+            int k = next + __popcll(dead & lanemask_lt);
+            next = min(next + (int)__popcll(dead), pool);
+            if (!alive && k < pool) {
+                int pix = k & (TILE_PIX - 1), s = s0 + (k >> 6);
+                int x = tx * TILE_W + (pix & (TILE_W - 1)), y = ty * TILE_H + (pix >> 3);
+                if (x < rk.width && y < rk.height) {  // camera.rs:97-99 + Camera::get_ray camera.rs:57-64
+                    rng.seed_stream(rk.seed, (uint64_t)y * (uint64_t)rk.width + (uint64_t)x, (uint64_t)s);
+                    double u = ((double)x + rng.gen_f64()) / (double)(rk.width - 1);
+                    double v = ((double)y + rng.gen_f64()) / (double)(rk.height - 1);
+                    double stt = 1.0 - v;
+                    D3 rd = muls(random_in_unit_disk(rng), cam.lens_radius);
+                    D3 offset = add(muls(cam.u, rd.x), muls(cam.v, rd.y));
+                    o = add(cam.origin, offset);
+                    d = sub(sub(add(add(cam.llc, muls(cam.horizontal, u)), muls(cam.vertical, stt)), cam.origin), offset);
+                    beta = mk(1., 1., 1.);
+                    L = mk(0., 0., 0.);
+                    depth = rk.max_depth;
+                    pix_id = y * rk.width + x;
+                    out_slot = ((uint32_t)wave << 12) | (((uint32_t)cur_slot * (uint32_t)UNIT_SPP + (uint32_t)(k >> 6)) * (uint32_t)TILE_PIX + (uint32_t)pix);
+                    alive = true;
+                    ready = false;
+                }
+            }
+        }
+        COOP_TIME(0);
+        // ---- world-space walk of the lanes that start a segment, instances deferred ----
+        if (__ballot(alive && !ready) != 0ull) COOP_STAT(2, __ballot(alive && !ready));
+        if (alive && !ready) {
+            pend = 0u;
+            h = traverse2<true, true>(A, stk, stk_stride, o, d, rk.t_min, INFINITY, &pend);
+            if (pend == 0u) ready = true;
+        }
+        COOP_TIME(1);
+        // ---- park the paths with a deferred instance ----
+        {
+            const bool want = alive && !ready;
+            const uint64_t mw = __ballot(want);
+            if (mw != 0ull) {
+                const int id = ring_pop(C.fq, mw, lane, lanemask_lt);
+                const bool park = want && id >= 0;
+                if (park) {
+                    const uint32_t ni = (uint32_t)(__ffs((int)pend) - 1);
+                    pend &= pend - 1u;
+                    const uint2 in = A.inst2[ni];
+                    const double* Minv = A.xforms + 32 * in.x;
+                    const D3 oo = xf_point(Minv, o), dd = xf_dir(Minv, d);
+                    uint64_t* q = pool_mem + (size_t)COOP_REC * (size_t)id;
+                    q[0] = __double_as_longlong(oo.x); q[1] = __double_as_longlong(oo.y); q[2] = __double_as_longlong(oo.z);
+                    q[3] = __double_as_longlong(dd.x); q[4] = __double_as_longlong(dd.y); q[5] = __double_as_longlong(dd.z);
+                    q[6] = __double_as_longlong(h.t);
+                    q[7] = ((uint64_t)in.y << 32) | (uint64_t)(uint32_t)h.node;
+                    q[8] = ((uint64_t)(uint32_t)(h.xf + 1) << 32) | (uint64_t)(((uint32_t)depth << 8) | ni);
+                    q[11] = __double_as_longlong(o.x); q[12] = __double_as_longlong(o.y); q[13] = __double_as_longlong(o.z);
+                    q[14] = __double_as_longlong(d.x); q[15] = __double_as_longlong(d.y); q[16] = __double_as_longlong(d.z);
+                    q[17] = __double_as_longlong(beta.x); q[18] = __double_as_longlong(beta.y); q[19] = __double_as_longlong(beta.z);
+                    q[20] = __double_as_longlong(L.x); q[21] = __double_as_longlong(L.y); q[22] = __double_as_longlong(L.z);
+                    q[23] = rng.s;
+                    q[24] = ((uint64_t)h.kp << 32) | (uint64_t)(uint32_t)pix_id;
+                    q[25] = ((uint64_t)pend << 32) | (uint64_t)out_slot;  // saved-stack count (bits 16..31) = 0: a fresh request
+                    alive = false;
+                }
+                const uint64_t mp = __ballot(park);
+                if (mp != 0ull && lane == __ffsll((long long)mp) - 1) atomicAdd(C.n_parked, (uint32_t)__popcll(mp));
+                ring_push(C.rq, park, (uint32_t)id, lane, lanemask_lt, true);
+                // pool exhausted (rare): walk the deferred instances in this lane, sparsely, as the plain kernel does
+                if (__ballot(want && id < 0) != 0ull) {
+                    if (want && id < 0) {
+                        h = coop_walk_inline(cargs, smem, stk, o, d, h, pend);
+                        ready = true;
+                    }
+                }
+            }
+        }
+        COOP_TIME(2);
+        // ---- free lanes adopt answered paths right before shading ----
+        {
+            uint64_t fr = __ballot(!alive);
+            if ((int)__popcll(fr) < REGEN_MIN && fr != ~0ull) fr = 0ull;
+            if (fr != 0ull && ring_len(C.aq) != 0u) {
+                const int id = ring_pop(C.aq, fr, lane, lanemask_lt);
+                bool repost = false, freed = false;
+                if (id >= 0) {
+                    uint64_t* q = pool_mem + (size_t)COOP_REC * (size_t)id;
+                    const uint64_t w8 = ld_sc1(q + 8), w10 = ld_sc1(q + 10), w25 = ld_sc1(q + 25);
+                    const uint32_t inst = (uint32_t)w8 & 0xffu;
+                    depth = (int)(((uint32_t)w8 >> 8) & 0xffffffu);
+                    h.t = __longlong_as_double(ld_sc1(q + 6));  // best hit before this instance: as posted
+                    h.node = (int)(uint32_t)ld_sc1(q + 7);
+                    h.xf = (int)(uint32_t)(w8 >> 32) - 1;
+                    h.kp = (uint32_t)(ld_sc1(q + 24) >> 32);
+                    if ((int)(uint32_t)w10 != h.node) {  // the walk accepted a candidate of this instance
+                        h.t = __longlong_as_double(ld_sc1(q + 9));
+                        h.node = (int)(uint32_t)w10;
+                        h.kp = (uint32_t)(w10 >> 32);
+                        h.xf = (int)A.inst2[inst].x;
+                    }
+                    pend = (uint32_t)(w25 >> 32);
+                    out_slot = (uint32_t)w25 & 0xffffu;
+                    o = mk(__longlong_as_double(ld_sc1(q + 11)), __longlong_as_double(ld_sc1(q + 12)), __longlong_as_double(ld_sc1(q + 13)));
+                    d = mk(__longlong_as_double(ld_sc1(q + 14)), __longlong_as_double(ld_sc1(q + 15)), __longlong_as_double(ld_sc1(q + 16)));
+                    if (pend != 0u) {  // next deferred instance of the same segment: the path stays parked, new request
+                        const uint32_t ni = (uint32_t)(__ffs((int)pend) - 1);
+                        pend &= pend - 1u;
+                        const uint2 in = A.inst2[ni];
+                        const double* Minv = A.xforms + 32 * in.x;
+                        const D3 oo = xf_point(Minv, o), dd = xf_dir(Minv, d);
+                        q[0] = __double_as_longlong(oo.x); q[1] = __double_as_longlong(oo.y); q[2] = __double_as_longlong(oo.z);
+                        q[3] = __double_as_longlong(dd.x); q[4] = __double_as_longlong(dd.y); q[5] = __double_as_longlong(dd.z);
+                        q[6] = __double_as_longlong(h.t);
+                        q[7] = ((uint64_t)in.y << 32) | (uint64_t)(uint32_t)h.node;
+                        q[8] = ((uint64_t)(uint32_t)(h.xf + 1) << 32) | (uint64_t)(((uint32_t)depth << 8) | ni);
+                        const uint64_t w24 = ld_sc1(q + 24);
+                        q[24] = ((uint64_t)h.kp << 32) | (uint64_t)(uint32_t)w24;
+                        q[25] = ((uint64_t)pend << 32) | (uint64_t)out_slot;
+                        repost = true;
+                    } else {
+                        beta = mk(__longlong_as_double(ld_sc1(q + 17)), __longlong_as_double(ld_sc1(q + 18)), __longlong_as_double(ld_sc1(q + 19)));
+                        L = mk(__longlong_as_double(ld_sc1(q + 20)), __longlong_as_double(ld_sc1(q + 21)), __longlong_as_double(ld_sc1(q + 22)));
+                        rng.s = ld_sc1(q + 23);
+                        pix_id = (int)(uint32_t)ld_sc1(q + 24);
+                        alive = true;
+                        ready = true;
+                        freed = true;
+                    }
+                }
+                ring_push(C.rq, repost, (uint32_t)id, lane, lanemask_lt, true);
+                {
+                    const uint64_t mf = __ballot(freed);
+                    if (mf != 0ull) {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the slot's loads have returned before it can be reused
+                        if (lane == __ffsll((long long)mf) - 1) atomicSub(C.n_parked, (uint32_t)__popcll(mf));
+                    }
+                    ring_push(C.fq, freed, (uint32_t)id, lane, lanemask_lt, false);
+                }
+            }
+        }
+        COOP_TIME(3);
+        // ---- shade: sample_ray's loop body after World::hit, photon_mapper.rs:336-362 ----
+        if (__ballot(alive && ready) != 0ull) COOP_STAT(3, __ballot(alive && ready));
+        if (alive && ready) {
+            bool done = true;
+            if (h.node >= 0 && depth > 0) {
+                depth -= 1;
+                Rec rec = materialize<true>(A, h, o, d, err);
+                D3 emitted, att, ndir;
+                bool diffuse;
+                bool scattered = shade(A, rec, d, rng, emitted, att, ndir, diffuse, err);
+                L = add(L, elemul(beta, emitted));
+                if (scattered) {
+                    bool go = true;
+                    if (INTEG == 2 && diffuse) {
+                        const double* e = rk.sppm_est + 6 * (size_t)pix_id;
+                        L = add(L, elemul(beta, mk(e[0], e[1], e[2])));
+                        L = add(L, elemul(beta, mk(e[3], e[4], e[5])));
+                        go = false;
+                    } else if (INTEG == 1 && diffuse) {
+                        go = mixture_step(A, rec, rng, att, beta, ndir, err);
+                    } else {
+                        beta = elemul(beta, att);
+                    }
+                    if (go) {
+                        o = rec.p;
+                        d = ndir;
+                        done = false;
+                    }
+                }
+            }
+            ready = false;
+            if (done) {  // into the ring slot of the wave that generated the path; its unit counter moves next iteration
+                double* dst = bring + (size_t)(out_slot >> 12) * RING_UNITS * UNIT_DOUBLES + 3 * (size_t)(out_slot & 0xfffu);
+                dst[0] = L.x;
+                dst[1] = L.y;
+                dst[2] = L.z;
+                dec_slot = (int)out_slot;
+                alive = false;
+            }
+        }
+        COOP_TIME(4);
+        // ---- serve: a wave's worth of requests waits ----
+        if (ring_len(C.rq) >= (uint32_t)COOP_BATCH) coop_serve(cargs, smem, stk, true COOP_STATS_PASS);
+        COOP_TIME(5);
+        // ---- nothing in the lanes, nothing to adopt, no path to generate: fold / fetch, else serve whatever waits, else leave ----
+        if (__ballot(alive) == 0ull && next >= pool && ring_len(C.aq) == 0u && __ballot(dec_slot >= 0) == 0ull) {
+            bool got_unit = false;
+            if (!finished) {  // units still running somewhere (parked, or adopted by other waves)
+                const UnitInfo u = next_unit(wst, rmeta, cfg, wring, accum, tickets, counter, false, lane);
+                if (u.pool > 0) {
+                    pool = u.pool;
+                    next = 0;
+                    s0 = u.s0;
+                    tx = u.tx;
+                    ty = u.ty;
+                    cur_slot = u.cur_slot;
+                    got_unit = true;
+                }
+                finished = u.finished != 0;
+            }
+            if (!got_unit) {
+                if (ring_len(C.rq) != 0u) {
+                    coop_serve(cargs, smem, stk, false COOP_STATS_PASS);
+                } else if (finished && lds_load(C.n_parked) == 0u) {
+                    break;
+                } else {
+                    COOP_STAT(5, 0ull);
+                    __builtin_amdgcn_s_sleep(8);  // other waves hold what this one waits for
+                }
+            }
+        }
+        COOP_TIME(6);
+    }
+#ifdef RTAMD_COOP_STATS
+    if (lane == 0) {
+        for (int i = 0; i < 6; i++) {
+            atomicAdd(&g_coop_stats[2 * i], cs.ev[i]);
+            atomicAdd(&g_coop_stats[2 * i + 1], cs.ln[i]);
+        }
+        for (int i = 0; i < 8; i++) atomicAdd(&g_coop_time[i], cs.tm[i]);
+    }
+#endif
+}
+
 // pixel_color /= spp (camera.rs:102); pixels of edge tiles that fall outside the image are zeroed
 __global__ void finalize_kernel(const double* __restrict__ accum, double* __restrict__ tiles, int64_t n_pix, int spp, int width,
                                 int height, int tiles_x, int rank, int world) {
@@ -1316,8 +2019,8 @@ static const DevInfo& dev_info(int dev) {
 struct Workspace {
     int device = -1;
     bool busy = false;
-    void *ring = nullptr, *accum = nullptr, *tickets = nullptr, *small = nullptr;
-    size_t ring_bytes = 0, accum_bytes = 0, ticket_bytes = 0;
+    void *ring = nullptr, *accum = nullptr, *tickets = nullptr, *small = nullptr, *coop = nullptr;
+    size_t ring_bytes = 0, accum_bytes = 0, ticket_bytes = 0, coop_bytes = 0;
 };
 static std::vector<Workspace*> g_ws;
 static const size_t WS_SMALL = 1024;
@@ -1331,7 +2034,7 @@ static void grow(void*& p, size_t& have, size_t need) {
 }
 struct WorkspaceLease {
     Workspace* w = nullptr;
-    WorkspaceLease(int dev, size_t need_ring, size_t need_accum, size_t need_tickets) {
+    WorkspaceLease(int dev, size_t need_ring, size_t need_accum, size_t need_tickets, size_t need_coop = 0) {
         {
             std::lock_guard<std::mutex> g(g_mu);
             for (Workspace* c : g_ws)
@@ -1351,6 +2054,7 @@ struct WorkspaceLease {
             grow(w->ring, w->ring_bytes, need_ring);
             grow(w->accum, w->accum_bytes, need_accum);
             grow(w->tickets, w->ticket_bytes, need_tickets);
+            if (need_coop) grow(w->coop, w->coop_bytes, need_coop);
         } catch (...) {
             std::lock_guard<std::mutex> g(g_mu);
             w->busy = false;
@@ -1374,9 +2078,9 @@ size_t release_workspaces() {  // frees every idle workspace (all devices); retu
             continue;
         }
         (void)hipSetDevice(w->device);
-        for (void* p : {w->ring, w->accum, w->tickets, w->small})
+        for (void* p : {w->ring, w->accum, w->tickets, w->small, w->coop})
             if (p) (void)hipFree(p);
-        freed += w->ring_bytes + w->accum_bytes + w->ticket_bytes + WS_SMALL;
+        freed += w->ring_bytes + w->accum_bytes + w->ticket_bytes + w->coop_bytes + WS_SMALL;
         delete w;
         it = g_ws.erase(it);
     }
@@ -1385,6 +2089,7 @@ size_t release_workspaces() {  // frees every idle workspace (all devices); retu
 }
 
 typedef void (*pt_fn)(FlatView, CamK, RenderK, double*, double*, unsigned int*, unsigned int*, int*);
+typedef void (*pt_coop_fn)(FlatView, CamK, RenderK, double*, double*, unsigned int*, unsigned int*, int*, uint64_t*);
 
 template <int ACCEL>
 static pt_fn pick_pt_kernel(bool lds, bool general, int integ) {
@@ -1414,32 +2119,43 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
     const size_t hot1 = (size_t)view.stage_bytes, hot2 = (size_t)(view.stage2_end - view.stage2_begin);
     const bool accel2_usable = view.accel_ok && camera_ok && stack2_bytes <= lds_max;  // per-lane stacks live in LDS
     const bool media = (view.kinds_mask & (1u << NK_MEDIUM_BEGIN)) != 0;               // flatten.cpp: such scenes have no accel
+    // kernel 5 = kernel 2's BVH with the cooperative instance service (pt_kernel_coop): for scenes with LARGE mesh instances
+    const size_t coop_lds = (size_t)(3 * COOP_POOL + 8) * sizeof(uint32_t) + ((sizeof(CoopArgs) + 15) & ~size_t(15));  // three rings of pool-slot ids, counters, argument block
+    const bool coop_usable = accel2_usable && general && !media && view.n_inst2 >= 1 && view.n_inst2 <= (uint32_t)COOP_MAX_INST &&
+                             view.inst_depth2 <= (uint32_t)COOP_STACK_MAX && stack2_bytes + coop_lds <= lds_max && plan.max_depth < (1 << 24);
     int kernel = plan.kernel;
-    if (kernel == 0) kernel = accel2_usable ? 2 : 1;
-    if (kernel == 2 && !accel2_usable)
+    // auto: the cooperative kernel from ~8k object-space nodes per instance (measured on the Cornell box + torus instance, 64 spp:
+    // 6,400 triangles / 4.3k nodes 597 vs 606 Msamples/s for kernel 2, 25,600 / 17k 557 vs 508, 102,400 / 68k 508 vs 434, 409,600 437 vs 383)
+    if (kernel == 0) kernel = accel2_usable ? ((coop_usable && view.max_inst_nodes2 >= 8192u) ? 5 : 2) : 1;
+    if (kernel == 5 && !coop_usable)
+        throw RtError(RT_ERR_UNSUPPORTED, "kernel 5 (cooperative instance service) needs a usable accel and 1..32 mesh instances of depth <= 40");
+    if ((kernel == 2 || kernel == 5) && !accel2_usable)
         throw RtError(RT_ERR_UNSUPPORTED, "kernel 2 requested but no usable accel for this scene/camera (unbounded item, depth overflow, stacks "
                                           "larger than LDS, negative t_min, or camera farther than 64x the scene extent); use kernel 0/1");
     const size_t ring_meta = ((size_t)(PT_BLOCK / 64) * (RING_UNITS * 4 + 8) + CFG_WORDS) * sizeof(uint32_t);  // ring / job bookkeeping, behind the stacks
-    const size_t stack_bytes = ((kernel == 2) ? stack2_bytes : 0) + ring_meta;
-    const size_t hot_bytes = (kernel == 2) ? hot2 : hot1;
-    const bool lds = hot_bytes > 0 && hot_bytes + stack_bytes <= lds_max && !tuning().no_lds;
+    const size_t stack_bytes = ((kernel == 2 || kernel == 5) ? stack2_bytes : 0) + ring_meta + ((kernel == 5) ? coop_lds : 0);
+    const size_t hot_bytes = (kernel == 2 || kernel == 5) ? hot2 : hot1;
+    const bool lds = hot_bytes > 0 && hot_bytes + stack_bytes <= lds_max && !tuning().no_lds && kernel != 5;  // kernel 5: scene in L2/HBM always
     const int integ = plan.integrator;
     if (integ == 1 && view.n_lights == 0) throw RtError(RT_ERR_ARG, "integrator 1 (light importance sampling) needs rt_scene_set_lights");
     if (integ == 2 && !plan.sppm_est) throw RtError(RT_ERR_ARG, "integrator 2 (SPPM) is reached through rt_render_sppm");
     if (media && integ != 0)
         throw RtError(RT_ERR_UNSUPPORTED, "scenes with a ConstantMedium render with integrator 0 only (the medium's random draw is part of the "
                                           "reference-order walk; light sampling and SPPM have no volume events)");
-    pt_fn fn = (kernel == 2) ? pick_pt_kernel<2>(lds, general, integ) : pick_pt_kernel<1>(lds, general, integ);
+    pt_fn fn = (kernel == 1) ? pick_pt_kernel<1>(lds, general, integ) : pick_pt_kernel<2>(lds, general, integ);
+    pt_coop_fn fn_coop = nullptr;
+    if (kernel == 5)
+        fn_coop = (integ == 1) ? pt_kernel_coop<1> : (integ == 2) ? pt_kernel_coop<2> : pt_kernel_coop<0>;
     if (media) fn = lds ? pt_kernel<true, true, 1, 0, true> : pt_kernel<false, true, 1, 0, true>;
     // scene too large for LDS: spend what is left after the stacks on the shallowest BVH levels (the Node2 array is depth-sorted)
     int n_top = 0;
-    if (kernel == 2 && !lds && lds_max > stack_bytes) {
+    if ((kernel == 2 || kernel == 5) && !lds && lds_max > stack_bytes) {
         size_t room = (lds_max - stack_bytes) / sizeof(Node2);
         if (tuning().n_top >= 0) room = std::min<size_t>(room, (size_t)tuning().n_top);
         n_top = (int)std::min<size_t>(room, view.n_nodes2);
     }
     const size_t smem = (lds ? hot_bytes : (size_t)n_top * sizeof(Node2)) + stack_bytes;
-    const void* fptr = (const void*)fn;
+    const void* fptr = (kernel == 5) ? (const void*)fn_coop : (const void*)fn;
     if (smem > 48 * 1024) HIP_CHECK(hipFuncSetAttribute(fptr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     int blocks_per_cu = 0;
     HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, fptr, PT_BLOCK, smem));
@@ -1450,7 +2166,8 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
     // workspace: RING_UNITS unit buffers (12 KB) per resident wave -- independent of the image -- plus accumulator and tickets
     const size_t ring_bytes = (size_t)grid * (PT_BLOCK / 64) * RING_UNITS * UNIT_DOUBLES * sizeof(double);
     WorkspaceLease lease(dev, ring_bytes, std::max<size_t>(16, (size_t)n_pix * 3 * sizeof(double)),
-                         std::max<size_t>(16, (size_t)plan.tiles_owned * sizeof(unsigned int)));
+                         std::max<size_t>(16, (size_t)plan.tiles_owned * sizeof(unsigned int)),
+                         (kernel == 5) ? (size_t)grid * COOP_POOL * COOP_REC * sizeof(uint64_t) : 0);
     struct Ptr {
         void* p;
     };
@@ -1486,8 +2203,12 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
         hipEvent_t e0 = events.make(), e1 = events.make();
         HIP_CHECK(hipEventRecord(e0, stream));
         if (rk.n_units > 0) {
-            hipLaunchKernelGGL(fn, dim3(grid), dim3(PT_BLOCK), smem, stream, view, ck, rk, (double*)ringp.p, (double*)accum.p,
-                               (unsigned int*)tickets.p, (unsigned int*)counter.p, (int*)err.p);
+            if (kernel == 5)
+                hipLaunchKernelGGL(fn_coop, dim3(grid), dim3(PT_BLOCK), smem, stream, view, ck, rk, (double*)ringp.p, (double*)accum.p,
+                                   (unsigned int*)tickets.p, (unsigned int*)counter.p, (int*)err.p, (uint64_t*)lease.w->coop);
+            else
+                hipLaunchKernelGGL(fn, dim3(grid), dim3(PT_BLOCK), smem, stream, view, ck, rk, (double*)ringp.p, (double*)accum.p,
+                                   (unsigned int*)tickets.p, (unsigned int*)counter.p, (int*)err.p);
             HIP_CHECK(hipGetLastError());
         }
         HIP_CHECK(hipEventRecord(e1, stream));
@@ -1518,8 +2239,26 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
         st->grid_blocks = grid;
         st->spp_chunk = plan.spp_chunk;
         st->scene_bytes = s.flat.blob.size();
-        st->reserved[1] = (uint64_t)(ring_bytes + (size_t)n_pix * 3 * sizeof(double) + (size_t)plan.tiles_owned * sizeof(unsigned int));  // workspace bytes
+        st->reserved[1] = (uint64_t)(ring_bytes + (size_t)n_pix * 3 * sizeof(double) + (size_t)plan.tiles_owned * sizeof(unsigned int) +
+                                     ((kernel == 5) ? (size_t)grid * COOP_POOL * COOP_REC * sizeof(uint64_t) : 0));  // workspace bytes
     }
+#ifdef RTAMD_COOP_STATS
+    if (kernel == 5) {
+        unsigned long long hs[16], z[16] = {0};
+        HIP_CHECK(hipMemcpyFromSymbol(hs, HIP_SYMBOL(g_coop_stats), sizeof(hs)));
+        const char* names[6] = {"serve rounds (lanes at start)", "serve passes (busy lanes)", "walk phases (lanes)", "shade phases (lanes)", "suspensions (walks)", "idle sleeps"};
+        for (int i = 0; i < 6; i++)
+            fprintf(stderr, "[coop stats] %-32s %12llu  lanes %14llu  (%.1f per event)\n", names[i], hs[2 * i], hs[2 * i + 1],
+                    hs[2 * i] ? (double)hs[2 * i + 1] / (double)hs[2 * i] : 0.);
+        HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_coop_stats), z, sizeof(z)));
+        unsigned long long tm[8], tot = 0;
+        HIP_CHECK(hipMemcpyFromSymbol(tm, HIP_SYMBOL(g_coop_time), sizeof(tm)));
+        for (int i = 0; i < 8; i++) tot += tm[i];
+        const char* tn[7] = {"fold + regenerate", "world-space walk", "park", "adopt", "shade", "serve (batch)", "tail: serve rest / idle"};
+        for (int i = 0; i < 7; i++) fprintf(stderr, "[coop time] %-26s %5.1f %%\n", tn[i], tot ? 100. * (double)tm[i] / (double)tot : 0.);
+        HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_coop_time), z, sizeof(tm)));
+    }
+#endif
 #ifdef RT_FOLD_STATS
     {
         unsigned long long hs[8], z[8] = {0};

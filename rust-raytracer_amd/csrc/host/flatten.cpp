@@ -284,7 +284,7 @@ void flatten(rt_scene& s) {
     // ---- accel (kernel 2) ----
     AccelBuild ab;
     ab.ok = b.accel_ok;
-    uint32_t root2 = REF_DONE;
+    uint32_t root2 = REF_DONE, max_inst_nodes = 0, inst_depth = 0;
     double origin_limit = 0.;
     if (ab.ok && !b.actx[0].items.empty()) {
         // E_w: largest |coordinate| of the world items; boxes are padded so that rounding a ray origin with
@@ -313,7 +313,10 @@ void flatten(rt_scene& s) {
                 for (auto& it : c.items)  // hit points inside the instance also serve as origins of secondary rays (in world space only)
                     for (int a = 0; a < 3; a++) oo = std::fmax(oo, std::fmax(std::fabs(it.box.mn[a]), std::fabs(it.box.mx[a])));
                 if (!(oo < 68719476736.)) { ab.ok = false; break; }
+                const size_t nodes_before = ab.nodes.size();
                 uint32_t r = accel_build_bvh(ab, c.items, std::ldexp(oo, -22), depth_tlas + 1);
+                max_inst_nodes = std::max<uint32_t>(max_inst_nodes, (uint32_t)(ab.nodes.size() - nodes_before));
+                inst_depth = (uint32_t)std::max(1, ab.max_depth - depth_tlas + 1);  // bound for every instance built so far
                 ab.inst[2 * (i - 1)] = c.xform;
                 ab.inst[2 * (i - 1) + 1] = r;
             }
@@ -404,6 +407,9 @@ void flatten(rt_scene& s) {
     v.accel_ok = ab.ok ? 1u : 0u;
     v.root2 = root2;
     v.stack2 = (uint32_t)(ab.max_depth + 2);
+    v.n_inst2 = (uint32_t)(ab.inst.size() / 2);
+    v.max_inst_nodes2 = max_inst_nodes;
+    v.inst_depth2 = inst_depth;
     v.origin_limit2 = origin_limit;
     // cold part (read once per path segment, by the winning leaf only): always global
     v.off_sphere_mat = append(f.blob, b.sphere_mat);

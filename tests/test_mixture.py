@@ -96,6 +96,8 @@ def test_hip_cornell_mixture_bit_exact_and_unbiased():
     img, _ = w.render(cam, width=40, height=40, spp=8, seed=1, integrator=1)
     exp, _ = o.render(40, 40, 8, seed=1, integrator=1)
     assert np.array_equal(img, exp)
+    coop, st = w.render(cam, width=40, height=40, spp=8, seed=1, integrator=1, kernel=5)   # the mesh instance through the request queue
+    assert st["kernel_used"] == 5 and np.array_equal(coop, exp)
     # equality in expectation on the GPU at a sample count the oracle could not afford: 8 independent renders per
     # estimator give block means and their standard errors; the two estimators must agree within Monte-Carlo error
     def blocks(integrator, spp, seeds):

@@ -37,7 +37,7 @@ def test_oracle_sppm_needs_lights():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kernel", [1, 2])
+@pytest.mark.parametrize("kernel", [1, 2, 5])
 def test_hip_sppm_bit_exact_vs_oracle_cornell(kernel):
     import oracle
     import rtamd
