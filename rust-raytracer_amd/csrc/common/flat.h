@@ -116,6 +116,15 @@ struct FlatView {  // by-value kernel argument
     uint32_t n_inst2;            // instances (object-space BVHs under a Transform)
     uint32_t max_inst_nodes2;    // Node2 count of the largest instance BVH
     uint32_t inst_depth2;        // depth of the deepest instance BVH (stack entries a suspended object-space walk can hold)
+    uint32_t n_world_items2;     // items2[0 .. n_world_items2) are the world-space BVH's (its leaves are laid out first)
 };
+
+// Kernel 5 keeps the WORLD-level tables in LDS even though the scene as a whole does not fit: spheres, rects, transforms, the
+// instance table and the world-space BVH's items (the mesh data -- triangles, object-space nodes and items -- stays in L2 / HBM).
+constexpr uint32_t coop_a16(uint32_t x) { return (x + 15u) & ~15u; }
+constexpr uint32_t coop_world_bytes(const FlatView& v) {
+    return coop_a16(v.off_rects - v.off_spheres) + coop_a16(v.off_tris - v.off_rects) + coop_a16(v.stage_bytes - v.off_xforms) +
+           coop_a16(8u * v.n_inst2) + coop_a16(8u * v.n_world_items2);
+}
 
 }  // namespace rtamd

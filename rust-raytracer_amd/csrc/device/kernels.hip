@@ -1169,7 +1169,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
 #define COOP_POOL 2048      // parked paths per workgroup (power of two)
 #endif
 #ifndef COOP_BATCH
-#define COOP_BATCH 64       // a wave starts serving once this many requests wait
+#define COOP_BATCH 128      // a wave starts serving once this many requests wait (64: -2 %)
 #endif
 #ifndef COOP_REFILL_TH
 #define COOP_REFILL_TH 48   // a serving wave goes back for more requests when fewer lanes than this still walk
@@ -1179,13 +1179,26 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
 #endif
 static const int COOP_MAX_INST = 32;     // one pending bit per instance
 static const int COOP_STACK_MAX = 40;    // stack entries a suspended walk can save (scenes with deeper BVHs use kernel 2)
-static const int COOP_REC = 26 + COOP_STACK_MAX / 2;  // u64 per pool slot:
-//   request  [0..5] object-space ray o, d   [6] best t so far   [7] node to continue at (initially the instance's root) << 32 | order of the best hit so far
-//            [8] (xform of the best hit so far + 1) << 32 | depth << 8 | instance index
-//   answer   [9] t   [10] kind|payload << 32 | order     (order unchanged = nothing closer inside the instance)
-//   path     [11..16] o, d (world)   [17..19] beta   [20..22] L   [23] rng   [24] kind|payload of the best hit so far << 32 | pix_id
-//            [25] instances still deferred << 32 | stack entries saved << 16 | owner wave << 12 | sample slot in the owner's ring
-//   walk     [26..] the saved stack of a suspended walk (two entries per word); [9], [10] then hold the walk's best t / kp|order
+static const int COOP_REC = 20 + COOP_STACK_MAX / 2;  // u64 per pool slot, read and written in 16-byte units (two u64):
+//   unit 0..2  [0..5]  the segment's ray o, d in WORLD space (the serving lane applies the instance's M^-1: transform.rs:153-156)
+//   unit 3     [6] best t so far   [7] kind|payload of the best hit so far << 32 | its order          (as posted with the request)
+//   unit 4     [8] node to continue at (initially the instance's root) << 32 | xform of the best hit so far + 1
+//              [9] instances still deferred << 32 | stack entries saved + 1 (0: fresh request) << 24 | instance << 16 | sample slot
+//   unit 5     [10] t   [11] kind|payload << 32 | order      of the walk so far / of the answer (order unchanged = nothing closer inside)
+//   unit 6..9  [12..14] beta   [15..17] L   [18] rng   [19] depth << 32 | pix_id
+//   unit 10..  the saved stack of a suspended walk, four entries per unit
+// Records are only touched by waves of one workgroup, i.e. of one CU, whose L1 they share: plain loads and stores, ordered by
+// s_waitcnt vmcnt(0) before the slot id is published through LDS (workgroup-scope release / acquire on gfx950).
+typedef ulonglong2 U2;
+DEV U2 ld_unit(const uint64_t* rec, int unit) { return ((const U2*)rec)[unit]; }
+DEV void st_unit(uint64_t* rec, int unit, uint64_t a, uint64_t b) {
+    U2 v;
+    v.x = a;
+    v.y = b;
+    ((U2*)rec)[unit] = v;
+}
+DEV uint64_t dbits(double x) { return (uint64_t)__double_as_longlong(x); }
+DEV double bitsd(uint64_t x) { return __longlong_as_double((long long)x); }
 
 #ifdef RTAMD_COOP_STATS  // tools-only build (tools/build_variant.sh stats -DRTAMD_COOP_STATS): schedule counters of pt_kernel_coop
 __device__ unsigned long long g_coop_stats[16];
@@ -1223,7 +1236,6 @@ struct CoopRing {  // multi-producer multi-consumer ring of slot ids in LDS; ent
     volatile uint32_t* buf;
     uint32_t* ht;  // {head, tail}: monotonic counters
 };
-DEV uint64_t ld_sc1(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }  // L2, never this CU's L1
 DEV uint32_t lds_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 DEV uint32_t ring_len(const CoopRing& R) { return lds_load(&R.ht[1]) - lds_load(&R.ht[0]); }
 // push the ids of the flagged lanes; `drain`: their records were just stored and must be in L2 before the ids are visible
@@ -1348,6 +1360,7 @@ struct CoopArgs {
     double t_min;
     uint32_t off_n2, off_items2, off_tripre2, off_spheres, off_rects, off_inst2, off_xforms, n_top;
     uint32_t lds_top, lds_coop;  // byte offsets of the Node2 cache and of the rings within the workgroup's LDS
+    uint32_t lds_inst2, lds_xforms;  // ... and of the LDS copies of the instance table and the transforms
 };
 #define AS_GLOBAL(T, p) ((T*)(__attribute__((address_space(1))) T*)(p))
 #define AS_LDS(T, p) ((T*)(__attribute__((address_space(3))) T*)(p))
@@ -1373,8 +1386,8 @@ DEV CoopCtx coop_ctx(const CoopArgs* args_generic, char* lds0_generic) {  // lds
     X.A.tripre2 = (const double2*)(base + rfl(ga->off_tripre2));
     X.A.spheres = (const double2*)(base + rfl(ga->off_spheres));
     X.A.rects = (const double2*)(base + rfl(ga->off_rects));
-    X.A.inst2 = (const uint2*)(base + rfl(ga->off_inst2));
-    X.A.xforms = (const double*)(base + rfl(ga->off_xforms));
+    X.A.inst2 = (const uint2*)(lds0 + rfl(ga->lds_inst2));
+    X.A.xforms = (const double*)(lds0 + rfl(ga->lds_xforms));
     X.A.n2_top = (const float4*)(lds0 + rfl(ga->lds_top));
     X.A.n2_top_count = rfl(ga->n_top);
     uint32_t* cb = (uint32_t*)(lds0 + rfl(ga->lds_coop));
@@ -1417,27 +1430,32 @@ __device__ __attribute__((noinline)) void coop_serve(const CoopArgs* args, char*
         if (got >= 0) {
             rid = got;
             const uint64_t* q = pool + (size_t)COOP_REC * (size_t)rid;
-            o = mk(__longlong_as_double(ld_sc1(q + 0)), __longlong_as_double(ld_sc1(q + 1)), __longlong_as_double(ld_sc1(q + 2)));
-            d = mk(__longlong_as_double(ld_sc1(q + 3)), __longlong_as_double(ld_sc1(q + 4)), __longlong_as_double(ld_sc1(q + 5)));
-            const uint64_t w7 = ld_sc1(q + 7), w25 = ld_sc1(q + 25);
-            cur = (uint32_t)(w7 >> 32);
-            const int n_saved = (int)((w25 >> 16) & 0xffffu);
+            const U2 u0 = ld_unit(q, 0), u1 = ld_unit(q, 1), u2 = ld_unit(q, 2), u3 = ld_unit(q, 3), u4 = ld_unit(q, 4);
+            const uint32_t inst = (uint32_t)(u4.y >> 16) & 0xffu;
+            const int n_saved = (int)((u4.y >> 24) & 0xffu);
+            const double* Minv = A.xforms + 32 * A.inst2[inst].x;
+            const D3 wo = mk(bitsd(u0.x), bitsd(u0.y), bitsd(u1.x)), wd = mk(bitsd(u1.y), bitsd(u2.x), bitsd(u2.y));
+            o = xf_point(Minv, wo);
+            d = xf_dir(Minv, wd);
             a = sqlen(d);
+            cur = (uint32_t)(u4.x >> 32);
             if (n_saved == 0) {  // fresh request
-                ht = __longlong_as_double(ld_sc1(q + 6));
-                hnode = (int)(uint32_t)w7;
+                ht = bitsd(u3.x);
+                hnode = (int)(uint32_t)u3.y;
                 hkp = 0u;
                 sp = 0;
-            } else {  // suspended walk: best hit so far in [9], [10]; the stack comes back into this lane's LDS stack
-                ht = __longlong_as_double(ld_sc1(q + 9));
-                const uint64_t w10 = ld_sc1(q + 10);
-                hnode = (int)(uint32_t)w10;
-                hkp = (uint32_t)(w10 >> 32);
-                const int n = n_saved - 1;  // saved count is biased by one so that an empty stack still marks "suspended"
-                for (int i = 0; i < n; i += 2) {
-                    const uint64_t w = ld_sc1(q + 26 + (i >> 1));
-                    stk[i * stride] = (uint32_t)w;
-                    if (i + 1 < n) stk[(i + 1) * stride] = (uint32_t)(w >> 32);
+            } else {  // suspended walk: its best hit so far in unit 5; the stack comes back into this lane's LDS stack
+                const U2 u5 = ld_unit(q, 5);
+                ht = bitsd(u5.x);
+                hnode = (int)(uint32_t)u5.y;
+                hkp = (uint32_t)(u5.y >> 32);
+                const int n = n_saved - 1;
+                for (int i = 0; i < n; i += 4) {
+                    const U2 w = ld_unit(q, 10 + (i >> 2));
+                    stk[i * stride] = (uint32_t)w.x;
+                    if (i + 1 < n) stk[(i + 1) * stride] = (uint32_t)(w.x >> 32);
+                    if (i + 2 < n) stk[(i + 2) * stride] = (uint32_t)w.y;
+                    if (i + 3 < n) stk[(i + 3) * stride] = (uint32_t)(w.y >> 32);
                 }
                 sp = n * stride;
             }
@@ -1450,11 +1468,7 @@ __device__ __attribute__((noinline)) void coop_serve(const CoopArgs* args, char*
             COOP_STAT(1, __ballot(rid >= 0));  // serve passes: busy lanes
             blas_pass(A, rid >= 0, stk, stride, o, d, a, t_min, r, ht, hnode, hkp, cur, sp, err);
             const bool fin = rid >= 0 && cur == REF_DONE;
-            if (fin) {
-                uint64_t* w = pool + (size_t)COOP_REC * (size_t)rid + 9;
-                w[0] = __double_as_longlong(ht);
-                w[1] = ((uint64_t)hkp << 32) | (uint64_t)(uint32_t)hnode;
-            }
+            if (fin) st_unit(pool + (size_t)COOP_REC * (size_t)rid, 5, dbits(ht), ((uint64_t)hkp << 32) | (uint64_t)(uint32_t)hnode);
             ring_push(C.aq, fin, (uint32_t)rid, lane, lanemask_lt, true);
             if (fin) rid = -1;
             const int busy = __popcll(__ballot(rid >= 0));
@@ -1473,15 +1487,14 @@ __device__ __attribute__((noinline)) void coop_serve(const CoopArgs* args, char*
             if (sus) {
                 uint64_t* q = pool + (size_t)COOP_REC * (size_t)rid;
                 const int n = sp / stride;
-                q[7] = ((uint64_t)cur << 32) | (uint64_t)(uint32_t)ld_sc1(q + 7);  // low half: the request's original best order stays for the adopter
-                q[9] = __double_as_longlong(ht);
-                q[10] = ((uint64_t)hkp << 32) | (uint64_t)(uint32_t)hnode;
-                for (int i = 0; i < n; i += 2) {
-                    const uint64_t lo = stk[i * stride], hi = (i + 1 < n) ? stk[(i + 1) * stride] : 0u;
-                    q[26 + (i >> 1)] = lo | (hi << 32);
+                const U2 u4 = ld_unit(q, 4);
+                st_unit(q, 4, ((uint64_t)cur << 32) | (uint64_t)(uint32_t)u4.x, (u4.y & ~(0xffull << 24)) | ((uint64_t)(n + 1) << 24));
+                st_unit(q, 5, dbits(ht), ((uint64_t)hkp << 32) | (uint64_t)(uint32_t)hnode);
+                for (int i = 0; i < n; i += 4) {
+                    const uint64_t e0 = stk[i * stride], e1 = (i + 1 < n) ? stk[(i + 1) * stride] : 0u;
+                    const uint64_t e2 = (i + 2 < n) ? stk[(i + 2) * stride] : 0u, e3 = (i + 3 < n) ? stk[(i + 3) * stride] : 0u;
+                    st_unit(q, 10 + (i >> 2), e0 | (e1 << 32), e2 | (e3 << 32));
                 }
-                const uint64_t w25 = ld_sc1(q + 25);
-                q[25] = (w25 & ~(0xffffull << 16)) | ((uint64_t)(n + 1) << 16);
             }
             ring_push(C.rq, sus, (uint32_t)rid, lane, lanemask_lt, true);
             return;
@@ -1520,17 +1533,37 @@ template <int INTEG>
 __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam, RenderK rk, double* __restrict__ ring, double* accum,
                                                            unsigned int* tickets, unsigned int* __restrict__ counter, int* __restrict__ err, uint64_t* coop) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // LDS map: [top-of-BVH Node2 cache][stacks: stack2 x PT_BLOCK words][ring / job bookkeeping as in pt_kernel]
+    // LDS map: [world-level tables][top-of-BVH Node2 cache][stacks: stack2 x PT_BLOCK words][ring / job bookkeeping as in pt_kernel]
     //          [RQ, AQ, FQ: COOP_POOL words each][8 counters][CoopArgs]          (the scene itself stays in L2 / HBM)
     uint32_t staged = 0;
     Acc A = make_acc(sv.base, sv.base, sv);
+    // world-level tables into LDS (coop_world_bytes, flat.h); A then is the view the world-space walk and the shading use
+    uint32_t lds_inst2 = 0, lds_xforms = 0;
+    {
+        auto stage = [&](uint32_t off, uint32_t bytes) {
+            const uint4* src = (const uint4*)(sv.base + off);
+            uint4* dst = (uint4*)(smem + staged);
+            for (uint32_t i = threadIdx.x; i < coop_a16(bytes) / 16; i += blockDim.x) dst[i] = src[i];
+            const char* at = smem + staged;
+            staged += coop_a16(bytes);
+            return at;
+        };
+        A.spheres = (const double2*)stage(sv.off_spheres, sv.off_rects - sv.off_spheres);
+        A.rects = (const double2*)stage(sv.off_rects, sv.off_tris - sv.off_rects);
+        lds_xforms = staged;
+        A.xforms = (const double*)stage(sv.off_xforms, sv.stage_bytes - sv.off_xforms);
+        lds_inst2 = staged;
+        A.inst2 = (const uint2*)stage(sv.off_inst2, 8u * sv.n_inst2);
+        A.items2 = (const uint2*)stage(sv.off_items2, 8u * sv.n_world_items2);  // world leaves only: instances are deferred
+    }
+    const uint32_t lds_top = staged;
     if (rk.n_top > 0) {
         const uint4* src = (const uint4*)(sv.base + sv.off_n2);
-        uint4* dst = (uint4*)smem;
+        uint4* dst = (uint4*)(smem + staged);
         for (uint32_t i = threadIdx.x; i < (uint32_t)rk.n_top * NODE2_F4; i += blockDim.x) dst[i] = src[i];
-        A.n2_top = (const float4*)smem;
+        A.n2_top = (const float4*)(smem + staged);
         A.n2_top_count = (uint32_t)rk.n_top;
-        staged = (uint32_t)rk.n_top * (uint32_t)sizeof(Node2);
+        staged += (uint32_t)rk.n_top * (uint32_t)sizeof(Node2);
     }
     uint32_t* stk = (uint32_t*)(smem + staged) + threadIdx.x;
     const int stk_stride = (int)blockDim.x;
@@ -1572,7 +1605,9 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
         cargs->off_spheres = sv.off_spheres; cargs->off_rects = sv.off_rects; cargs->off_inst2 = sv.off_inst2;
         cargs->off_xforms = sv.off_xforms;
         cargs->n_top = (uint32_t)rk.n_top;
-        cargs->lds_top = 0u;
+        cargs->lds_top = lds_top;
+        cargs->lds_inst2 = lds_inst2;
+        cargs->lds_xforms = lds_xforms;
         cargs->lds_coop = (uint32_t)((char*)coop_base - smem);
     }
     __syncthreads();
@@ -1667,22 +1702,17 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
                 if (park) {
                     const uint32_t ni = (uint32_t)(__ffs((int)pend) - 1);
                     pend &= pend - 1u;
-                    const uint2 in = A.inst2[ni];
-                    const double* Minv = A.xforms + 32 * in.x;
-                    const D3 oo = xf_point(Minv, o), dd = xf_dir(Minv, d);
                     uint64_t* q = pool_mem + (size_t)COOP_REC * (size_t)id;
-                    q[0] = __double_as_longlong(oo.x); q[1] = __double_as_longlong(oo.y); q[2] = __double_as_longlong(oo.z);
-                    q[3] = __double_as_longlong(dd.x); q[4] = __double_as_longlong(dd.y); q[5] = __double_as_longlong(dd.z);
-                    q[6] = __double_as_longlong(h.t);
-                    q[7] = ((uint64_t)in.y << 32) | (uint64_t)(uint32_t)h.node;
-                    q[8] = ((uint64_t)(uint32_t)(h.xf + 1) << 32) | (uint64_t)(((uint32_t)depth << 8) | ni);
-                    q[11] = __double_as_longlong(o.x); q[12] = __double_as_longlong(o.y); q[13] = __double_as_longlong(o.z);
-                    q[14] = __double_as_longlong(d.x); q[15] = __double_as_longlong(d.y); q[16] = __double_as_longlong(d.z);
-                    q[17] = __double_as_longlong(beta.x); q[18] = __double_as_longlong(beta.y); q[19] = __double_as_longlong(beta.z);
-                    q[20] = __double_as_longlong(L.x); q[21] = __double_as_longlong(L.y); q[22] = __double_as_longlong(L.z);
-                    q[23] = rng.s;
-                    q[24] = ((uint64_t)h.kp << 32) | (uint64_t)(uint32_t)pix_id;
-                    q[25] = ((uint64_t)pend << 32) | (uint64_t)out_slot;  // saved-stack count (bits 16..31) = 0: a fresh request
+                    st_unit(q, 0, dbits(o.x), dbits(o.y));
+                    st_unit(q, 1, dbits(o.z), dbits(d.x));
+                    st_unit(q, 2, dbits(d.y), dbits(d.z));
+                    st_unit(q, 3, dbits(h.t), ((uint64_t)h.kp << 32) | (uint64_t)(uint32_t)h.node);
+                    st_unit(q, 4, ((uint64_t)A.inst2[ni].y << 32) | (uint64_t)(uint32_t)(h.xf + 1),
+                            ((uint64_t)pend << 32) | (uint64_t)(ni << 16) | (uint64_t)out_slot);  // saved-stack count 0: a fresh request
+                    st_unit(q, 6, dbits(beta.x), dbits(beta.y));
+                    st_unit(q, 7, dbits(beta.z), dbits(L.x));
+                    st_unit(q, 8, dbits(L.y), dbits(L.z));
+                    st_unit(q, 9, rng.s, ((uint64_t)(uint32_t)depth << 32) | (uint64_t)(uint32_t)pix_id);
                     alive = false;
                 }
                 const uint64_t mp = __ballot(park);
@@ -1707,43 +1737,37 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
                 bool repost = false, freed = false;
                 if (id >= 0) {
                     uint64_t* q = pool_mem + (size_t)COOP_REC * (size_t)id;
-                    const uint64_t w8 = ld_sc1(q + 8), w10 = ld_sc1(q + 10), w25 = ld_sc1(q + 25);
-                    const uint32_t inst = (uint32_t)w8 & 0xffu;
-                    depth = (int)(((uint32_t)w8 >> 8) & 0xffffffu);
-                    h.t = __longlong_as_double(ld_sc1(q + 6));  // best hit before this instance: as posted
-                    h.node = (int)(uint32_t)ld_sc1(q + 7);
-                    h.xf = (int)(uint32_t)(w8 >> 32) - 1;
-                    h.kp = (uint32_t)(ld_sc1(q + 24) >> 32);
-                    if ((int)(uint32_t)w10 != h.node) {  // the walk accepted a candidate of this instance
-                        h.t = __longlong_as_double(ld_sc1(q + 9));
-                        h.node = (int)(uint32_t)w10;
-                        h.kp = (uint32_t)(w10 >> 32);
+                    const U2 u3 = ld_unit(q, 3), u4 = ld_unit(q, 4), u5 = ld_unit(q, 5);
+                    const uint32_t inst = (uint32_t)(u4.y >> 16) & 0xffu;
+                    h.t = bitsd(u3.x);  // best hit before this instance: as posted
+                    h.node = (int)(uint32_t)u3.y;
+                    h.kp = (uint32_t)(u3.y >> 32);
+                    h.xf = (int)(uint32_t)u4.x - 1;
+                    if ((int)(uint32_t)u5.y != h.node) {  // the walk accepted a candidate of this instance
+                        h.t = bitsd(u5.x);
+                        h.node = (int)(uint32_t)u5.y;
+                        h.kp = (uint32_t)(u5.y >> 32);
                         h.xf = (int)A.inst2[inst].x;
                     }
-                    pend = (uint32_t)(w25 >> 32);
-                    out_slot = (uint32_t)w25 & 0xffffu;
-                    o = mk(__longlong_as_double(ld_sc1(q + 11)), __longlong_as_double(ld_sc1(q + 12)), __longlong_as_double(ld_sc1(q + 13)));
-                    d = mk(__longlong_as_double(ld_sc1(q + 14)), __longlong_as_double(ld_sc1(q + 15)), __longlong_as_double(ld_sc1(q + 16)));
+                    pend = (uint32_t)(u4.y >> 32);
+                    out_slot = (uint32_t)u4.y & 0xffffu;
                     if (pend != 0u) {  // next deferred instance of the same segment: the path stays parked, new request
                         const uint32_t ni = (uint32_t)(__ffs((int)pend) - 1);
                         pend &= pend - 1u;
-                        const uint2 in = A.inst2[ni];
-                        const double* Minv = A.xforms + 32 * in.x;
-                        const D3 oo = xf_point(Minv, o), dd = xf_dir(Minv, d);
-                        q[0] = __double_as_longlong(oo.x); q[1] = __double_as_longlong(oo.y); q[2] = __double_as_longlong(oo.z);
-                        q[3] = __double_as_longlong(dd.x); q[4] = __double_as_longlong(dd.y); q[5] = __double_as_longlong(dd.z);
-                        q[6] = __double_as_longlong(h.t);
-                        q[7] = ((uint64_t)in.y << 32) | (uint64_t)(uint32_t)h.node;
-                        q[8] = ((uint64_t)(uint32_t)(h.xf + 1) << 32) | (uint64_t)(((uint32_t)depth << 8) | ni);
-                        const uint64_t w24 = ld_sc1(q + 24);
-                        q[24] = ((uint64_t)h.kp << 32) | (uint64_t)(uint32_t)w24;
-                        q[25] = ((uint64_t)pend << 32) | (uint64_t)out_slot;
+                        st_unit(q, 3, dbits(h.t), ((uint64_t)h.kp << 32) | (uint64_t)(uint32_t)h.node);
+                        st_unit(q, 4, ((uint64_t)A.inst2[ni].y << 32) | (uint64_t)(uint32_t)(h.xf + 1),
+                                ((uint64_t)pend << 32) | (uint64_t)(ni << 16) | (uint64_t)out_slot);
                         repost = true;
                     } else {
-                        beta = mk(__longlong_as_double(ld_sc1(q + 17)), __longlong_as_double(ld_sc1(q + 18)), __longlong_as_double(ld_sc1(q + 19)));
-                        L = mk(__longlong_as_double(ld_sc1(q + 20)), __longlong_as_double(ld_sc1(q + 21)), __longlong_as_double(ld_sc1(q + 22)));
-                        rng.s = ld_sc1(q + 23);
-                        pix_id = (int)(uint32_t)ld_sc1(q + 24);
+                        const U2 u0 = ld_unit(q, 0), u1 = ld_unit(q, 1), u2 = ld_unit(q, 2);
+                        const U2 u6 = ld_unit(q, 6), u7 = ld_unit(q, 7), u8 = ld_unit(q, 8), u9 = ld_unit(q, 9);
+                        o = mk(bitsd(u0.x), bitsd(u0.y), bitsd(u1.x));
+                        d = mk(bitsd(u1.y), bitsd(u2.x), bitsd(u2.y));
+                        beta = mk(bitsd(u6.x), bitsd(u6.y), bitsd(u7.x));
+                        L = mk(bitsd(u7.y), bitsd(u8.x), bitsd(u8.y));
+                        rng.s = u9.x;
+                        depth = (int)(uint32_t)(u9.y >> 32);
+                        pix_id = (int)(uint32_t)u9.y;
                         alive = true;
                         ready = true;
                         freed = true;
@@ -2120,9 +2144,10 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
     const bool accel2_usable = view.accel_ok && camera_ok && stack2_bytes <= lds_max;  // per-lane stacks live in LDS
     const bool media = (view.kinds_mask & (1u << NK_MEDIUM_BEGIN)) != 0;               // flatten.cpp: such scenes have no accel
     // kernel 5 = kernel 2's BVH with the cooperative instance service (pt_kernel_coop): for scenes with LARGE mesh instances
-    const size_t coop_lds = (size_t)(3 * COOP_POOL + 8) * sizeof(uint32_t) + ((sizeof(CoopArgs) + 15) & ~size_t(15));  // three rings of pool-slot ids, counters, argument block
+    const size_t coop_world = coop_world_bytes(view);  // world-level tables, always in LDS for this kernel
+    const size_t coop_lds = (size_t)(3 * COOP_POOL + 8) * sizeof(uint32_t) + ((sizeof(CoopArgs) + 15) & ~size_t(15)) + coop_world;  // + three rings of pool-slot ids, counters, argument block
     const bool coop_usable = accel2_usable && general && !media && view.n_inst2 >= 1 && view.n_inst2 <= (uint32_t)COOP_MAX_INST &&
-                             view.inst_depth2 <= (uint32_t)COOP_STACK_MAX && stack2_bytes + coop_lds <= lds_max && plan.max_depth < (1 << 24);
+                             view.inst_depth2 <= (uint32_t)COOP_STACK_MAX && coop_world <= 16384 && stack2_bytes + coop_lds <= lds_max && plan.max_depth < (1 << 24);
     int kernel = plan.kernel;
     // auto: the cooperative kernel from ~8k object-space nodes per instance (measured on the Cornell box + torus instance, 64 spp:
     // 6,400 triangles / 4.3k nodes 597 vs 606 Msamples/s for kernel 2, 25,600 / 17k 557 vs 508, 102,400 / 68k 508 vs 434, 409,600 437 vs 383)

@@ -284,7 +284,7 @@ void flatten(rt_scene& s) {
     // ---- accel (kernel 2) ----
     AccelBuild ab;
     ab.ok = b.accel_ok;
-    uint32_t root2 = REF_DONE, max_inst_nodes = 0, inst_depth = 0;
+    uint32_t root2 = REF_DONE, max_inst_nodes = 0, inst_depth = 0, n_world_items = 0;
     double origin_limit = 0.;
     if (ab.ok && !b.actx[0].items.empty()) {
         // E_w: largest |coordinate| of the world items; boxes are padded so that rounding a ray origin with
@@ -302,6 +302,7 @@ void flatten(rt_scene& s) {
             if (!(origin_limit < 68719476736.)) ab.ok = false;  // 2^36
             root2 = accel_build_bvh(ab, b.actx[0].items, pad_w, 0);
             const int depth_tlas = ab.max_depth;
+            n_world_items = (uint32_t)(ab.items.size() / 2);
             ab.inst.assign(2 * (b.actx.size() - 1), 0u);
             for (size_t i = 1; ab.ok && i < b.actx.size(); i++) {
                 auto& c = b.actx[i];
@@ -410,6 +411,7 @@ void flatten(rt_scene& s) {
     v.n_inst2 = (uint32_t)(ab.inst.size() / 2);
     v.max_inst_nodes2 = max_inst_nodes;
     v.inst_depth2 = inst_depth;
+    v.n_world_items2 = n_world_items;
     v.origin_limit2 = origin_limit;
     // cold part (read once per path segment, by the winning leaf only): always global
     v.off_sphere_mat = append(f.blob, b.sphere_mat);
