@@ -125,7 +125,7 @@ typedef struct rt_tuning {
     int32_t no_lds;                /* 1: keep scene tables in global memory even when they fit LDS (A/B runs)            */
     int32_t top_nodes;             /* >= 0: cap on the BVH nodes cached in LDS when the scene lives in L2/HBM; -1 auto  */
     int32_t sub_spp;               /* 1..8: sample indices per work unit (a wave's pool = 64 px x sub_spp); 0 auto      */
-    int32_t reserved;
+    int32_t coop_pool;             /* 1..2048: parked-path slots per workgroup in kernel 5 (small values force its in-lane fallback); 0 auto */
     int32_t max_leaf;              /* 1..4: accel builder, items per leaf; 0 auto (read at rt_scene_commit)             */
     int32_t sppm_photon_capacity;  /* > 0: initial photon-buffer capacity (forces the grow-and-retry path); 0 auto      */
     int32_t sppm_knn_candidates;   /* >= 0: k-nearest candidates kept in LDS (0 forces the out-of-LDS selection); -1 auto */
@@ -241,7 +241,7 @@ typedef struct rt_scene_info {
     int32_t n_nodes, n_boxes, n_spheres, n_rects, n_tris, n_xforms, n_materials, n_textures;
     int32_t n_verts, max_depth, committed, reserved;
     uint64_t bytes;
-    int32_t accel_ok, accel_nodes, accel_items, accel_instances, accel_stack, reserved2;
+    int32_t accel_ok, accel_nodes, accel_items, accel_instances, accel_stack, accel_compact;  /* accel_compact: 1 if the compact object-space copies kernel 5 needs were built */
 } rt_scene_info;
 int rt_scene_info_get(const rt_scene* s, rt_scene_info* out);
 

@@ -95,6 +95,7 @@ int rt_tuning_set(const rt_tuning* t) {
         n.n_top = t->top_nodes < 0 ? -1 : t->top_nodes;
         n.sub_spp = std::max(0, t->sub_spp);
         n.max_leaf = t->max_leaf;
+        n.coop_pool = std::max(0, t->coop_pool);
         n.sppm_cap = std::max(0, t->sppm_photon_capacity);
         n.knn_cand = t->sppm_knn_candidates < 0 ? -1 : t->sppm_knn_candidates;
         n.c_box = t->sah_box_cost;

@@ -117,14 +117,47 @@ struct FlatView {  // by-value kernel argument
     uint32_t max_inst_nodes2;    // Node2 count of the largest instance BVH
     uint32_t inst_depth2;        // depth of the deepest instance BVH (stack entries a suspended object-space walk can hold)
     uint32_t n_world_items2;     // items2[0 .. n_world_items2) are the world-space BVH's (its leaves are laid out first)
+    // kernel 5's compact copies of the object-space data (see "Compact instance data" below); coop_data_ok = 0: not available
+    uint32_t coop_data_ok;
+    uint32_t off_n2q;            // NodeQ per Node2 index (object-space nodes only; world-space entries are unused)
+    uint32_t off_tri32;          // Tri32 per item index (object-space leaves only)
+    uint32_t off_qgrid;          // QGrid per instance
+    uint32_t world_top2;         // world-space BVH nodes all have an index below this (the Node2 array is depth-sorted)
 };
+
+// ---------------------------------------------------------------------------
+// Compact instance data (kernel 5).  The serving waves of kernel 5 are bound by the number of cache lines the L1 has to look
+// up, not by arithmetic, so the object-space BVHs and triangles get a second, smaller encoding:
+//   NodeQ (32 B, Node2 is 64): both children's boxes on a 16-bit grid laid over the instance's bounds, rounded OUTWARD and
+//     padded by P grid units; the serving lane maps its object-space ray into grid coordinates once per request
+//     (o_g = (o - mn) * k + shift, d_g = d * k per axis: t is unchanged) and runs the same conservative f32 slab test (box32)
+//     on the integers.  box32's proof is coordinate-free: it needs stored bounds that contain the exact box with a margin of
+//     4 * 2^-24 * |o|max, here in grid units, hence P = ceil(2^-22 * O_g) + 2 with O_g = the largest grid coordinate a ray
+//     origin can have (the +2 covers floor/ceil of the host's f64 products and the f64 rounding of o_g, d_g: < 2^-14 units).
+//   Tri32 (48 B, item + hoisted record are 88): the three vertices in f32 -- meshes come out of the OBJ loader as f32 widened
+//     to f64 (mesh.rs:160-172), so this is exact; the edges e0 = pb - pa, e1 = pc - pa are formed in f64 by the lane exactly as
+//     the host formed them -- plus the item's order and kind|payload, so that a leaf needs no second table.
+//   Instances whose vertices are not f32 values, or that hold anything but triangles, have no compact copy: kernel 2 renders.
+// ---------------------------------------------------------------------------
+struct NodeQ {
+    uint32_t lox, loy, loz, hix, hiy, hiz;  // child 0 in the low half, child 1 in the high half
+    uint32_t child[2];
+};
+struct Tri32 {
+    float pa[3], pb[3], pc[3];
+    uint32_t order, kp, pad;
+};
+struct QGrid {
+    double mn[3], k[3], shift, pad;
+};
+static const double QGRID_MAX = 65535.0;
 
 // Kernel 5 keeps the WORLD-level tables in LDS even though the scene as a whole does not fit: spheres, rects, transforms, the
 // instance table and the world-space BVH's items (the mesh data -- triangles, object-space nodes and items -- stays in L2 / HBM).
 constexpr uint32_t coop_a16(uint32_t x) { return (x + 15u) & ~15u; }
 constexpr uint32_t coop_world_bytes(const FlatView& v) {
     return coop_a16(v.off_rects - v.off_spheres) + coop_a16(v.off_tris - v.off_rects) + coop_a16(v.stage_bytes - v.off_xforms) +
-           coop_a16(8u * v.n_inst2) + coop_a16(8u * v.n_world_items2);
+           coop_a16(8u * v.n_inst2) + coop_a16(8u * v.n_world_items2) + coop_a16(64u * v.n_inst2);  // + QGrid per instance
 }
 
 }  // namespace rtamd

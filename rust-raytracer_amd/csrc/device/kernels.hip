@@ -137,6 +137,12 @@ struct Acc {  // typed views into the blob (LDS or global; the address space is 
     const uint2* lights;     // {NK_SPHERE | NK_RECT_XZ, payload}
     uint32_t n_lights;
     const MediumDev* media;  // always global
+    // kernel 5's serving waves: compact object-space data (flat.h "Compact instance data")
+    const uint4* n2q;        // 2 x uint4 per NodeQ
+    const uint4* n2q_top;    // LDS copy of the first n2q_top_count NodeQ
+    uint32_t n2q_top_count;
+    const uint4* tri32;      // 3 x uint4 per Tri32
+    const double* qgrid;     // 8 per instance
 };
 template <class P>
 DEV Acc make_acc(P hot, const char* gbase, const FlatView& v) {  // hot: LDS copy or the global blob; cold part always global
@@ -184,6 +190,8 @@ struct RenderK {
     int job_units;    // consecutive units of one tile a wave takes at a time (one ticket hand-off per job); n_units counts JOBS
     const double* sppm_est;  // INTEG 2: per pixel {caustic estimate[3], global estimate[3]}, index y*width + x
     int n_top;               // kernel 2 with the scene in L2/HBM: number of (depth-sorted) Node2 cached in LDS
+    int n_topq;              // kernel 5: number of NodeQ cached in LDS for the serving waves
+    int coop_pool;           // kernel 5: parked-path slots in use (<= COOP_POOL)
 };
 
 // ------------------------------------------------------ intersection ------
@@ -246,9 +254,12 @@ DEV bool rect_hit(const double2* r, int axis, D3 o, D3 d, double t_min, double t
 }
 DEV D3 ld3(const double* p, uint32_t i) { return mk(p[3 * i], p[3 * i + 1], p[3 * i + 2]); }
 // Triangle::hit, mesh.rs:57-102 ; returns t and the barycentrics b1,b2
+DEV bool tri_hit_v(D3 pa, D3 e0, D3 e1, D3 o, D3 dir, double t_min, double t_max, double& t_out, double& b1o, double& b2o);
 DEV bool tri_hit(const double2* q, D3 o, D3 dir, double t_min, double t_max, double& t_out, double& b1o, double& b2o) {
     double2 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4];
-    D3 pa = mk(q0.x, q0.y, q1.x), e0 = mk(q1.y, q2.x, q2.y), e1 = mk(q3.x, q3.y, q4.x);
+    return tri_hit_v(mk(q0.x, q0.y, q1.x), mk(q1.y, q2.x, q2.y), mk(q3.x, q3.y, q4.x), o, dir, t_min, t_max, t_out, b1o, b2o);
+}
+DEV bool tri_hit_v(D3 pa, D3 e0, D3 e1, D3 o, D3 dir, double t_min, double t_max, double& t_out, double& b1o, double& b2o) {
     D3 s0 = cross(dir, e1);
     double dd = dot(s0, e0);
     if (dd == 0.0) return false;
@@ -1351,6 +1362,69 @@ DEV void blas_pass(const Acc& A, bool act, uint32_t* stk, const int stride, D3 o
 }
 
 
+// The same pass over the compact encoding (flat.h "Compact instance data"): NodeQ boxes are grid integers and `r` is the ray in
+// grid coordinates; triangles come as f32 vertices with order and kind|payload in the record.  (o, d) is the object-space ray.
+DEV void blas_pass_q(const Acc& A, bool act, uint32_t* stk, const int stride, D3 o, D3 d, double t_min, Ray32& r, double& ht, int& hnode,
+                     uint32_t& hkp, uint32_t& cur, int& sp) {
+    // (measured and dropped: ending the descent early once fewer than 16 / 24 / 32 / 40 lanes still descend -- 631 / 574 / 547 / 517
+    // against 632 Msamples/s -- and testing at most 1 or 2 triangles of a leaf per pass, 543 / 612)
+    while (act && (cur >> REF_TAG_SHIFT) == 0u) {
+        uint4 u0, u1;  // (lox, loy, loz, hix) (hiy, hiz, c0, c1); child 0 in the low halves
+        if (cur < A.n2q_top_count) {
+            const uint4* p = A.n2q_top + 2 * cur;
+            u0 = p[0]; u1 = p[1];
+        } else {
+            const uint4* p = A.n2q + 2 * cur;
+            u0 = p[0]; u1 = p[1];
+        }
+        float e0, e1;
+        const bool h0 = box32((float)(u0.x & 0xffffu), (float)(u0.y & 0xffffu), (float)(u0.z & 0xffffu), (float)(u0.w & 0xffffu),
+                              (float)(u1.x & 0xffffu), (float)(u1.y & 0xffffu), r, e0);
+        const bool h1 = box32((float)(u0.x >> 16), (float)(u0.y >> 16), (float)(u0.z >> 16), (float)(u0.w >> 16), (float)(u1.x >> 16),
+                              (float)(u1.y >> 16), r, e1);
+        const uint32_t c0 = u1.z, c1 = u1.w;
+        if (h0 && h1) {
+            const bool swap = e1 < e0;
+            stk[sp] = swap ? c0 : c1;
+            sp += stride;
+            cur = swap ? c1 : c0;
+        } else if (h0) {
+            cur = c0;
+        } else if (h1) {
+            cur = c1;
+        } else if (sp > 0) {
+            sp -= stride;
+            cur = stk[sp];
+        } else {
+            cur = REF_DONE;
+        }
+    }
+    if (act && (cur >> REF_TAG_SHIFT) == 1u) {  // leaf: Triangle::hit in f64 (mesh.rs:57-102), tie rule as in traverse2
+        const uint32_t first = cur & REF_LEAF_FIRST_MASK, cnt = ((cur >> REF_LEAF_COUNT_SHIFT) & 7u) + 1u;
+        for (uint32_t i = 0; i < cnt; i++) {
+            const uint4* p = A.tri32 + 3 * (first + i);
+            const uint4 a = p[0], b = p[1], c = p[2];
+            const D3 pa = mk((double)__uint_as_float(a.x), (double)__uint_as_float(a.y), (double)__uint_as_float(a.z));
+            const D3 pb = mk((double)__uint_as_float(a.w), (double)__uint_as_float(b.x), (double)__uint_as_float(b.y));
+            const D3 pc = mk((double)__uint_as_float(b.z), (double)__uint_as_float(b.w), (double)__uint_as_float(c.x));
+            double t = 0., b1, b2;
+            const bool got = tri_hit_v(pa, sub(pb, pa), sub(pc, pa), o, d, t_min, ht, t, b1, b2);
+            if (got && (t < ht || (int)c.y > hnode || !(t == t))) {
+                ht = t;
+                hnode = (int)c.y;
+                hkp = c.z;
+                r.best = ray32_best(t);
+            }
+        }
+        if (sp > 0) {
+            sp -= stride;
+            cur = stk[sp];
+        } else {
+            cur = REF_DONE;
+        }
+    }
+}
+
 // Out-of-line pieces of pt_kernel_coop get what they need from a block in LDS (written once per workgroup): a call passes
 // arguments in VGPRs, these are wave-uniform and belong in SGPRs, and the pointers keep their address spaces this way.
 struct CoopArgs {
@@ -1361,6 +1435,7 @@ struct CoopArgs {
     uint32_t off_n2, off_items2, off_tripre2, off_spheres, off_rects, off_inst2, off_xforms, n_top;
     uint32_t lds_top, lds_coop;  // byte offsets of the Node2 cache and of the rings within the workgroup's LDS
     uint32_t lds_inst2, lds_xforms;  // ... and of the LDS copies of the instance table and the transforms
+    uint32_t off_n2q, off_tri32, lds_qgrid, lds_topq, n_topq;  // compact object-space data; its grids and top nodes in LDS
 };
 #define AS_GLOBAL(T, p) ((T*)(__attribute__((address_space(1))) T*)(p))
 #define AS_LDS(T, p) ((T*)(__attribute__((address_space(3))) T*)(p))
@@ -1390,6 +1465,11 @@ DEV CoopCtx coop_ctx(const CoopArgs* args_generic, char* lds0_generic) {  // lds
     X.A.xforms = (const double*)(lds0 + rfl(ga->lds_xforms));
     X.A.n2_top = (const float4*)(lds0 + rfl(ga->lds_top));
     X.A.n2_top_count = rfl(ga->n_top);
+    X.A.n2q = (const uint4*)(base + rfl(ga->off_n2q));
+    X.A.tri32 = (const uint4*)(base + rfl(ga->off_tri32));
+    X.A.qgrid = (const double*)(lds0 + rfl(ga->lds_qgrid));
+    X.A.n2q_top = (const uint4*)(lds0 + rfl(ga->lds_topq));
+    X.A.n2q_top_count = rfl(ga->n_topq);
     uint32_t* cb = (uint32_t*)(lds0 + rfl(ga->lds_coop));
     X.C.rq.buf = cb;
     X.C.aq.buf = cb + COOP_POOL;
@@ -1409,7 +1489,6 @@ __device__ __attribute__((noinline)) void coop_serve(const CoopArgs* args, char*
     const CoopLds& C = X.C;
     const Acc& A = X.A;
     uint64_t* pool = X.pool;
-    int* err = X.err;
     const double t_min = X.t_min;
     uint32_t* stk = AS_LDS(uint32_t, stk_generic);
     const int stride = PT_BLOCK;
@@ -1418,7 +1497,6 @@ __device__ __attribute__((noinline)) void coop_serve(const CoopArgs* args, char*
     may_suspend = __ballot(may_suspend) != 0ull;
     int rid = -1;
     D3 o = mk(0, 0, 0), d = mk(0, 0, 1);
-    double a = 1.;
     Ray32 r = make_ray32(o, mk(1, 1, 1), t_min, 0.);
     double ht = 0.;
     int hnode = -1;
@@ -1437,7 +1515,6 @@ __device__ __attribute__((noinline)) void coop_serve(const CoopArgs* args, char*
             const D3 wo = mk(bitsd(u0.x), bitsd(u0.y), bitsd(u1.x)), wd = mk(bitsd(u1.y), bitsd(u2.x), bitsd(u2.y));
             o = xf_point(Minv, wo);
             d = xf_dir(Minv, wd);
-            a = sqlen(d);
             cur = (uint32_t)(u4.x >> 32);
             if (n_saved == 0) {  // fresh request
                 ht = bitsd(u3.x);
@@ -1459,14 +1536,17 @@ __device__ __attribute__((noinline)) void coop_serve(const CoopArgs* args, char*
                 }
                 sp = n * stride;
             }
-            r = make_ray32(o, rcp3(d), t_min, ht);
+            const double* g = A.qgrid + 8 * inst;  // the ray on the instance's grid: same t (QGrid, flat.h)
+            const D3 og = mk((o.x - g[0]) * g[3] + g[6], (o.y - g[1]) * g[4] + g[6], (o.z - g[2]) * g[5] + g[6]);
+            const D3 dg = mk(d.x * g[3], d.y * g[4], d.z * g[5]);
+            r = make_ray32(og, rcp3(dg), t_min, ht);
         }
         if (__ballot(rid >= 0) == 0ull) return;
         COOP_STAT(0, __ballot(rid >= 0));  // serve rounds: lanes holding a request at the start of a round
         bool thin = false;
         for (;;) {
             COOP_STAT(1, __ballot(rid >= 0));  // serve passes: busy lanes
-            blas_pass(A, rid >= 0, stk, stride, o, d, a, t_min, r, ht, hnode, hkp, cur, sp, err);
+            blas_pass_q(A, rid >= 0, stk, stride, o, d, t_min, r, ht, hnode, hkp, cur, sp);
             const bool fin = rid >= 0 && cur == REF_DONE;
             if (fin) st_unit(pool + (size_t)COOP_REC * (size_t)rid, 5, dbits(ht), ((uint64_t)hkp << 32) | (uint64_t)(uint32_t)hnode);
             ring_push(C.aq, fin, (uint32_t)rid, lane, lanemask_lt, true);
@@ -1538,7 +1618,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
     uint32_t staged = 0;
     Acc A = make_acc(sv.base, sv.base, sv);
     // world-level tables into LDS (coop_world_bytes, flat.h); A then is the view the world-space walk and the shading use
-    uint32_t lds_inst2 = 0, lds_xforms = 0;
+    uint32_t lds_inst2 = 0, lds_xforms = 0, lds_qgrid = 0;
     {
         auto stage = [&](uint32_t off, uint32_t bytes) {
             const uint4* src = (const uint4*)(sv.base + off);
@@ -1555,6 +1635,8 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
         lds_inst2 = staged;
         A.inst2 = (const uint2*)stage(sv.off_inst2, 8u * sv.n_inst2);
         A.items2 = (const uint2*)stage(sv.off_items2, 8u * sv.n_world_items2);  // world leaves only: instances are deferred
+        lds_qgrid = staged;
+        stage(sv.off_qgrid, (uint32_t)sizeof(QGrid) * sv.n_inst2);
     }
     const uint32_t lds_top = staged;
     if (rk.n_top > 0) {
@@ -1564,6 +1646,13 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
         A.n2_top = (const float4*)(smem + staged);
         A.n2_top_count = (uint32_t)rk.n_top;
         staged += (uint32_t)rk.n_top * (uint32_t)sizeof(Node2);
+    }
+    const uint32_t lds_topq = staged;  // the serving waves' cache: the shallowest NodeQ of every object-space BVH
+    {
+        const uint4* src = (const uint4*)(sv.base + sv.off_n2q);
+        uint4* dst = (uint4*)(smem + staged);
+        for (uint32_t i = threadIdx.x; i < (uint32_t)rk.n_topq * 2u; i += blockDim.x) dst[i] = src[i];
+        staged += (uint32_t)rk.n_topq * (uint32_t)sizeof(NodeQ);
     }
     uint32_t* stk = (uint32_t*)(smem + staged) + threadIdx.x;
     const int stk_stride = (int)blockDim.x;
@@ -1588,9 +1677,9 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
     for (uint32_t i = threadIdx.x; i < (uint32_t)COOP_POOL; i += blockDim.x) {
         C.rq.buf[i] = 0u;
         C.aq.buf[i] = 0u;
-        C.fq.buf[i] = i + 1u;  // every pool slot is free
+        C.fq.buf[i] = i < (uint32_t)rk.coop_pool ? i + 1u : 0u;  // every pool slot in use is free
     }
-    if (threadIdx.x < 8) cnt[threadIdx.x] = (threadIdx.x == 5) ? (uint32_t)COOP_POOL : 0u;  // FQ tail = COOP_POOL
+    if (threadIdx.x < 8) cnt[threadIdx.x] = (threadIdx.x == 5) ? (uint32_t)rk.coop_pool : 0u;  // FQ tail = number of slots
     if (lane < 8) wst[lane] = (lane == 6) ? 1u : 0u;
     if (threadIdx.x == 0) {
         cfg[CFG_N_JOBS] = rk.n_units; cfg[CFG_TILES_OWNED] = rk.tiles_owned; cfg[CFG_JOB_UNITS] = rk.job_units;
@@ -1608,6 +1697,8 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
         cargs->lds_top = lds_top;
         cargs->lds_inst2 = lds_inst2;
         cargs->lds_xforms = lds_xforms;
+        cargs->off_n2q = sv.off_n2q; cargs->off_tri32 = sv.off_tri32; cargs->lds_qgrid = lds_qgrid;
+        cargs->lds_topq = lds_topq; cargs->n_topq = (uint32_t)rk.n_topq;
         cargs->lds_coop = (uint32_t)((char*)coop_base - smem);
     }
     __syncthreads();
@@ -1717,7 +1808,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
                 }
                 const uint64_t mp = __ballot(park);
                 if (mp != 0ull && lane == __ffsll((long long)mp) - 1) atomicAdd(C.n_parked, (uint32_t)__popcll(mp));
-                ring_push(C.rq, park, (uint32_t)id, lane, lanemask_lt, true);
+                ring_push(C.rq, park, (uint32_t)id, lane, lanemask_lt, true);  // (publishing an iteration later, behind the stores' round trip: no gain)
                 // pool exhausted (rare): walk the deferred instances in this lane, sparsely, as the plain kernel does
                 if (__ballot(want && id < 0) != 0ull) {
                     if (want && id < 0) {
@@ -1737,7 +1828,10 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
                 bool repost = false, freed = false;
                 if (id >= 0) {
                     uint64_t* q = pool_mem + (size_t)COOP_REC * (size_t)id;
+                    // the whole record in one round trip (a re-posted path wastes the second half; rare: several instances on one ray)
                     const U2 u3 = ld_unit(q, 3), u4 = ld_unit(q, 4), u5 = ld_unit(q, 5);
+                    const U2 u0 = ld_unit(q, 0), u1 = ld_unit(q, 1), u2 = ld_unit(q, 2);
+                    const U2 u6 = ld_unit(q, 6), u7 = ld_unit(q, 7), u8 = ld_unit(q, 8), u9 = ld_unit(q, 9);
                     const uint32_t inst = (uint32_t)(u4.y >> 16) & 0xffu;
                     h.t = bitsd(u3.x);  // best hit before this instance: as posted
                     h.node = (int)(uint32_t)u3.y;
@@ -1759,8 +1853,6 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
                                 ((uint64_t)pend << 32) | (uint64_t)(ni << 16) | (uint64_t)out_slot);
                         repost = true;
                     } else {
-                        const U2 u0 = ld_unit(q, 0), u1 = ld_unit(q, 1), u2 = ld_unit(q, 2);
-                        const U2 u6 = ld_unit(q, 6), u7 = ld_unit(q, 7), u8 = ld_unit(q, 8), u9 = ld_unit(q, 9);
                         o = mk(bitsd(u0.x), bitsd(u0.y), bitsd(u1.x));
                         d = mk(bitsd(u1.y), bitsd(u2.x), bitsd(u2.y));
                         beta = mk(bitsd(u6.x), bitsd(u6.y), bitsd(u7.x));
@@ -1827,7 +1919,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
         }
         COOP_TIME(4);
         // ---- serve: a wave's worth of requests waits ----
-        if (ring_len(C.rq) >= (uint32_t)COOP_BATCH) coop_serve(cargs, smem, stk, true COOP_STATS_PASS);
+        if (ring_len(C.rq) >= min((uint32_t)COOP_BATCH, (uint32_t)rk.coop_pool / 4u + 1u)) coop_serve(cargs, smem, stk, true COOP_STATS_PASS);
         COOP_TIME(5);
         // ---- nothing in the lanes, nothing to adopt, no path to generate: fold / fetch, else serve whatever waits, else leave ----
         if (__ballot(alive) == 0ull && next >= pool && ring_len(C.aq) == 0u && __ballot(dec_slot >= 0) == 0ull) {
@@ -2146,14 +2238,14 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
     // kernel 5 = kernel 2's BVH with the cooperative instance service (pt_kernel_coop): for scenes with LARGE mesh instances
     const size_t coop_world = coop_world_bytes(view);  // world-level tables, always in LDS for this kernel
     const size_t coop_lds = (size_t)(3 * COOP_POOL + 8) * sizeof(uint32_t) + ((sizeof(CoopArgs) + 15) & ~size_t(15)) + coop_world;  // + three rings of pool-slot ids, counters, argument block
-    const bool coop_usable = accel2_usable && general && !media && view.n_inst2 >= 1 && view.n_inst2 <= (uint32_t)COOP_MAX_INST &&
+    const bool coop_usable = accel2_usable && general && !media && view.coop_data_ok != 0 && view.n_inst2 >= 1 && view.n_inst2 <= (uint32_t)COOP_MAX_INST &&
                              view.inst_depth2 <= (uint32_t)COOP_STACK_MAX && coop_world <= 16384 && stack2_bytes + coop_lds <= lds_max && plan.max_depth < (1 << 24);
     int kernel = plan.kernel;
     // auto: the cooperative kernel from ~8k object-space nodes per instance (measured on the Cornell box + torus instance, 64 spp:
     // 6,400 triangles / 4.3k nodes 597 vs 606 Msamples/s for kernel 2, 25,600 / 17k 557 vs 508, 102,400 / 68k 508 vs 434, 409,600 437 vs 383)
     if (kernel == 0) kernel = accel2_usable ? ((coop_usable && view.max_inst_nodes2 >= 8192u) ? 5 : 2) : 1;
     if (kernel == 5 && !coop_usable)
-        throw RtError(RT_ERR_UNSUPPORTED, "kernel 5 (cooperative instance service) needs a usable accel and 1..32 mesh instances of depth <= 40");
+        throw RtError(RT_ERR_UNSUPPORTED, "kernel 5 (cooperative instance service) needs a usable accel and 1..32 instances that hold only triangles with f32 vertices (OBJ meshes), of BVH depth <= 40");
     if ((kernel == 2 || kernel == 5) && !accel2_usable)
         throw RtError(RT_ERR_UNSUPPORTED, "kernel 2 requested but no usable accel for this scene/camera (unbounded item, depth overflow, stacks "
                                           "larger than LDS, negative t_min, or camera farther than 64x the scene extent); use kernel 0/1");
@@ -2173,13 +2265,21 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
         fn_coop = (integ == 1) ? pt_kernel_coop<1> : (integ == 2) ? pt_kernel_coop<2> : pt_kernel_coop<0>;
     if (media) fn = lds ? pt_kernel<true, true, 1, 0, true> : pt_kernel<false, true, 1, 0, true>;
     // scene too large for LDS: spend what is left after the stacks on the shallowest BVH levels (the Node2 array is depth-sorted)
-    int n_top = 0;
-    if ((kernel == 2 || kernel == 5) && !lds && lds_max > stack_bytes) {
+    int n_top = 0, n_topq = 0;
+    if (kernel == 2 && !lds && lds_max > stack_bytes) {
         size_t room = (lds_max - stack_bytes) / sizeof(Node2);
         if (tuning().n_top >= 0) room = std::min<size_t>(room, (size_t)tuning().n_top);
         n_top = (int)std::min<size_t>(room, view.n_nodes2);
     }
-    const size_t smem = (lds ? hot_bytes : (size_t)n_top * sizeof(Node2)) + stack_bytes;
+    if (kernel == 5 && lds_max > stack_bytes) {  // f32 nodes for the world-space walk (at most 128), the rest of LDS for the compact object-space nodes
+        size_t room = lds_max - stack_bytes;
+        n_top = (int)std::min<size_t>(std::min<size_t>(room / sizeof(Node2), 128), view.world_top2);
+        if (tuning().n_top >= 0) n_top = std::min(n_top, tuning().n_top);
+        room -= (size_t)n_top * sizeof(Node2);
+        n_topq = (int)std::min<size_t>(room / sizeof(NodeQ), view.n_nodes2);
+        if (tuning().n_top >= 0) n_topq = std::min(n_topq, tuning().n_top);
+    }
+    const size_t smem = (lds ? hot_bytes : (size_t)n_top * sizeof(Node2) + (size_t)n_topq * sizeof(NodeQ)) + stack_bytes;
     const void* fptr = (kernel == 5) ? (const void*)fn_coop : (const void*)fn;
     if (smem > 48 * 1024) HIP_CHECK(hipFuncSetAttribute(fptr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     int blocks_per_cu = 0;
@@ -2223,6 +2323,8 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
         rk.tiles_owned = (int)std::max<int64_t>(1, plan.tiles_owned);
         rk.sppm_est = plan.sppm_est;
         rk.n_top = n_top;
+        rk.n_topq = n_topq;
+        rk.coop_pool = tuning().coop_pool > 0 ? std::min(tuning().coop_pool, (int)COOP_POOL) : (int)COOP_POOL;
         HIP_CHECK(hipMemsetAsync(counter.p, 0, sizeof(unsigned int), stream));
         HIP_CHECK(hipMemsetAsync(tickets.p, 0, std::max<size_t>(16, (size_t)plan.tiles_owned * sizeof(unsigned int)), stream));
         hipEvent_t e0 = events.make(), e1 = events.make();

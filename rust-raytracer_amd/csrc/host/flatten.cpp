@@ -285,6 +285,7 @@ void flatten(rt_scene& s) {
     AccelBuild ab;
     ab.ok = b.accel_ok;
     uint32_t root2 = REF_DONE, max_inst_nodes = 0, inst_depth = 0, n_world_items = 0;
+    std::vector<double> inst_oo;  // per instance: bound of |object-space ray origin|
     double origin_limit = 0.;
     if (ab.ok && !b.actx[0].items.empty()) {
         // E_w: largest |coordinate| of the world items; boxes are padded so that rounding a ray origin with
@@ -314,6 +315,7 @@ void flatten(rt_scene& s) {
                 for (auto& it : c.items)  // hit points inside the instance also serve as origins of secondary rays (in world space only)
                     for (int a = 0; a < 3; a++) oo = std::fmax(oo, std::fmax(std::fabs(it.box.mn[a]), std::fabs(it.box.mx[a])));
                 if (!(oo < 68719476736.)) { ab.ok = false; break; }
+                inst_oo.push_back(oo);
                 const size_t nodes_before = ab.nodes.size();
                 uint32_t r = accel_build_bvh(ab, c.items, std::ldexp(oo, -22), depth_tlas + 1);
                 max_inst_nodes = std::max<uint32_t>(max_inst_nodes, (uint32_t)(ab.nodes.size() - nodes_before));
@@ -381,6 +383,121 @@ void flatten(rt_scene& s) {
         }
     }
 
+    // ---- kernel 5: compact object-space data (common/flat.h "Compact instance data") ----
+    std::vector<NodeQ> n2q;
+    std::vector<Tri32> tri32;
+    std::vector<QGrid> qgrid;
+    bool coop_data = ab.ok && !ab.inst.empty();
+    uint32_t world_top = 0;
+    if (ab.ok) {
+        // world-space nodes after the depth sort: new_of of the first n_world_nodes old indices -- recomputed from the roots
+        std::vector<uint32_t> st;
+        if ((root2 >> REF_TAG_SHIFT) == 0u) st.push_back(root2);
+        while (!st.empty()) {
+            const uint32_t n = st.back();
+            st.pop_back();
+            world_top = std::max(world_top, n + 1);
+            for (int k = 0; k < 2; k++)
+                if ((ab.nodes[n].child[k] >> REF_TAG_SHIFT) == 0u) st.push_back(ab.nodes[n].child[k]);
+        }
+    }
+    if (coop_data) {
+        n2q.assign(ab.nodes.size(), NodeQ{});
+        tri32.assign(ab.items.size() / 2, Tri32{});
+        qgrid.assign(ab.inst.size() / 2, QGrid{});
+        auto is_f32 = [](double x) { return (double)(float)x == x; };
+        for (size_t i = 0; coop_data && i < ab.inst.size() / 2; i++) {
+            const uint32_t root = ab.inst[2 * i + 1];
+            if ((root >> REF_TAG_SHIFT) != 0u) { coop_data = false; break; }
+            const Node2& rn = ab.nodes[root];
+            double mn[3], mx[3];
+            const float* lo[3] = {rn.lo_x, rn.lo_y, rn.lo_z};
+            const float* hi[3] = {rn.hi_x, rn.hi_y, rn.hi_z};
+            for (int a = 0; a < 3; a++) {
+                mn[a] = std::fmin((double)lo[a][0], (double)lo[a][1]);
+                mx[a] = std::fmax((double)hi[a][0], (double)hi[a][1]);
+            }
+            // grid: g(x) = (x - mn) * k + shift, shift = P + 1, (mx - mn) * k = QGRID_MAX - 2 P - 2
+            double k0 = 0., mabs = 0.;
+            for (int a = 0; a < 3; a++) {
+                const double ext = mx[a] - mn[a];
+                k0 = std::fmax(k0, ext > 0. ? QGRID_MAX / ext : 1.);
+                mabs = std::fmax(mabs, std::fabs(mn[a]));
+            }
+            const double og = (inst_oo[i] + mabs) * k0 + 65536.;  // bound of |o_g|
+            if (!(og < 34359738368.)) { coop_data = false; break; }  // 2^35: box32 needs coordinates below 2^36
+            const double P = std::ceil(std::ldexp(og, -22)) + 2.;
+            if (!(P <= 4096.)) { coop_data = false; break; }
+            QGrid g{};
+            for (int a = 0; a < 3; a++) {
+                const double ext = mx[a] - mn[a];
+                g.mn[a] = mn[a];
+                g.k[a] = ext > 0. ? (QGRID_MAX - 2. * P - 2.) / ext : 1.;
+            }
+            g.shift = P + 1.;
+            qgrid[i] = g;
+            std::vector<uint32_t> st{root};
+            while (coop_data && !st.empty()) {
+                const uint32_t n = st.back();
+                st.pop_back();
+                const Node2& nd = ab.nodes[n];
+                const float* l[3] = {nd.lo_x, nd.lo_y, nd.lo_z};
+                const float* h[3] = {nd.hi_x, nd.hi_y, nd.hi_z};
+                uint32_t ql[3], qh[3];
+                for (int a = 0; a < 3; a++) {
+                    uint32_t w_lo = 0, w_hi = 0;
+                    for (int c = 0; c < 2; c++) {
+                        const double a_lo = std::floor(((double)l[a][c] - g.mn[a]) * g.k[a]) + 1.;           // g(lo) - P, rounded down
+                        const double a_hi = std::ceil(((double)h[a][c] - g.mn[a]) * g.k[a]) + 2. * P + 1.;   // g(hi) + P, rounded up
+                        if (!(a_lo >= 0. && a_hi <= QGRID_MAX && a_lo <= a_hi)) coop_data = false;
+                        w_lo |= (uint32_t)a_lo << (16 * c);
+                        w_hi |= (uint32_t)a_hi << (16 * c);
+                    }
+                    ql[a] = w_lo;
+                    qh[a] = w_hi;
+                }
+                NodeQ q{ql[0], ql[1], ql[2], qh[0], qh[1], qh[2], {nd.child[0], nd.child[1]}};
+                n2q[n] = q;
+                for (int c = 0; c < 2; c++) {
+                    const uint32_t r = nd.child[c];
+                    if ((r >> REF_TAG_SHIFT) == 0u) {
+                        st.push_back(r);
+                    } else if ((r >> REF_TAG_SHIFT) == 1u) {
+                        const uint32_t first = r & REF_LEAF_FIRST_MASK, cnt = ((r >> REF_LEAF_COUNT_SHIFT) & 7u) + 1u;
+                        for (uint32_t j = first; j < first + cnt; j++) {
+                            const uint32_t kp = ab.items[2 * j];
+                            if ((kp & NK_MASK) != NK_TRI) { coop_data = false; break; }
+                            const uint32_t t = kp >> NK_BITS;
+                            Tri32 tr{};
+                            const double* pre = &b.tripre[(size_t)t * 10];
+                            double v[3][3];
+                            for (int c3 = 0; c3 < 3; c3++)
+                                for (int a = 0; a < 3; a++) {
+                                    v[c3][a] = b.vpos[3 * (size_t)b.tris[4 * (size_t)t + c3] + a];
+                                    if (!is_f32(v[c3][a])) coop_data = false;
+                                }
+                            for (int a = 0; a < 3; a++) {
+                                tr.pa[a] = (float)v[0][a];
+                                tr.pb[a] = (float)v[1][a];
+                                tr.pc[a] = (float)v[2][a];
+                                // the lane forms pb - pa, pc - pa in f64: must be the hoisted record's values, bit for bit
+                                if (v[0][a] != pre[a] || v[1][a] - v[0][a] != pre[3 + a] || v[2][a] - v[0][a] != pre[6 + a]) coop_data = false;
+                            }
+                            tr.order = ab.items[2 * j + 1];
+                            tr.kp = kp;
+                            tri32[j] = tr;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (!coop_data) {
+        n2q.clear();
+        tri32.clear();
+        qgrid.clear();
+    }
+
     // hot part (read once per visited node): candidates for LDS residency
     v.off_meta = append(f.blob, b.meta);
     v.off_boxes = append(f.blob, b.boxes);
@@ -404,6 +521,9 @@ void flatten(rt_scene& s) {
     v.off_n2 = append(f.blob, ab.nodes);
     f.blob.resize((f.blob.size() + 15) & ~size_t(15));
     v.stage2_end = (uint32_t)f.blob.size();
+    v.off_n2q = append(f.blob, n2q);  // kernel 5's compact object-space data: never staged as a whole
+    v.off_tri32 = append(f.blob, tri32);
+    v.off_qgrid = append(f.blob, qgrid);
     v.n_nodes2 = (uint32_t)ab.nodes.size();
     v.accel_ok = ab.ok ? 1u : 0u;
     v.root2 = root2;
@@ -412,6 +532,8 @@ void flatten(rt_scene& s) {
     v.max_inst_nodes2 = max_inst_nodes;
     v.inst_depth2 = inst_depth;
     v.n_world_items2 = n_world_items;
+    v.coop_data_ok = coop_data ? 1u : 0u;
+    v.world_top2 = world_top;
     v.origin_limit2 = origin_limit;
     // cold part (read once per path segment, by the winning leaf only): always global
     v.off_sphere_mat = append(f.blob, b.sphere_mat);
@@ -449,6 +571,7 @@ void flatten(rt_scene& s) {
     in.accel_items = (int32_t)(ab.items.size() / 2);
     in.accel_instances = (int32_t)(ab.inst.size() / 2);
     in.accel_stack = (int32_t)v.stack2;
+    in.accel_compact = (int32_t)v.coop_data_ok;
     s.committed = true;
 }
 

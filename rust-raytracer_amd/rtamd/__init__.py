@@ -63,7 +63,7 @@ class rt_sppm_config(C.Structure):
 
 
 class rt_tuning(C.Structure):
-    _fields_ = [("no_lds", C.c_int32), ("top_nodes", C.c_int32), ("sub_spp", C.c_int32), ("reserved", C.c_int32),
+    _fields_ = [("no_lds", C.c_int32), ("top_nodes", C.c_int32), ("sub_spp", C.c_int32), ("coop_pool", C.c_int32),
                 ("max_leaf", C.c_int32), ("sppm_photon_capacity", C.c_int32), ("sppm_knn_candidates", C.c_int32),
                 ("sah_box_cost", C.c_double)]
 
@@ -78,7 +78,7 @@ OBJECT_TYPES = ("Sphere", "Rect", "Cube", "Triangle", "Mesh", "Transform", "Hita
 class rt_scene_info(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("n_nodes", "n_boxes", "n_spheres", "n_rects", "n_tris", "n_xforms", "n_materials",
                                          "n_textures", "n_verts", "max_depth", "committed", "reserved")] + [("bytes", C.c_uint64)] + \
-               [(n, C.c_int32) for n in ("accel_ok", "accel_nodes", "accel_items", "accel_instances", "accel_stack", "reserved2")]
+               [(n, C.c_int32) for n in ("accel_ok", "accel_nodes", "accel_items", "accel_instances", "accel_stack", "accel_compact")]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if not k.startswith("reserved")}

@@ -125,7 +125,7 @@ pub struct rt_tuning {
     pub no_lds: i32,
     pub top_nodes: i32,
     pub sub_spp: i32,
-    pub reserved: i32,
+    pub coop_pool: i32,
     pub max_leaf: i32,
     pub sppm_photon_capacity: i32,
     pub sppm_knn_candidates: i32,
@@ -163,7 +163,7 @@ pub struct rt_scene_info {
     pub accel_items: i32,
     pub accel_instances: i32,
     pub accel_stack: i32,
-    pub reserved2: i32,
+    pub accel_compact: i32,
 }
 
 #[link(name = "rtamd")]

@@ -417,6 +417,90 @@ def test_c4_first_hits_agree_between_traversals():
         assert len(bad) == 0, "kernel %d: %d rays differ, first %s" % (k, len(bad), rays[bad[0, 0]] if len(bad) else None)
 
 
+def _random_instance_scene(rng, B, meshes, mesh_fn):
+    """Cornell walls + light with 1..3 randomly placed, rotated and (non-uniformly) scaled mesh instances."""
+    from rtamd import shapes
+    P0, N0, I0 = meshes[0]
+    items = shapes.cornell_with_mesh(B, P0, N0, I0, scale=float(rng.uniform(60.0, 140.0)), translate=tuple(rng.uniform(150.0, 400.0, 3)),
+                                     rotate=tuple(rng.uniform(-180.0, 180.0, 3)))
+    grey = B.Lambertian(B.ConstantTexture((0.6, 0.6, 0.6)))
+    glass = B.Dielectric(1.5, B.ConstantTexture((1.0, 1.0, 1.0)))
+    for k, (P, N, I) in enumerate(meshes[1:]):
+        mesh = mesh_fn(B, P, N, I, glass if k == 0 else grey, 7 + k)
+        items.append(B.Transform(tuple(rng.uniform(-180.0, 180.0, 3)), tuple(rng.uniform(20.0, 90.0, 3)), tuple(rng.uniform(100.0, 450.0, 3)), mesh))
+    return items
+
+
+def test_coop_kernel_equals_kernel2_on_random_instances():
+    """kernel 5 (cooperative instance service: 16-bit grid boxes, f32 triangle records, parked paths) against kernel 2 on
+    random placements: rotations, non-uniform scales, overlapping instances, glass (paths re-enter the mesh), 1..3 instances."""
+    import rtamd
+    from rtamd import shapes
+    rng = np.random.default_rng(505)
+    cam = _c4_scene()["cam"]
+    for trial in range(6):
+        meshes = [shapes.torus(int(rng.integers(6, 40)), int(rng.integers(8, 60))) for _ in range(int(rng.integers(1, 4)))]
+        state = rng.bit_generator.state
+        w = rtamd.World()
+        w.new(_random_instance_scene(rng, w, meshes, lambda B, P, N, I, m, sd: B.Mesh(P, N, I, m, bvh_seed=sd)), bvh_seed=trial)
+        assert w.info()["accel_compact"] == 1
+        a, sa = w.render(cam, width=96, height=96, spp=6, seed=trial, kernel=2)
+        b, sb = w.render(cam, width=96, height=96, spp=6, seed=trial, kernel=5)
+        assert sb["kernel_used"] == 5 and sa["kernel_used"] == 2
+        _assert_same(b, a, "random instances, trial %d" % trial)
+        assert a.max() > 0
+        if trial == 0:  # and against the oracle once
+            import oracle
+            rng.bit_generator.state = state
+            o = oracle.Scene()
+            o.World(_random_instance_scene(rng, o, meshes, lambda B, P, N, I, m, sd: B.Mesh(P, N, I, m, sd)), trial)
+            o.Camera((278, 278, -800), (278, 278, 278), (0, 1, 0), 50, 1.0, 0.0, 10.0)
+            exp, _ = o.render(32, 32, 2, seed=9)
+            img, _ = w.render(cam, width=32, height=32, spp=2, seed=9, kernel=5)
+            _assert_same(img, exp, "random instances against the oracle")
+
+
+def test_coop_kernel_full_size_equals_kernel2_at_more_samples():
+    """C4 at 256 x 256 x 8 spp: half a million paths through the 102,400-triangle instance, kernel 5 == kernel 2 bit for bit."""
+    c = _c4_scene()
+    a, _ = c["world"].render(c["cam"], width=256, height=256, spp=8, seed=3, kernel=2)
+    b, st = c["world"].render(c["cam"], width=256, height=256, spp=8, seed=3, kernel=5)
+    assert st["kernel_used"] == 5
+    _assert_same(b, a, "C4 256x256x8, kernel 5 against kernel 2")
+
+
+def test_coop_kernel_pool_exhaustion_walks_in_the_lane(tuning):
+    """with only 32 parked-path slots per workgroup most deferred walks take the in-lane fallback (coop_walk_inline) and the
+    rest trickle through the rings: same image."""
+    c = _c4_scene()
+    exp = c["exp"]
+    tuning(coop_pool=32)
+    img, st = c["world"].render(c["cam"], width=64, height=64, spp=4, seed=1, kernel=5)
+    assert st["kernel_used"] == 5
+    _assert_same(img, exp, "C4, kernel 5 with 32 pool slots")
+    tuning(coop_pool=1)
+    img, _ = c["world"].render(c["cam"], width=64, height=64, spp=4, seed=1, kernel=5)
+    _assert_same(img, exp, "C4, kernel 5 with one pool slot")
+
+
+def test_coop_kernel_needs_f32_mesh_vertices():
+    """vertices that are not f32 values (possible through rt_mesh_data / Mesh(...), never through the OBJ loader) have no compact
+    copy: automatic selection stays on kernel 2 and asking for kernel 5 is refused."""
+    import rtamd
+    from rtamd import shapes
+    P, N, I = shapes.torus(160, 320)
+    P = P * (1.0 + 2.0 ** -40)   # no longer representable in f32
+    w = rtamd.World()
+    w.new(shapes.cornell_with_mesh(w, P, N, I), bvh_seed=1)
+    assert w.info()["accel_compact"] == 0 and w.info()["accel_ok"] == 1
+    cam = _c4_scene()["cam"]
+    _, st = w.render(cam, width=32, height=32, spp=2, seed=1)
+    assert st["kernel_used"] == 2
+    with pytest.raises(rtamd.RtError) as e:
+        w.render(cam, width=32, height=32, spp=2, seed=1, kernel=5)
+    assert e.value.code == -10   # RT_ERR_UNSUPPORTED
+
+
 @pytest.mark.parametrize("kernel", [1, 2])
 def test_many_spheres_outside_lds_bit_exact(kernel):
     """30,000 spheres: the sphere-only kernels with the scene in L2/HBM instead of LDS (variants <LDS=false, GENERAL=false>)."""
