@@ -41,6 +41,7 @@ struct Builder {
         std::map<int, size_t> of;  // object id -> item slot (a re-emitted object keeps one slot, latest order)
         uint32_t xform = 0;
         const double* Minv = nullptr;
+        const double* M = nullptr;
     };
     std::vector<InstCtx> actx{1};
     std::vector<size_t> ctx_stack{0};
@@ -159,6 +160,7 @@ struct Builder {
                     actx.emplace_back();
                     actx.back().xform = it->second;
                     actx.back().Minv = o.Minv;
+                    actx.back().M = o.M;
                     ci = ctx_of_xform.emplace(id, actx.size() - 1).first;
                 }
                 uint32_t inst_index = (uint32_t)(ci->second - 1);
@@ -287,6 +289,38 @@ void flatten(rt_scene& s) {
     uint32_t root2 = REF_DONE, max_inst_nodes = 0, inst_depth = 0, n_world_items = 0;
     std::vector<double> inst_oo;  // per instance: bound of |object-space ray origin|
     double origin_limit = 0.;
+    // An instance's item in the enclosing space carries the Transform's own bounding box (the box of the 8 transformed corners
+    // of the child's box, transform.rs:104-150): loose for a rotated mesh.  For culling, the union of the transformed boxes of the
+    // instance's ITEMS is as valid (affine images of the items lie inside it; the f64 rounding of M * corner is orders of
+    // magnitude below the pad added at build time) and tighter: fewer rays enter the object-space BVH for nothing.
+    for (size_t i = 1; b.accel_ok && i < b.actx.size(); i++) {
+        const auto& c = b.actx[i];
+        if (c.items.empty() || !c.M) continue;
+        Box tb;
+        for (int a = 0; a < 3; a++) { tb.mn[a] = INFINITY; tb.mx[a] = -INFINITY; }
+        for (const auto& it : c.items)
+            for (int corner = 0; corner < 8; corner++) {
+                const double x = (corner & 1) ? it.box.mx[0] : it.box.mn[0], y = (corner & 2) ? it.box.mx[1] : it.box.mn[1],
+                             z = (corner & 4) ? it.box.mx[2] : it.box.mn[2];
+                for (int a = 0; a < 3; a++) {
+                    const double w = c.M[4 * a] * x + c.M[4 * a + 1] * y + c.M[4 * a + 2] * z + c.M[4 * a + 3];
+                    tb.mn[a] = std::fmin(tb.mn[a], w);
+                    tb.mx[a] = std::fmax(tb.mx[a], w);
+                }
+            }
+        bool finite = true;
+        for (int a = 0; a < 3; a++) finite = finite && std::isfinite(tb.mn[a]) && std::isfinite(tb.mx[a]);
+        if (!finite) continue;
+        const uint32_t want = NK_INSTANCE | ((uint32_t)(i - 1) << NK_BITS);
+        for (auto& pc : b.actx)
+            for (auto& it : pc.items)
+                if (it.kp == want)
+                    for (int a = 0; a < 3; a++) {  // never larger than the Transform's own box; a margin of 2^-40 of its size for the rounding
+                        const double m = std::ldexp(std::fabs(tb.mx[a]) + std::fabs(tb.mn[a]), -40);
+                        it.box.mn[a] = std::fmax(it.box.mn[a], tb.mn[a] - m);
+                        it.box.mx[a] = std::fmin(it.box.mx[a], tb.mx[a] + m);
+                    }
+    }
     if (ab.ok && !b.actx[0].items.empty()) {
         // E_w: largest |coordinate| of the world items; boxes are padded so that rounding a ray origin with
         // max-abs coordinate <= 64*E_w to f32 (relative error 2^-24) can never make the f32 slab test cull a box
