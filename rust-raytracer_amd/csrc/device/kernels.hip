@@ -1214,7 +1214,7 @@ DEV double bitsd(uint64_t x) { return __longlong_as_double((long long)x); }
 #ifdef RTAMD_COOP_STATS  // tools-only build (tools/build_variant.sh stats -DRTAMD_COOP_STATS): schedule counters of pt_kernel_coop
 __device__ unsigned long long g_coop_stats[16];
 struct CoopStats {
-    unsigned long long ev[6] = {0, 0, 0, 0, 0, 0}, ln[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long ev[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ln[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = 0;  // shader-clock cycles per phase of the main loop
 };
 __device__ unsigned long long g_coop_time[8];
@@ -1619,6 +1619,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
     Acc A = make_acc(sv.base, sv.base, sv);
     // world-level tables into LDS (coop_world_bytes, flat.h); A then is the view the world-space walk and the shading use
     uint32_t lds_inst2 = 0, lds_xforms = 0, lds_qgrid = 0;
+    const double* qgrid_lds = nullptr;
     {
         auto stage = [&](uint32_t off, uint32_t bytes) {
             const uint4* src = (const uint4*)(sv.base + off);
@@ -1636,7 +1637,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
         A.inst2 = (const uint2*)stage(sv.off_inst2, 8u * sv.n_inst2);
         A.items2 = (const uint2*)stage(sv.off_items2, 8u * sv.n_world_items2);  // world leaves only: instances are deferred
         lds_qgrid = staged;
-        stage(sv.off_qgrid, (uint32_t)sizeof(QGrid) * sv.n_inst2);
+        qgrid_lds = (const double*)stage(sv.off_qgrid, (uint32_t)sizeof(QGrid) * sv.n_inst2);
     }
     const uint32_t lds_top = staged;
     if (rk.n_top > 0) {
@@ -1647,7 +1648,8 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
         A.n2_top_count = (uint32_t)rk.n_top;
         staged += (uint32_t)rk.n_top * (uint32_t)sizeof(Node2);
     }
-    const uint32_t lds_topq = staged;  // the serving waves' cache: the shallowest NodeQ of every object-space BVH
+    const uint32_t lds_topq = staged;  // the shallowest NodeQ of every object-space BVH: for the serving waves and for the entry walk
+    const uint4* n2q_lds = (const uint4*)(smem + staged);
     {
         const uint4* src = (const uint4*)(sv.base + sv.off_n2q);
         uint4* dst = (uint4*)(smem + staged);
@@ -1771,48 +1773,99 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
                     out_slot = ((uint32_t)wave << 12) | (((uint32_t)cur_slot * (uint32_t)UNIT_SPP + (uint32_t)(k >> 6)) * (uint32_t)TILE_PIX + (uint32_t)pix);
                     alive = true;
                     ready = false;
+                    pend = 0u;
                 }
             }
         }
         COOP_TIME(0);
         // ---- world-space walk of the lanes that start a segment, instances deferred ----
-        if (__ballot(alive && !ready) != 0ull) COOP_STAT(2, __ballot(alive && !ready));
-        if (alive && !ready) {
-            pend = 0u;
+        if (__ballot(alive && !ready && pend == 0u) != 0ull) COOP_STAT(2, __ballot(alive && !ready && pend == 0u));
+        if (alive && !ready && pend == 0u) {  // (pend != 0: a path between two deferred instances of one segment)
             h = traverse2<true, true>(A, stk, stk_stride, o, d, rk.t_min, INFINITY, &pend);
             if (pend == 0u) ready = true;
         }
         COOP_TIME(1);
-        // ---- park the paths with a deferred instance ----
+        // ---- enter the first deferred instance of each such path: the top of its BVH is in LDS (NodeQ cache), so the lane walks
+        //      it here; most rays that only clip the instance's box end there and never leave the lane.  Where the walk needs a
+        //      node or a leaf from memory it stops, and what is left of it (node + stack) is parked as a suspended walk ----
         {
-            const bool want = alive && !ready;
+            const bool want = alive && !ready;  // (pend != 0)
             const uint64_t mw = __ballot(want);
             if (mw != 0ull) {
-                const int id = ring_pop(C.fq, mw, lane, lanemask_lt);
-                const bool park = want && id >= 0;
+                uint32_t ent_cur = REF_DONE, ni = 0u;
+                int ent_sp = 0;
+                if (want) {
+                    ni = (uint32_t)(__ffs((int)pend) - 1);
+                    const double* Minv = A.xforms + 32 * A.inst2[ni].x;
+                    const D3 oo = xf_point(Minv, o), dd = xf_dir(Minv, d);
+                    const double* g = qgrid_lds + 8 * ni;
+                    const D3 og = mk((oo.x - g[0]) * g[3] + g[6], (oo.y - g[1]) * g[4] + g[6], (oo.z - g[2]) * g[5] + g[6]);
+                    const D3 dg = mk(dd.x * g[3], dd.y * g[4], dd.z * g[5]);
+                    const Ray32 r = make_ray32(og, rcp3(dg), rk.t_min, h.t);
+                    ent_cur = A.inst2[ni].y;
+                    while ((ent_cur >> REF_TAG_SHIFT) == 0u && ent_cur < (uint32_t)rk.n_topq) {
+                        const uint4* p = n2q_lds + 2 * ent_cur;
+                        const uint4 u0 = p[0], u1 = p[1];
+                        float e0, e1;
+                        const bool h0 = box32((float)(u0.x & 0xffffu), (float)(u0.y & 0xffffu), (float)(u0.z & 0xffffu), (float)(u0.w & 0xffffu),
+                                              (float)(u1.x & 0xffffu), (float)(u1.y & 0xffffu), r, e0);
+                        const bool h1 = box32((float)(u0.x >> 16), (float)(u0.y >> 16), (float)(u0.z >> 16), (float)(u0.w >> 16),
+                                              (float)(u1.x >> 16), (float)(u1.y >> 16), r, e1);
+                        const uint32_t c0 = u1.z, c1 = u1.w;
+                        if (h0 && h1) {
+                            const bool swap = e1 < e0;
+                            stk[ent_sp] = swap ? c0 : c1;
+                            ent_sp += stk_stride;
+                            ent_cur = swap ? c1 : c0;
+                        } else if (h0) {
+                            ent_cur = c0;
+                        } else if (h1) {
+                            ent_cur = c1;
+                        } else if (ent_sp > 0) {
+                            ent_sp -= stk_stride;
+                            ent_cur = stk[ent_sp];
+                        } else {
+                            ent_cur = REF_DONE;
+                        }
+                    }
+                    if (ent_cur == REF_DONE) {  // nothing of this instance within reach: next one (next iteration), or shade
+                        pend &= pend - 1u;
+                        if (pend == 0u) ready = true;
+                    }
+                }
+                const bool need = want && ent_cur != REF_DONE;
+                const int id = ring_pop(C.fq, __ballot(need), lane, lanemask_lt);
+                const bool park = need && id >= 0;
                 if (park) {
-                    const uint32_t ni = (uint32_t)(__ffs((int)pend) - 1);
                     pend &= pend - 1u;
+                    const int n = ent_sp / stk_stride;
                     uint64_t* q = pool_mem + (size_t)COOP_REC * (size_t)id;
                     st_unit(q, 0, dbits(o.x), dbits(o.y));
                     st_unit(q, 1, dbits(o.z), dbits(d.x));
                     st_unit(q, 2, dbits(d.y), dbits(d.z));
                     st_unit(q, 3, dbits(h.t), ((uint64_t)h.kp << 32) | (uint64_t)(uint32_t)h.node);
-                    st_unit(q, 4, ((uint64_t)A.inst2[ni].y << 32) | (uint64_t)(uint32_t)(h.xf + 1),
-                            ((uint64_t)pend << 32) | (uint64_t)(ni << 16) | (uint64_t)out_slot);  // saved-stack count 0: a fresh request
+                    st_unit(q, 4, ((uint64_t)ent_cur << 32) | (uint64_t)(uint32_t)(h.xf + 1),
+                            ((uint64_t)pend << 32) | ((uint64_t)(n + 1) << 24) | (uint64_t)(ni << 16) | (uint64_t)out_slot);  // a suspended walk
+                    st_unit(q, 5, dbits(h.t), (uint64_t)(uint32_t)h.node);  // its best so far: what the world-space walk found
                     st_unit(q, 6, dbits(beta.x), dbits(beta.y));
                     st_unit(q, 7, dbits(beta.z), dbits(L.x));
                     st_unit(q, 8, dbits(L.y), dbits(L.z));
                     st_unit(q, 9, rng.s, ((uint64_t)(uint32_t)depth << 32) | (uint64_t)(uint32_t)pix_id);
+                    for (int i = 0; i < n; i += 4) {
+                        const uint64_t e0 = stk[i * stk_stride], e1 = (i + 1 < n) ? stk[(i + 1) * stk_stride] : 0u;
+                        const uint64_t e2 = (i + 2 < n) ? stk[(i + 2) * stk_stride] : 0u, e3 = (i + 3 < n) ? stk[(i + 3) * stk_stride] : 0u;
+                        st_unit(q, 10 + (i >> 2), e0 | (e1 << 32), e2 | (e3 << 32));
+                    }
                     alive = false;
                 }
                 const uint64_t mp = __ballot(park);
                 if (mp != 0ull && lane == __ffsll((long long)mp) - 1) atomicAdd(C.n_parked, (uint32_t)__popcll(mp));
                 ring_push(C.rq, park, (uint32_t)id, lane, lanemask_lt, true);  // (publishing an iteration later, behind the stores' round trip: no gain)
                 // pool exhausted (rare): walk the deferred instances in this lane, sparsely, as the plain kernel does
-                if (__ballot(want && id < 0) != 0ull) {
-                    if (want && id < 0) {
+                if (__ballot(need && id < 0) != 0ull) {
+                    if (need && id < 0) {
                         h = coop_walk_inline(cargs, smem, stk, o, d, h, pend);
+                        pend = 0u;
                         ready = true;
                     }
                 }
@@ -1825,7 +1878,8 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
             if ((int)__popcll(fr) < REGEN_MIN && fr != ~0ull) fr = 0ull;
             if (fr != 0ull && ring_len(C.aq) != 0u) {
                 const int id = ring_pop(C.aq, fr, lane, lanemask_lt);
-                bool repost = false, freed = false;
+                COOP_STAT(6, __ballot(id >= 0));
+                bool repost = false, freed = false, hit_inside = false;
                 if (id >= 0) {
                     uint64_t* q = pool_mem + (size_t)COOP_REC * (size_t)id;
                     // the whole record in one round trip (a re-posted path wastes the second half; rare: several instances on one ray)
@@ -1838,6 +1892,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
                     h.kp = (uint32_t)(u3.y >> 32);
                     h.xf = (int)(uint32_t)u4.x - 1;
                     if ((int)(uint32_t)u5.y != h.node) {  // the walk accepted a candidate of this instance
+                        hit_inside = true;
                         h.t = bitsd(u5.x);
                         h.node = (int)(uint32_t)u5.y;
                         h.kp = (uint32_t)(u5.y >> 32);
@@ -1865,6 +1920,8 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
                         freed = true;
                     }
                 }
+                COOP_STAT(7, __ballot(hit_inside));
+                (void)hit_inside;
                 ring_push(C.rq, repost, (uint32_t)id, lane, lanemask_lt, true);
                 {
                     const uint64_t mf = __ballot(freed);
@@ -1908,6 +1965,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
                 }
             }
             ready = false;
+            pend = 0u;
             if (done) {  // into the ring slot of the wave that generated the path; its unit counter moves next iteration
                 double* dst = bring + (size_t)(out_slot >> 12) * RING_UNITS * UNIT_DOUBLES + 3 * (size_t)(out_slot & 0xfffu);
                 dst[0] = L.x;
@@ -1952,7 +2010,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
     }
 #ifdef RTAMD_COOP_STATS
     if (lane == 0) {
-        for (int i = 0; i < 6; i++) {
+        for (int i = 0; i < 8; i++) {
             atomicAdd(&g_coop_stats[2 * i], cs.ev[i]);
             atomicAdd(&g_coop_stats[2 * i + 1], cs.ln[i]);
         }
@@ -2373,8 +2431,8 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
     if (kernel == 5) {
         unsigned long long hs[16], z[16] = {0};
         HIP_CHECK(hipMemcpyFromSymbol(hs, HIP_SYMBOL(g_coop_stats), sizeof(hs)));
-        const char* names[6] = {"serve rounds (lanes at start)", "serve passes (busy lanes)", "walk phases (lanes)", "shade phases (lanes)", "suspensions (walks)", "idle sleeps"};
-        for (int i = 0; i < 6; i++)
+        const char* names[8] = {"serve rounds (lanes at start)", "serve passes (busy lanes)", "walk phases (lanes)", "shade phases (lanes)", "suspensions (walks)", "idle sleeps", "adoptions (paths)", "... that hit inside the instance"};
+        for (int i = 0; i < 8; i++)
             fprintf(stderr, "[coop stats] %-32s %12llu  lanes %14llu  (%.1f per event)\n", names[i], hs[2 * i], hs[2 * i + 1],
                     hs[2 * i] ? (double)hs[2 * i + 1] / (double)hs[2 * i] : 0.);
         HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_coop_stats), z, sizeof(z)));
