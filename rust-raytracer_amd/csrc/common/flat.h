@@ -123,6 +123,7 @@ struct FlatView {  // by-value kernel argument
     uint32_t off_tri32;          // Tri32 per item index (object-space leaves only)
     uint32_t off_qgrid;          // QGrid per instance
     uint32_t world_top2;         // world-space BVH nodes all have an index below this (the Node2 array is depth-sorted)
+    uint32_t world_depth2;       // depth of the world-space BVH (kernel 5 walks it and the object-space BVHs separately)
 };
 
 // ---------------------------------------------------------------------------

@@ -192,6 +192,7 @@ struct RenderK {
     int n_top;               // kernel 2 with the scene in L2/HBM: number of (depth-sorted) Node2 cached in LDS
     int n_topq;              // kernel 5: number of NodeQ cached in LDS for the serving waves
     int coop_pool;           // kernel 5: parked-path slots in use (<= COOP_POOL)
+    int coop_stack;          // kernel 5: stack entries per lane
 };
 
 // ------------------------------------------------------ intersection ------
@@ -824,7 +825,9 @@ DEV bool mixture_step(const Acc& A, const Rec& rec, Rng& rng, D3 att, D3& beta, 
 // with the smallest index is at the head of its wave's ring and its predecessor is folded.
 // Accumulator and ticket cross waves on different XCDs (L2s are not coherent): both are accessed ONLY with 8-/4-byte agent-scope
 // atomics (served at the memory side), the folding wave drains its stores (s_waitcnt vmcnt(0)) before it advances the ticket.
-static const int REGEN_MIN = 8;
+#ifndef REGEN_MIN
+#define REGEN_MIN 8
+#endif
 static const int UNIT_SPP = 8;                              // sample indices per work unit, at most
 #ifndef RING_UNITS
 #define RING_UNITS 6                                         // unit buffers per wave (two jobs of 2 units and some slack)
@@ -1177,10 +1180,10 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
 // path, and a finished path stores its sample into the ring slot of the wave that generated it (any wave of the workgroup
 // may finish it; the unit's LDS counter is decremented one iteration later, behind a drained store).  Bit-identical images.
 #ifndef COOP_POOL
-#define COOP_POOL 2048      // parked paths per workgroup (power of two)
+#define COOP_POOL 1024      // parked paths per workgroup (power of two; 2048: -1 %, the LDS is worth more as node cache)
 #endif
 #ifndef COOP_BATCH
-#define COOP_BATCH 128      // a wave starts serving once this many requests wait (64: -2 %)
+#define COOP_BATCH 32       // a wave starts serving once this many requests wait (16: -3 %, 64: -2 %, 128: -5 %)
 #endif
 #ifndef COOP_REFILL_TH
 #define COOP_REFILL_TH 48   // a serving wave goes back for more requests when fewer lanes than this still walk
@@ -1243,8 +1246,8 @@ __device__ unsigned long long g_coop_time[8];
 #endif
 
 DEV D3 rcp3(D3 d) { return mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z); }
-struct CoopRing {  // multi-producer multi-consumer ring of slot ids in LDS; entries are id + 1, 0 = not yet written
-    volatile uint32_t* buf;
+struct CoopRing {  // multi-producer multi-consumer ring of slot ids in LDS; entries are id + 1 (16 bit), 0 = not yet written
+    volatile uint16_t* buf;
     uint32_t* ht;  // {head, tail}: monotonic counters
 };
 DEV uint32_t lds_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -1258,7 +1261,7 @@ DEV void ring_push(const CoopRing& R, bool push, uint32_t id, int lane, uint64_t
     if (lane == leader) base = atomicAdd(&R.ht[1], (uint32_t)__popcll(m));
     base = __shfl(base, leader);
     if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (push) R.buf[(base + (uint32_t)__popcll(m & lanemask_lt)) & (COOP_POOL - 1)] = id + 1u;
+    if (push) R.buf[(base + (uint32_t)__popcll(m & lanemask_lt)) & (COOP_POOL - 1)] = (uint16_t)(id + 1u);
 }
 // pop up to popcount(want) ids; lanes of `want` that get one return it, the others return -1
 DEV int ring_pop(const CoopRing& R, uint64_t want, int lane, uint64_t lanemask_lt) {
@@ -1284,7 +1287,7 @@ DEV int ring_pop(const CoopRing& R, uint64_t want, int lane, uint64_t lanemask_l
         const uint32_t slot = (h0 + (uint32_t)rank) & (COOP_POOL - 1);
         uint32_t v;
         do { v = R.buf[slot]; } while (v == 0u);  // its producer reserved the slot and writes it within a few instructions
-        R.buf[slot] = 0u;
+        R.buf[slot] = (uint16_t)0;
         id = (int)v - 1;
     }
     return id;
@@ -1470,11 +1473,11 @@ DEV CoopCtx coop_ctx(const CoopArgs* args_generic, char* lds0_generic) {  // lds
     X.A.qgrid = (const double*)(lds0 + rfl(ga->lds_qgrid));
     X.A.n2q_top = (const uint4*)(lds0 + rfl(ga->lds_topq));
     X.A.n2q_top_count = rfl(ga->n_topq);
-    uint32_t* cb = (uint32_t*)(lds0 + rfl(ga->lds_coop));
+    uint16_t* cb = (uint16_t*)(lds0 + rfl(ga->lds_coop));
     X.C.rq.buf = cb;
     X.C.aq.buf = cb + COOP_POOL;
     X.C.fq.buf = cb + 2 * COOP_POOL;
-    uint32_t* cnt = cb + 3 * COOP_POOL;
+    uint32_t* cnt = (uint32_t*)(cb + 3 * COOP_POOL);
     X.C.rq.ht = cnt;
     X.C.aq.ht = cnt + 2;
     X.C.fq.ht = cnt + 4;
@@ -1661,25 +1664,25 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
     const int lane = threadIdx.x & 63;
     const uint64_t lanemask_lt = (1ull << lane) - 1ull;
     const int wave = threadIdx.x >> 6;
-    uint32_t* book = (uint32_t*)(smem + staged) + (size_t)sv.stack2 * PT_BLOCK;
+    uint32_t* book = (uint32_t*)(smem + staged) + (size_t)rk.coop_stack * PT_BLOCK;  // stacks: max(world depth, object-space depth) + 2 entries
     uint32_t* rmeta = book + (size_t)wave * RING_UNITS * 4;
     uint32_t* wst = book + (size_t)(PT_BLOCK / 64) * RING_UNITS * 4 + (size_t)wave * 8;
     int* cfg = (int*)(book + (size_t)(PT_BLOCK / 64) * (RING_UNITS * 4 + 8));
-    uint32_t* coop_base = (uint32_t*)(cfg + CFG_WORDS);
-    CoopArgs* cargs = (CoopArgs*)(coop_base + 3 * COOP_POOL + 8);
+    uint16_t* coop_base = (uint16_t*)(cfg + CFG_WORDS);
+    uint32_t* cnt = (uint32_t*)(coop_base + 3 * COOP_POOL);
+    CoopArgs* cargs = (CoopArgs*)(cnt + 8);
     CoopLds C;
     C.rq.buf = coop_base;
     C.aq.buf = coop_base + COOP_POOL;
     C.fq.buf = coop_base + 2 * COOP_POOL;
-    uint32_t* cnt = coop_base + 3 * COOP_POOL;
     C.rq.ht = cnt;
     C.aq.ht = cnt + 2;
     C.fq.ht = cnt + 4;
     C.n_parked = cnt + 6;
     for (uint32_t i = threadIdx.x; i < (uint32_t)COOP_POOL; i += blockDim.x) {
-        C.rq.buf[i] = 0u;
-        C.aq.buf[i] = 0u;
-        C.fq.buf[i] = i < (uint32_t)rk.coop_pool ? i + 1u : 0u;  // every pool slot in use is free
+        C.rq.buf[i] = (uint16_t)0;
+        C.aq.buf[i] = (uint16_t)0;
+        C.fq.buf[i] = (uint16_t)(i < (uint32_t)rk.coop_pool ? i + 1u : 0u);  // every pool slot in use is free
     }
     if (threadIdx.x < 8) cnt[threadIdx.x] = (threadIdx.x == 5) ? (uint32_t)rk.coop_pool : 0u;  // FQ tail = number of slots
     if (lane < 8) wst[lane] = (lane == 6) ? 1u : 0u;
@@ -2294,10 +2297,12 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
     const bool accel2_usable = view.accel_ok && camera_ok && stack2_bytes <= lds_max;  // per-lane stacks live in LDS
     const bool media = (view.kinds_mask & (1u << NK_MEDIUM_BEGIN)) != 0;               // flatten.cpp: such scenes have no accel
     // kernel 5 = kernel 2's BVH with the cooperative instance service (pt_kernel_coop): for scenes with LARGE mesh instances
+    const uint32_t stack5 = std::max(view.world_depth2, view.inst_depth2) + 2u;  // the two walks of kernel 5 never share a stack
+    const size_t stack5_bytes = (size_t)stack5 * PT_BLOCK * sizeof(uint32_t);
     const size_t coop_world = coop_world_bytes(view);  // world-level tables, always in LDS for this kernel
-    const size_t coop_lds = (size_t)(3 * COOP_POOL + 8) * sizeof(uint32_t) + ((sizeof(CoopArgs) + 15) & ~size_t(15)) + coop_world;  // + three rings of pool-slot ids, counters, argument block
+    const size_t coop_lds = (size_t)3 * COOP_POOL * sizeof(uint16_t) + 8 * sizeof(uint32_t) + ((sizeof(CoopArgs) + 15) & ~size_t(15)) + coop_world;  // + three rings of pool-slot ids, counters, argument block
     const bool coop_usable = accel2_usable && general && !media && view.coop_data_ok != 0 && view.n_inst2 >= 1 && view.n_inst2 <= (uint32_t)COOP_MAX_INST &&
-                             view.inst_depth2 <= (uint32_t)COOP_STACK_MAX && coop_world <= 16384 && stack2_bytes + coop_lds <= lds_max && plan.max_depth < (1 << 24);
+                             view.inst_depth2 <= (uint32_t)COOP_STACK_MAX && coop_world <= 16384 && stack5_bytes + coop_lds <= lds_max && plan.max_depth < (1 << 24);
     int kernel = plan.kernel;
     // auto: the cooperative kernel from ~8k object-space nodes per instance (measured on the Cornell box + torus instance, 64 spp:
     // 6,400 triangles / 4.3k nodes 597 vs 606 Msamples/s for kernel 2, 25,600 / 17k 557 vs 508, 102,400 / 68k 508 vs 434, 409,600 437 vs 383)
@@ -2308,7 +2313,7 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
         throw RtError(RT_ERR_UNSUPPORTED, "kernel 2 requested but no usable accel for this scene/camera (unbounded item, depth overflow, stacks "
                                           "larger than LDS, negative t_min, or camera farther than 64x the scene extent); use kernel 0/1");
     const size_t ring_meta = ((size_t)(PT_BLOCK / 64) * (RING_UNITS * 4 + 8) + CFG_WORDS) * sizeof(uint32_t);  // ring / job bookkeeping, behind the stacks
-    const size_t stack_bytes = ((kernel == 2 || kernel == 5) ? stack2_bytes : 0) + ring_meta + ((kernel == 5) ? coop_lds : 0);
+    const size_t stack_bytes = ((kernel == 2) ? stack2_bytes : (kernel == 5) ? stack5_bytes : 0) + ring_meta + ((kernel == 5) ? coop_lds : 0);
     const size_t hot_bytes = (kernel == 2 || kernel == 5) ? hot2 : hot1;
     const bool lds = hot_bytes > 0 && hot_bytes + stack_bytes <= lds_max && !tuning().no_lds && kernel != 5;  // kernel 5: scene in L2/HBM always
     const int integ = plan.integrator;
@@ -2382,6 +2387,7 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
         rk.sppm_est = plan.sppm_est;
         rk.n_top = n_top;
         rk.n_topq = n_topq;
+        rk.coop_stack = (int)stack5;
         rk.coop_pool = tuning().coop_pool > 0 ? std::min(tuning().coop_pool, (int)COOP_POOL) : (int)COOP_POOL;
         HIP_CHECK(hipMemsetAsync(counter.p, 0, sizeof(unsigned int), stream));
         HIP_CHECK(hipMemsetAsync(tickets.p, 0, std::max<size_t>(16, (size_t)plan.tiles_owned * sizeof(unsigned int)), stream));

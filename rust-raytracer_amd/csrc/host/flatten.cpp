@@ -286,7 +286,7 @@ void flatten(rt_scene& s) {
     // ---- accel (kernel 2) ----
     AccelBuild ab;
     ab.ok = b.accel_ok;
-    uint32_t root2 = REF_DONE, max_inst_nodes = 0, inst_depth = 0, n_world_items = 0;
+    uint32_t root2 = REF_DONE, max_inst_nodes = 0, inst_depth = 0, n_world_items = 0, world_depth = 0;
     std::vector<double> inst_oo;  // per instance: bound of |object-space ray origin|
     double origin_limit = 0.;
     // An instance's item in the enclosing space carries the Transform's own bounding box (the box of the 8 transformed corners
@@ -338,6 +338,7 @@ void flatten(rt_scene& s) {
             root2 = accel_build_bvh(ab, b.actx[0].items, pad_w, 0);
             const int depth_tlas = ab.max_depth;
             n_world_items = (uint32_t)(ab.items.size() / 2);
+            world_depth = (uint32_t)depth_tlas;
             ab.inst.assign(2 * (b.actx.size() - 1), 0u);
             for (size_t i = 1; ab.ok && i < b.actx.size(); i++) {
                 auto& c = b.actx[i];
@@ -568,6 +569,7 @@ void flatten(rt_scene& s) {
     v.n_world_items2 = n_world_items;
     v.coop_data_ok = coop_data ? 1u : 0u;
     v.world_top2 = world_top;
+    v.world_depth2 = world_depth;
     v.origin_limit2 = origin_limit;
     // cold part (read once per path segment, by the winning leaf only): always global
     v.off_sphere_mat = append(f.blob, b.sphere_mat);
