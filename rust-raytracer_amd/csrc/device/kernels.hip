@@ -1188,6 +1188,9 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
 #ifndef COOP_REFILL_TH
 #define COOP_REFILL_TH 48   // a serving wave goes back for more requests when fewer lanes than this still walk
 #endif
+#ifndef COOP_ENTRY_NODES
+#define COOP_ENTRY_NODES 64  // depth-sorted NodeQ indices below this are walked by the parking lane itself
+#endif
 #ifndef COOP_SUSPEND_TH
 #define COOP_SUSPEND_TH 20  // ... and suspends its walks when fewer than this are left and no request waits
 #endif
@@ -1653,6 +1656,8 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
     }
     const uint32_t lds_topq = staged;  // the shallowest NodeQ of every object-space BVH: for the serving waves and for the entry walk
     const uint4* n2q_lds = (const uint4*)(smem + staged);
+    // the entry walk stays in the first COOP_ENTRY_NODES cached nodes (measured: 16 / 64 nodes 870, 256 866, 1024 860, all cached 856 Msamples/s)
+    const uint32_t entry_top = min((uint32_t)rk.n_topq, (uint32_t)COOP_ENTRY_NODES);
     {
         const uint4* src = (const uint4*)(sv.base + sv.off_n2q);
         uint4* dst = (uint4*)(smem + staged);
@@ -1806,7 +1811,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
                     const D3 dg = mk(dd.x * g[3], dd.y * g[4], dd.z * g[5]);
                     const Ray32 r = make_ray32(og, rcp3(dg), rk.t_min, h.t);
                     ent_cur = A.inst2[ni].y;
-                    while ((ent_cur >> REF_TAG_SHIFT) == 0u && ent_cur < (uint32_t)rk.n_topq) {
+                    while ((ent_cur >> REF_TAG_SHIFT) == 0u && ent_cur < entry_top) {
                         const uint4* p = n2q_lds + 2 * ent_cur;
                         const uint4 u0 = p[0], u1 = p[1];
                         float e0, e1;

@@ -14,4 +14,5 @@ w = rtamd.World(); w.new(shapes.cornell_with_mesh(w, P, N, I), bvh_seed=1)
 cam = rtamd.Camera(((278, 278, -800), (278, 278, 278)), (0, 1, 0), 50, 1.0, 0.0, 10.0)
 w.render(cam, width=1200, height=1200, spp=2, seed=1)
 _, st = w.render(cam, width=1200, height=1200, spp=spp, seed=1, kernel=int(os.environ.get("C4_KERNEL", "0")))
-print(json.dumps(dict(msamples_per_s=st["samples"] / (st["kernel_ms"] * 1e-3) / 1e6, kernel_ms=st["kernel_ms"], launches=st["launches"], lds=st["scene_in_lds"], info=w.info())))
+print(json.dumps(dict(msamples_per_s=st["samples"] / (st["kernel_ms"] * 1e-3) / 1e6, kernel_ms=st["kernel_ms"], kernel=st["kernel_used"], launches=st["launches"],
+                      workspace_mb=round(st["workspace_bytes"] / 1e6), lds=st["scene_in_lds"], info=w.info())))

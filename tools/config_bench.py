@@ -28,5 +28,5 @@ run("C3 cornell 800x800x2000 (brute force)", wc, cc, 800, 800, 2000)
 P, N, I = shapes.torus(160, 320)
 wm = rtamd.World(); wm.new(shapes.cornell_with_mesh(wm, P, N, I), bvh_seed=1)
 cm = rtamd.Camera(((278, 278, -800), (278, 278, 278)), (0, 1, 0), 50, 1.0, 0.0, 10.0)
-run("C4 cornell + 102,400-tri torus 1200x1200x1000 (one GPU)", wm, cm, 1200, 1200, 1000, kernels=(2,))
+run("C4 cornell + 102,400-tri torus 1200x1200x1000 (one GPU)", wm, cm, 1200, 1200, 1000, kernels=(5, 2))
 json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "config_bench.json"), "w"), indent=1)
