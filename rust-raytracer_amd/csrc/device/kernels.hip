@@ -443,11 +443,14 @@ DEV bool box32(float lox, float loy, float loz, float hix, float hiy, float hiz,
     float px = __builtin_fmaf(lox, r.ix, -r.cx), qx = __builtin_fmaf(hix, r.ix, -r.cx);
     float py = __builtin_fmaf(loy, r.iy, -r.cy), qy = __builtin_fmaf(hiy, r.iy, -r.cy);
     float pz = __builtin_fmaf(loz, r.iz, -r.cz), qz = __builtin_fmaf(hiz, r.iz, -r.cz);
-    float tn = fmaxf(fmaxf(fminf(px, qx), fminf(py, qy)), fmaxf(fminf(pz, qz), r.tmin));
+    // max(tn, tmin) <= min(tf, best) written as three compares (tmin <= best always): the loop-invariant tmin / best then need no
+    // per-node canonicalising v_max (the compiler re-quiets values that come from another basic block): 2 of 46 VALU per node.
+    // NaN rays (degenerate cameras, Q2) must keep passing every box -- the reference accepts NaN hits -- hence the negated
+    // compares: fminf / fmaxf drop a NaN axis as before, and an all-NaN tn or tf fails no "greater than".
+    float tn = fmaxf(fmaxf(fminf(px, qx), fminf(py, qy)), fminf(pz, qz));
     float tf = fminf(fminf(fmaxf(px, qx), fmaxf(py, qy)), fmaxf(pz, qz)) * (1.0f + 4.76837158203125e-7f);
-    tf = fminf(tf, r.best);
     entry = tn;
-    return tn <= tf;
+    return !(tn > tf) && !(tn > r.best) && !(r.tmin > tf);
 }
 
 // Closest hit through the accel (common/flat.h): near-child-first BVH2 descent with a per-lane stack in LDS,
