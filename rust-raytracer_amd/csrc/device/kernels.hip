@@ -110,6 +110,11 @@ DEV D3 xf_dir(const double* t, D3 p) {  // vec3.rs:180-184 (w = 0)
 }
 
 // ------------------------------------------------------------- scene ------
+#define AS_G __attribute__((address_space(1)))
+#define AS_L __attribute__((address_space(3)))
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 struct Acc {  // typed views into the blob (LDS or global; the address space is inferred per instantiation)
     const uint2* meta;
     const double2* boxes;    // 3 x double2 per box: (minx,miny) (minz,maxx) (maxy,maxz)
@@ -120,7 +125,9 @@ struct Acc {  // typed views into the blob (LDS or global; the address space is 
     const uint4* tris;       // a,b,c,mat
     const double2* tripre;   // 5 x double2 per triangle: pa, e0 = pb-pa, e1 = pc-pa (mesh.rs:69, hoisted to commit time)
     const double2* tripre2;  // the same records in accel ITEM order (a leaf's triangles are contiguous)
-    const float4* n2_top;    // LDS copy of the first n2_top_count Node2 (the shallowest levels) when the scene itself is not in LDS
+    const AS_L f32x4* n2_top;  // LDS copy of the first n2_top_count Node2 (the shallowest levels) when the scene itself is not in LDS;
+                               // typed with its address space: a generic pointer here lets the compiler fold the cached / uncached
+                               // node loads into one FLAT load of a selected address
     uint32_t n2_top_count;
     const double* xforms;    // 32 per transform: M^-1 then M, row-major
     const MatDev* mats;
@@ -459,7 +466,9 @@ DEV bool box32(float lox, float loy, float loz, float hix, float hiy, float hiz,
 // primitives are met differs, which cannot change the result.
 // DEFER (cooperative kernel 5): an instance item is not entered; its index is recorded in *pend and its object-space BVH is
 // walked later by whichever wave serves the workgroup's request ring (coop_serve), starting from this walk's result.
-template <bool GENERAL, bool DEFER = false>
+// TOP: the scene lives in L2/HBM and the shallowest nodes are cached in LDS (A.n2_top); false for LDS-resident scenes, which then
+// carry no test for it in the node loop.
+template <bool GENERAL, bool DEFER = false, bool TOP = true>
 DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, double t_min, double t_max, uint32_t* pend = nullptr) {
     D3 o = wo, d = wd;
     D3 inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
@@ -475,13 +484,14 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
     uint32_t cur = A.root2;
     for (;;) {
         while ((cur >> REF_TAG_SHIFT) == 0u) {  // inner node: test both children
-            float4 q0, q1, q2, q3;  // (lox0,lox1,loy0,loy1) (loz0,loz1,hix0,hix1) (hiy0,hiy1,hiz0,hiz1) (c0,c1,-,-)
-            if (cur < A.n2_top_count) {  // the shallowest levels are cached in LDS when the scene lives in L2/HBM
-                const float4* p = A.n2_top + NODE2_F4 * cur;
-                q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
+            f32x4 q0, q1, q2;  // (lox0,lox1,loy0,loy1) (loz0,loz1,hix0,hix1) (hiy0,hiy1,hiz0,hiz1) (c0,c1,-,-)
+            f32x2 q3;          // (only the two child refs of the fourth quad: an 8-byte read)
+            if (TOP && cur < A.n2_top_count) {  // the shallowest levels are cached in LDS when the scene lives in L2/HBM
+                const AS_L f32x4* p = A.n2_top + NODE2_F4 * cur;
+                q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = *(const AS_L f32x2*)(p + 3);
             } else {
-                const float4* p = A.n2 + NODE2_F4 * cur;
-                q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
+                const f32x4* p = (const f32x4*)A.n2 + NODE2_F4 * cur;
+                q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = *(const f32x2*)(p + 3);
             }
             float e0, e1;
             bool h0 = box32(q0.x, q0.z, q1.x, q1.z, q2.x, q2.z, r, e0);
@@ -1030,7 +1040,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
             uint4* dst = (uint4*)smem;
             for (uint32_t i = threadIdx.x; i < (uint32_t)rk.n_top * NODE2_F4; i += blockDim.x) dst[i] = src[i];
             __syncthreads();
-            A.n2_top = (const float4*)smem;
+            A.n2_top = (const AS_L f32x4*)smem;
             A.n2_top_count = (uint32_t)rk.n_top;
             staged = (uint32_t)rk.n_top * (uint32_t)sizeof(Node2);
         }
@@ -1121,7 +1131,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
             }
             // ---- one path segment: sample_ray's loop body, photon_mapper.rs:335-362 ----
             if (alive) {
-                Hit h = (ACCEL == 2) ? traverse2<GENERAL>(A, stk, stk_stride, o, d, rk.t_min, INFINITY)
+                Hit h = (ACCEL == 2) ? traverse2<GENERAL, false, !LDS>(A, stk, stk_stride, o, d, rk.t_min, INFINITY)
                                      : traverse<GENERAL, MEDIA>(A, o, d, rk.t_min, INFINITY, &rng);
                 bool done = true;
                 if (h.node >= 0 && depth > 0) {  // Q12: depth test after the hit, before emission
@@ -1209,7 +1219,7 @@ static const int COOP_REC = 20 + COOP_STACK_MAX / 2;  // u64 per pool slot, read
 //   unit 10..  the saved stack of a suspended walk, four entries per unit
 // Records are only touched by waves of one workgroup, i.e. of one CU, whose L1 they share: plain loads and stores, ordered by
 // s_waitcnt vmcnt(0) before the slot id is published through LDS (workgroup-scope release / acquire on gfx950).
-typedef ulonglong2 U2;
+typedef unsigned long long U2 __attribute__((ext_vector_type(2)));
 DEV U2 ld_unit(const uint64_t* rec, int unit) { return ((const U2*)rec)[unit]; }
 DEV void st_unit(uint64_t* rec, int unit, uint64_t a, uint64_t b) {
     U2 v;
@@ -1252,11 +1262,14 @@ __device__ unsigned long long g_coop_time[8];
 #endif
 
 DEV D3 rcp3(D3 d) { return mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z); }
+// Address spaces are spelled out in the pieces that run out of line (or through volatile accesses): the compiler infers them
+// from kernel arguments and `extern __shared__`, not from pointers that went through memory, and falls back to FLAT
+// instructions (64-bit VALU address arithmetic, both wait counters, a slower path into LDS).
 struct CoopRing {  // multi-producer multi-consumer ring of slot ids in LDS; entries are id + 1 (16 bit), 0 = not yet written
-    volatile uint16_t* buf;
-    uint32_t* ht;  // {head, tail}: monotonic counters
+    volatile AS_L uint16_t* buf;
+    AS_L uint32_t* ht;  // {head, tail}: monotonic counters
 };
-DEV uint32_t lds_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+DEV uint32_t lds_load(const AS_L uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 DEV uint32_t ring_len(const CoopRing& R) { return lds_load(&R.ht[1]) - lds_load(&R.ht[0]); }
 // push the ids of the flagged lanes; `drain`: their records were just stored and must be in L2 before the ids are visible
 DEV void ring_push(const CoopRing& R, bool push, uint32_t id, int lane, uint64_t lanemask_lt, bool drain) {
@@ -1264,7 +1277,7 @@ DEV void ring_push(const CoopRing& R, bool push, uint32_t id, int lane, uint64_t
     if (m == 0ull) return;
     const int leader = __ffsll((long long)m) - 1;
     uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(&R.ht[1], (uint32_t)__popcll(m));
+    if (lane == leader) base = __hip_atomic_fetch_add(&R.ht[1], (uint32_t)__popcll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     base = __shfl(base, leader);
     if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (push) R.buf[(base + (uint32_t)__popcll(m & lanemask_lt)) & (COOP_POOL - 1)] = (uint16_t)(id + 1u);
@@ -1275,10 +1288,11 @@ DEV int ring_pop(const CoopRing& R, uint64_t want, int lane, uint64_t lanemask_l
     uint32_t h0 = 0, k = 0;
     if (lane == 0) {
         for (;;) {
-            const uint32_t hd = lds_load(&R.ht[0]), tl = lds_load(&R.ht[1]);
+            uint32_t hd = lds_load(&R.ht[0]);
+            const uint32_t tl = lds_load(&R.ht[1]);
             if (hd == tl) break;
             const uint32_t n = min((uint32_t)__popcll(want), tl - hd);
-            if (atomicCAS(&R.ht[0], hd, hd + n) == hd) {
+            if (__hip_atomic_compare_exchange_strong(&R.ht[0], &hd, hd + n, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
                 h0 = hd;
                 k = n;
                 break;
@@ -1300,8 +1314,8 @@ DEV int ring_pop(const CoopRing& R, uint64_t want, int lane, uint64_t lanemask_l
 }
 
 struct CoopLds {
-    CoopRing rq, aq, fq;  // requests, answers, free pool slots
-    uint32_t* n_parked;   // paths currently in the pool
+    CoopRing rq, aq, fq;        // requests, answers, free pool slots
+    AS_L uint32_t* n_parked;    // paths currently in the pool
 };
 
 // One while-while pass of the object-space walk for the lanes with `act`: descend to a leaf, test its items (traverse2's
@@ -1309,13 +1323,14 @@ struct CoopLds {
 DEV void blas_pass(const Acc& A, bool act, uint32_t* stk, const int stride, D3 o, D3 d, double a, double t_min, Ray32& r, double& ht, int& hnode,
                    uint32_t& hkp, uint32_t& cur, int& sp, int* err) {
     while (act && (cur >> REF_TAG_SHIFT) == 0u) {  // inner node: both children, conservative f32 boxes
-        float4 q0, q1, q2, q3;
+        f32x4 q0, q1, q2;
+        f32x2 q3;
         if (cur < A.n2_top_count) {
-            const float4* p = A.n2_top + NODE2_F4 * cur;
-            q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
+            const AS_L f32x4* p = A.n2_top + NODE2_F4 * cur;
+            q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = *(const AS_L f32x2*)(p + 3);
         } else {
-            const float4* p = A.n2 + NODE2_F4 * cur;
-            q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
+            const f32x4* p = (const f32x4*)A.n2 + NODE2_F4 * cur;
+            q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = *(const f32x2*)(p + 3);
         }
         float e0, e1;
         const bool h0 = box32(q0.x, q0.z, q1.x, q1.z, q2.x, q2.z, r, e0);
@@ -1371,19 +1386,34 @@ DEV void blas_pass(const Acc& A, bool act, uint32_t* stk, const int stride, D3 o
 }
 
 
-// The same pass over the compact encoding (flat.h "Compact instance data"): NodeQ boxes are grid integers and `r` is the ray in
-// grid coordinates; triangles come as f32 vertices with order and kind|payload in the record.  (o, d) is the object-space ray.
-DEV void blas_pass_q(const Acc& A, bool act, uint32_t* stk, const int stride, D3 o, D3 d, double t_min, Ray32& r, double& ht, int& hnode,
+// The serving waves' view of the scene, every pointer with its address space.
+struct ServeCtx {
+    const AS_G u32x4* n2q;       // 2 per NodeQ
+    const AS_L u32x4* n2q_top;   // LDS copy of the first n_topq NodeQ
+    uint32_t n_topq;
+    const AS_G u32x4* tri32;     // 3 per Tri32
+    const AS_L double* qgrid;    // 8 per instance
+    const AS_L uint32_t* inst2;  // 2 per instance: xform, root
+    const AS_L double* xforms;   // 32 per transform
+    AS_G U2* pool;               // this workgroup's parked-path records, COOP_REC / 2 units each
+    CoopLds C;
+    double t_min;
+};
+// One while-while pass of the object-space walk over the compact encoding (flat.h "Compact instance data") for the lanes with
+// `act`: descend to a leaf, test its triangles.  NodeQ boxes are grid integers and `r` is the ray in grid coordinates; triangles
+// come as f32 vertices with order and kind|payload in the record; (o, d) is the object-space ray.  cur == REF_DONE afterwards
+// means the walk is complete.
+DEV void blas_pass_q(const ServeCtx& X, bool act, AS_L uint32_t* stk, const int stride, D3 o, D3 d, double t_min, Ray32& r, double& ht, int& hnode,
                      uint32_t& hkp, uint32_t& cur, int& sp) {
     // (measured and dropped: ending the descent early once fewer than 16 / 24 / 32 / 40 lanes still descend -- 631 / 574 / 547 / 517
     // against 632 Msamples/s -- and testing at most 1 or 2 triangles of a leaf per pass, 543 / 612)
     while (act && (cur >> REF_TAG_SHIFT) == 0u) {
-        uint4 u0, u1;  // (lox, loy, loz, hix) (hiy, hiz, c0, c1); child 0 in the low halves
-        if (cur < A.n2q_top_count) {
-            const uint4* p = A.n2q_top + 2 * cur;
+        u32x4 u0, u1;  // (lox, loy, loz, hix) (hiy, hiz, c0, c1); child 0 in the low halves
+        if (cur < X.n_topq) {
+            const AS_L u32x4* p = X.n2q_top + 2 * cur;
             u0 = p[0]; u1 = p[1];
         } else {
-            const uint4* p = A.n2q + 2 * cur;
+            const AS_G u32x4* p = X.n2q + 2 * (size_t)cur;
             u0 = p[0]; u1 = p[1];
         }
         float e0, e1;
@@ -1411,8 +1441,8 @@ DEV void blas_pass_q(const Acc& A, bool act, uint32_t* stk, const int stride, D3
     if (act && (cur >> REF_TAG_SHIFT) == 1u) {  // leaf: Triangle::hit in f64 (mesh.rs:57-102), tie rule as in traverse2
         const uint32_t first = cur & REF_LEAF_FIRST_MASK, cnt = ((cur >> REF_LEAF_COUNT_SHIFT) & 7u) + 1u;
         for (uint32_t i = 0; i < cnt; i++) {
-            const uint4* p = A.tri32 + 3 * (first + i);
-            const uint4 a = p[0], b = p[1], c = p[2];
+            const AS_G u32x4* p = X.tri32 + 3 * (size_t)(first + i);
+            const u32x4 a = p[0], b = p[1], c = p[2];
             const D3 pa = mk((double)__uint_as_float(a.x), (double)__uint_as_float(a.y), (double)__uint_as_float(a.z));
             const D3 pb = mk((double)__uint_as_float(a.w), (double)__uint_as_float(b.x), (double)__uint_as_float(b.y));
             const D3 pc = mk((double)__uint_as_float(b.z), (double)__uint_as_float(b.w), (double)__uint_as_float(c.x));
@@ -1450,6 +1480,19 @@ struct CoopArgs {
 #define AS_LDS(T, p) ((T*)(__attribute__((address_space(3))) T*)(p))
 DEV uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 DEV uint64_t rfl64(uint64_t v) { return ((uint64_t)rfl((uint32_t)(v >> 32)) << 32) | (uint64_t)rfl((uint32_t)v); }
+DEV CoopLds coop_rings(AS_L char* at) {  // [RQ | AQ | FQ: COOP_POOL 16-bit entries each][8 counters]
+    CoopLds C;
+    AS_L uint16_t* cb = (AS_L uint16_t*)at;
+    C.rq.buf = cb;
+    C.aq.buf = cb + COOP_POOL;
+    C.fq.buf = cb + 2 * COOP_POOL;
+    AS_L uint32_t* cnt = (AS_L uint32_t*)(cb + 3 * COOP_POOL);
+    C.rq.ht = cnt;
+    C.aq.ht = cnt + 2;
+    C.fq.ht = cnt + 4;
+    C.n_parked = cnt + 6;
+    return C;
+}
 struct CoopCtx {
     Acc A;  // only the fields the object-space walk reads
     CoopLds C;
@@ -1472,34 +1515,42 @@ DEV CoopCtx coop_ctx(const CoopArgs* args_generic, char* lds0_generic) {  // lds
     X.A.rects = (const double2*)(base + rfl(ga->off_rects));
     X.A.inst2 = (const uint2*)(lds0 + rfl(ga->lds_inst2));
     X.A.xforms = (const double*)(lds0 + rfl(ga->lds_xforms));
-    X.A.n2_top = (const float4*)(lds0 + rfl(ga->lds_top));
+    X.A.n2_top = (const AS_L f32x4*)(lds0 + rfl(ga->lds_top));
     X.A.n2_top_count = rfl(ga->n_top);
     X.A.n2q = (const uint4*)(base + rfl(ga->off_n2q));
     X.A.tri32 = (const uint4*)(base + rfl(ga->off_tri32));
     X.A.qgrid = (const double*)(lds0 + rfl(ga->lds_qgrid));
     X.A.n2q_top = (const uint4*)(lds0 + rfl(ga->lds_topq));
     X.A.n2q_top_count = rfl(ga->n_topq);
-    uint16_t* cb = (uint16_t*)(lds0 + rfl(ga->lds_coop));
-    X.C.rq.buf = cb;
-    X.C.aq.buf = cb + COOP_POOL;
-    X.C.fq.buf = cb + 2 * COOP_POOL;
-    uint32_t* cnt = (uint32_t*)(cb + 3 * COOP_POOL);
-    X.C.rq.ht = cnt;
-    X.C.aq.ht = cnt + 2;
-    X.C.fq.ht = cnt + 4;
-    X.C.n_parked = cnt + 6;
+    X.C = coop_rings((AS_L char*)lds0_generic + rfl(ga->lds_coop));
+    return X;
+}
+// the serving waves' context: the same block, every pointer typed with its address space
+DEV ServeCtx serve_ctx(const CoopArgs* args_generic, char* lds0_generic) {
+    const AS_L CoopArgs* ga = (const AS_L CoopArgs*)args_generic;
+    AS_L char* lds0 = (AS_L char*)lds0_generic;
+    ServeCtx X;
+    const AS_G char* base = (const AS_G char*)rfl64((uint64_t)ga->base);
+    X.pool = (AS_G U2*)rfl64((uint64_t)ga->pool);
+    X.t_min = __longlong_as_double((long long)rfl64((uint64_t)__double_as_longlong(ga->t_min)));
+    X.n2q = (const AS_G u32x4*)(base + rfl(ga->off_n2q));
+    X.tri32 = (const AS_G u32x4*)(base + rfl(ga->off_tri32));
+    X.n2q_top = (const AS_L u32x4*)(lds0 + rfl(ga->lds_topq));
+    X.n_topq = rfl(ga->n_topq);
+    X.qgrid = (const AS_L double*)(lds0 + rfl(ga->lds_qgrid));
+    X.inst2 = (const AS_L uint32_t*)(lds0 + rfl(ga->lds_inst2));
+    X.xforms = (const AS_L double*)(lds0 + rfl(ga->lds_xforms));
+    X.C = coop_rings(lds0 + rfl(ga->lds_coop));
     return X;
 }
 
 // Serve the request ring with this wave: walk, refill, suspend the tail.  `may_suspend`: the wave has other work to go back to.
 // Out of line: the caller's paths stay in callee-saved registers (saved once per call) instead of squeezing the walk's loop.
 __device__ __attribute__((noinline)) void coop_serve(const CoopArgs* args, char* lds0, uint32_t* stk_generic, bool may_suspend COOP_STATS_ARG) {
-    const CoopCtx X = coop_ctx(args, lds0);
+    const ServeCtx X = serve_ctx(args, lds0);
     const CoopLds& C = X.C;
-    const Acc& A = X.A;
-    uint64_t* pool = X.pool;
     const double t_min = X.t_min;
-    uint32_t* stk = AS_LDS(uint32_t, stk_generic);
+    AS_L uint32_t* stk = (AS_L uint32_t*)stk_generic;
     const int stride = PT_BLOCK;
     const int lane = (int)(threadIdx.x & 63u);
     const uint64_t lanemask_lt = (1ull << lane) - 1ull;
@@ -1516,14 +1567,16 @@ __device__ __attribute__((noinline)) void coop_serve(const CoopArgs* args, char*
         const int got = ring_pop(C.rq, __ballot(rid < 0), lane, lanemask_lt);
         if (got >= 0) {
             rid = got;
-            const uint64_t* q = pool + (size_t)COOP_REC * (size_t)rid;
-            const U2 u0 = ld_unit(q, 0), u1 = ld_unit(q, 1), u2 = ld_unit(q, 2), u3 = ld_unit(q, 3), u4 = ld_unit(q, 4);
+            const AS_G U2* q = X.pool + (size_t)(COOP_REC / 2) * (size_t)rid;
+            const U2 u0 = q[0], u1 = q[1], u2 = q[2], u3 = q[3], u4 = q[4];
             const uint32_t inst = (uint32_t)(u4.y >> 16) & 0xffu;
             const int n_saved = (int)((u4.y >> 24) & 0xffu);
-            const double* Minv = A.xforms + 32 * A.inst2[inst].x;
+            const AS_L double* m = X.xforms + 32 * X.inst2[2 * inst];  // M^-1: Transform::hit, transform.rs:153-156 (xf_point / xf_dir)
             const D3 wo = mk(bitsd(u0.x), bitsd(u0.y), bitsd(u1.x)), wd = mk(bitsd(u1.y), bitsd(u2.x), bitsd(u2.y));
-            o = xf_point(Minv, wo);
-            d = xf_dir(Minv, wd);
+            o = mk(m[0] * wo.x + m[1] * wo.y + m[2] * wo.z + m[3] * 1., m[4] * wo.x + m[5] * wo.y + m[6] * wo.z + m[7] * 1.,
+                   m[8] * wo.x + m[9] * wo.y + m[10] * wo.z + m[11] * 1.);
+            d = mk(m[0] * wd.x + m[1] * wd.y + m[2] * wd.z + m[3] * 0., m[4] * wd.x + m[5] * wd.y + m[6] * wd.z + m[7] * 0.,
+                   m[8] * wd.x + m[9] * wd.y + m[10] * wd.z + m[11] * 0.);
             cur = (uint32_t)(u4.x >> 32);
             if (n_saved == 0) {  // fresh request
                 ht = bitsd(u3.x);
@@ -1531,13 +1584,13 @@ __device__ __attribute__((noinline)) void coop_serve(const CoopArgs* args, char*
                 hkp = 0u;
                 sp = 0;
             } else {  // suspended walk: its best hit so far in unit 5; the stack comes back into this lane's LDS stack
-                const U2 u5 = ld_unit(q, 5);
+                const U2 u5 = q[5];
                 ht = bitsd(u5.x);
                 hnode = (int)(uint32_t)u5.y;
                 hkp = (uint32_t)(u5.y >> 32);
                 const int n = n_saved - 1;
                 for (int i = 0; i < n; i += 4) {
-                    const U2 w = ld_unit(q, 10 + (i >> 2));
+                    const U2 w = q[10 + (i >> 2)];
                     stk[i * stride] = (uint32_t)w.x;
                     if (i + 1 < n) stk[(i + 1) * stride] = (uint32_t)(w.x >> 32);
                     if (i + 2 < n) stk[(i + 2) * stride] = (uint32_t)w.y;
@@ -1545,7 +1598,7 @@ __device__ __attribute__((noinline)) void coop_serve(const CoopArgs* args, char*
                 }
                 sp = n * stride;
             }
-            const double* g = A.qgrid + 8 * inst;  // the ray on the instance's grid: same t (QGrid, flat.h)
+            const AS_L double* g = X.qgrid + 8 * inst;  // the ray on the instance's grid: same t (QGrid, flat.h)
             const D3 og = mk((o.x - g[0]) * g[3] + g[6], (o.y - g[1]) * g[4] + g[6], (o.z - g[2]) * g[5] + g[6]);
             const D3 dg = mk(d.x * g[3], d.y * g[4], d.z * g[5]);
             r = make_ray32(og, rcp3(dg), t_min, ht);
@@ -1555,9 +1608,14 @@ __device__ __attribute__((noinline)) void coop_serve(const CoopArgs* args, char*
         bool thin = false;
         for (;;) {
             COOP_STAT(1, __ballot(rid >= 0));  // serve passes: busy lanes
-            blas_pass_q(A, rid >= 0, stk, stride, o, d, t_min, r, ht, hnode, hkp, cur, sp);
+            blas_pass_q(X, rid >= 0, stk, stride, o, d, t_min, r, ht, hnode, hkp, cur, sp);
             const bool fin = rid >= 0 && cur == REF_DONE;
-            if (fin) st_unit(pool + (size_t)COOP_REC * (size_t)rid, 5, dbits(ht), ((uint64_t)hkp << 32) | (uint64_t)(uint32_t)hnode);
+            if (fin) {
+                U2 ans;
+                ans.x = dbits(ht);
+                ans.y = ((uint64_t)hkp << 32) | (uint64_t)(uint32_t)hnode;
+                X.pool[(size_t)(COOP_REC / 2) * (size_t)rid + 5] = ans;
+            }
             ring_push(C.aq, fin, (uint32_t)rid, lane, lanemask_lt, true);
             if (fin) rid = -1;
             const int busy = __popcll(__ballot(rid >= 0));
@@ -1574,15 +1632,23 @@ __device__ __attribute__((noinline)) void coop_serve(const CoopArgs* args, char*
             const bool sus = rid >= 0;
             COOP_STAT(4, __ballot(sus));
             if (sus) {
-                uint64_t* q = pool + (size_t)COOP_REC * (size_t)rid;
+                AS_G U2* q = X.pool + (size_t)(COOP_REC / 2) * (size_t)rid;
                 const int n = sp / stride;
-                const U2 u4 = ld_unit(q, 4);
-                st_unit(q, 4, ((uint64_t)cur << 32) | (uint64_t)(uint32_t)u4.x, (u4.y & ~(0xffull << 24)) | ((uint64_t)(n + 1) << 24));
-                st_unit(q, 5, dbits(ht), ((uint64_t)hkp << 32) | (uint64_t)(uint32_t)hnode);
+                const U2 u4 = q[4];
+                U2 w4, w5;
+                w4.x = ((uint64_t)cur << 32) | (uint64_t)(uint32_t)u4.x;
+                w4.y = (u4.y & ~(0xffull << 24)) | ((uint64_t)(n + 1) << 24);
+                w5.x = dbits(ht);
+                w5.y = ((uint64_t)hkp << 32) | (uint64_t)(uint32_t)hnode;
+                q[4] = w4;
+                q[5] = w5;
                 for (int i = 0; i < n; i += 4) {
                     const uint64_t e0 = stk[i * stride], e1 = (i + 1 < n) ? stk[(i + 1) * stride] : 0u;
                     const uint64_t e2 = (i + 2 < n) ? stk[(i + 2) * stride] : 0u, e3 = (i + 3 < n) ? stk[(i + 3) * stride] : 0u;
-                    st_unit(q, 10 + (i >> 2), e0 | (e1 << 32), e2 | (e3 << 32));
+                    U2 w;
+                    w.x = e0 | (e1 << 32);
+                    w.y = e2 | (e3 << 32);
+                    q[10 + (i >> 2)] = w;
                 }
             }
             ring_push(C.rq, sus, (uint32_t)rid, lane, lanemask_lt, true);
@@ -1653,7 +1719,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
         const uint4* src = (const uint4*)(sv.base + sv.off_n2);
         uint4* dst = (uint4*)(smem + staged);
         for (uint32_t i = threadIdx.x; i < (uint32_t)rk.n_top * NODE2_F4; i += blockDim.x) dst[i] = src[i];
-        A.n2_top = (const float4*)(smem + staged);
+        A.n2_top = (const AS_L f32x4*)(smem + staged);
         A.n2_top_count = (uint32_t)rk.n_top;
         staged += (uint32_t)rk.n_top * (uint32_t)sizeof(Node2);
     }
@@ -1676,17 +1742,10 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
     uint32_t* rmeta = book + (size_t)wave * RING_UNITS * 4;
     uint32_t* wst = book + (size_t)(PT_BLOCK / 64) * RING_UNITS * 4 + (size_t)wave * 8;
     int* cfg = (int*)(book + (size_t)(PT_BLOCK / 64) * (RING_UNITS * 4 + 8));
-    uint16_t* coop_base = (uint16_t*)(cfg + CFG_WORDS);
-    uint32_t* cnt = (uint32_t*)(coop_base + 3 * COOP_POOL);
-    CoopArgs* cargs = (CoopArgs*)(cnt + 8);
-    CoopLds C;
-    C.rq.buf = coop_base;
-    C.aq.buf = coop_base + COOP_POOL;
-    C.fq.buf = coop_base + 2 * COOP_POOL;
-    C.rq.ht = cnt;
-    C.aq.ht = cnt + 2;
-    C.fq.ht = cnt + 4;
-    C.n_parked = cnt + 6;
+    char* coop_base = (char*)(cfg + CFG_WORDS);
+    const CoopLds C = coop_rings((AS_L char*)coop_base);
+    AS_L uint32_t* cnt = C.rq.ht;
+    CoopArgs* cargs = (CoopArgs*)(coop_base + 3 * COOP_POOL * sizeof(uint16_t) + 8 * sizeof(uint32_t));
     for (uint32_t i = threadIdx.x; i < (uint32_t)COOP_POOL; i += blockDim.x) {
         C.rq.buf[i] = (uint16_t)0;
         C.aq.buf[i] = (uint16_t)0;
@@ -1870,7 +1929,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
                     alive = false;
                 }
                 const uint64_t mp = __ballot(park);
-                if (mp != 0ull && lane == __ffsll((long long)mp) - 1) atomicAdd(C.n_parked, (uint32_t)__popcll(mp));
+                if (mp != 0ull && lane == __ffsll((long long)mp) - 1) __hip_atomic_fetch_add(C.n_parked, (uint32_t)__popcll(mp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 ring_push(C.rq, park, (uint32_t)id, lane, lanemask_lt, true);  // (publishing an iteration later, behind the stores' round trip: no gain)
                 // pool exhausted (rare): walk the deferred instances in this lane, sparsely, as the plain kernel does
                 if (__ballot(need && id < 0) != 0ull) {
@@ -1938,7 +1997,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
                     const uint64_t mf = __ballot(freed);
                     if (mf != 0ull) {
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the slot's loads have returned before it can be reused
-                        if (lane == __ffsll((long long)mf) - 1) atomicSub(C.n_parked, (uint32_t)__popcll(mf));
+                        if (lane == __ffsll((long long)mf) - 1) __hip_atomic_fetch_add(C.n_parked, 0u - (uint32_t)__popcll(mf), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                     ring_push(C.fq, freed, (uint32_t)id, lane, lanemask_lt, false);
                 }
@@ -2082,7 +2141,7 @@ __global__ void hit_kernel(FlatView sv, int accel, size_t n, const double* rays,
     if (i >= n) return;
     Acc A = make_acc(sv.base, sv.base, sv);
     D3 o = mk(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]), d = mk(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
-    Hit h = (accel == 2) ? traverse2<true>(A, (uint32_t*)smem + threadIdx.x, (int)blockDim.x, o, d, t_min, t_max)
+    Hit h = (accel == 2) ? traverse2<true, false, false>(A, (uint32_t*)smem + threadIdx.x, (int)blockDim.x, o, d, t_min, t_max)
                          : traverse<true>(A, o, d, t_min, t_max);
     double* q = out + 12 * i;
     for (int k = 0; k < 12; k++) q[k] = 0.;
