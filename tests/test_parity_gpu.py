@@ -469,6 +469,34 @@ def test_coop_kernel_full_size_equals_kernel2_at_more_samples():
     _assert_same(b, a, "C4 256x256x8, kernel 5 against kernel 2")
 
 
+def test_coop_kernel_image_does_not_depend_on_partition_chunking_or_unit_size(tuning):
+    """kernel 5 under the schedule knobs: tile partition over ranks, spp chunking (several launches), work-unit size, a
+    single tile with many units (every path of the image competes for one ticket chain) -- the same image as kernel 2."""
+    c = _c4_scene()
+    world, cam = c["world"], c["cam"]
+    w, h, spp = 72, 56, 12
+    full, st = world.render(cam, width=w, height=h, spp=spp, seed=6, kernel=2)
+    coop, st5 = world.render(cam, width=w, height=h, spp=spp, seed=6, kernel=5)
+    assert st5["kernel_used"] == 5 and st5["launches"] == 1
+    _assert_same(coop, full, "kernel 5 against kernel 2")
+    for world_size in (2, 3):
+        acc = np.zeros_like(full)
+        for r in range(world_size):
+            part, _ = world.render(cam, width=w, height=h, spp=spp, seed=6, rank=r, world=world_size, kernel=5)
+            assert np.count_nonzero(acc[part != 0]) == 0
+            acc += part
+        assert np.array_equal(acc, full), "kernel 5: partition over %d ranks changed the image" % world_size
+    for sub, chunk in ((3, 0), (1, 5), (8, 7)):
+        tuning(sub_spp=sub)
+        other, st2 = world.render(cam, width=w, height=h, spp=spp, seed=6, spp_chunk=chunk, kernel=5)
+        assert st2["launches"] == (1 if chunk == 0 else -(-spp // chunk))
+        assert np.array_equal(other, full), (sub, chunk)
+    tuning()
+    a, _ = world.render(cam, width=8, height=8, spp=400, seed=2, kernel=2)   # one tile, 50 units
+    b, _ = world.render(cam, width=8, height=8, spp=400, seed=2, kernel=5)
+    _assert_same(b, a, "one tile, 50 units, kernel 5")
+
+
 def test_coop_kernel_pool_exhaustion_walks_in_the_lane(tuning):
     """with only 32 parked-path slots per workgroup most deferred walks take the in-lane fallback (coop_walk_inline) and the
     rest trickle through the rings: same image."""
