@@ -1195,6 +1195,9 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
 #ifndef COOP_POOL
 #define COOP_POOL 1024      // parked paths per workgroup (power of two; 2048: -1 %, the LDS is worth more as node cache)
 #endif
+// Ring capacity: twice the pool, so that a ring position is written again only after 1024 further pops have gone by since a
+// consumer reserved it (a consumer reads its entry a few instructions after it has advanced the head).
+#define COOP_RING (2 * COOP_POOL)
 #ifndef COOP_BATCH
 #define COOP_BATCH 32       // a wave starts serving once this many requests wait (16: -3 %, 64: -2 %, 128: -5 %)
 #endif
@@ -1280,7 +1283,7 @@ DEV void ring_push(const CoopRing& R, bool push, uint32_t id, int lane, uint64_t
     if (lane == leader) base = __hip_atomic_fetch_add(&R.ht[1], (uint32_t)__popcll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     base = __shfl(base, leader);
     if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (push) R.buf[(base + (uint32_t)__popcll(m & lanemask_lt)) & (COOP_POOL - 1)] = (uint16_t)(id + 1u);
+    if (push) R.buf[(base + (uint32_t)__popcll(m & lanemask_lt)) & (COOP_RING - 1)] = (uint16_t)(id + 1u);
 }
 // pop up to popcount(want) ids; lanes of `want` that get one return it, the others return -1
 DEV int ring_pop(const CoopRing& R, uint64_t want, int lane, uint64_t lanemask_lt) {
@@ -1304,7 +1307,7 @@ DEV int ring_pop(const CoopRing& R, uint64_t want, int lane, uint64_t lanemask_l
     const int rank = __popcll(want & lanemask_lt);
     int id = -1;
     if (((want >> lane) & 1ull) != 0ull && rank < (int)k) {
-        const uint32_t slot = (h0 + (uint32_t)rank) & (COOP_POOL - 1);
+        const uint32_t slot = (h0 + (uint32_t)rank) & (COOP_RING - 1);
         uint32_t v;
         do { v = R.buf[slot]; } while (v == 0u);  // its producer reserved the slot and writes it within a few instructions
         R.buf[slot] = (uint16_t)0;
@@ -1315,7 +1318,6 @@ DEV int ring_pop(const CoopRing& R, uint64_t want, int lane, uint64_t lanemask_l
 
 struct CoopLds {
     CoopRing rq, aq, fq;        // requests, answers, free pool slots
-    AS_L uint32_t* n_parked;    // paths currently in the pool
 };
 
 // One while-while pass of the object-space walk for the lanes with `act`: descend to a leaf, test its items (traverse2's
@@ -1480,17 +1482,16 @@ struct CoopArgs {
 #define AS_LDS(T, p) ((T*)(__attribute__((address_space(3))) T*)(p))
 DEV uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 DEV uint64_t rfl64(uint64_t v) { return ((uint64_t)rfl((uint32_t)(v >> 32)) << 32) | (uint64_t)rfl((uint32_t)v); }
-DEV CoopLds coop_rings(AS_L char* at) {  // [RQ | AQ | FQ: COOP_POOL 16-bit entries each][8 counters]
+DEV CoopLds coop_rings(AS_L char* at) {  // [RQ | AQ | FQ: COOP_RING 16-bit entries each][8 counters]
     CoopLds C;
     AS_L uint16_t* cb = (AS_L uint16_t*)at;
     C.rq.buf = cb;
-    C.aq.buf = cb + COOP_POOL;
-    C.fq.buf = cb + 2 * COOP_POOL;
-    AS_L uint32_t* cnt = (AS_L uint32_t*)(cb + 3 * COOP_POOL);
+    C.aq.buf = cb + COOP_RING;
+    C.fq.buf = cb + 2 * COOP_RING;
+    AS_L uint32_t* cnt = (AS_L uint32_t*)(cb + 3 * COOP_RING);
     C.rq.ht = cnt;
     C.aq.ht = cnt + 2;
     C.fq.ht = cnt + 4;
-    C.n_parked = cnt + 6;
     return C;
 }
 struct CoopCtx {
@@ -1689,7 +1690,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
                                                            unsigned int* tickets, unsigned int* __restrict__ counter, int* __restrict__ err, uint64_t* coop) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // LDS map: [world-level tables][top-of-BVH Node2 cache][stacks: stack2 x PT_BLOCK words][ring / job bookkeeping as in pt_kernel]
-    //          [RQ, AQ, FQ: COOP_POOL words each][8 counters][CoopArgs]          (the scene itself stays in L2 / HBM)
+    //          [RQ, AQ, FQ: COOP_RING 16-bit entries each][8 counters][CoopArgs]     (the scene itself stays in L2 / HBM)
     uint32_t staged = 0;
     Acc A = make_acc(sv.base, sv.base, sv);
     // world-level tables into LDS (coop_world_bytes, flat.h); A then is the view the world-space walk and the shading use
@@ -1745,8 +1746,8 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
     char* coop_base = (char*)(cfg + CFG_WORDS);
     const CoopLds C = coop_rings((AS_L char*)coop_base);
     AS_L uint32_t* cnt = C.rq.ht;
-    CoopArgs* cargs = (CoopArgs*)(coop_base + 3 * COOP_POOL * sizeof(uint16_t) + 8 * sizeof(uint32_t));
-    for (uint32_t i = threadIdx.x; i < (uint32_t)COOP_POOL; i += blockDim.x) {
+    CoopArgs* cargs = (CoopArgs*)(coop_base + 3 * COOP_RING * sizeof(uint16_t) + 8 * sizeof(uint32_t));
+    for (uint32_t i = threadIdx.x; i < (uint32_t)COOP_RING; i += blockDim.x) {
         C.rq.buf[i] = (uint16_t)0;
         C.aq.buf[i] = (uint16_t)0;
         C.fq.buf[i] = (uint16_t)(i < (uint32_t)rk.coop_pool ? i + 1u : 0u);  // every pool slot in use is free
@@ -1928,8 +1929,6 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
                     }
                     alive = false;
                 }
-                const uint64_t mp = __ballot(park);
-                if (mp != 0ull && lane == __ffsll((long long)mp) - 1) __hip_atomic_fetch_add(C.n_parked, (uint32_t)__popcll(mp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 ring_push(C.rq, park, (uint32_t)id, lane, lanemask_lt, true);  // (publishing an iteration later, behind the stores' round trip: no gain)
                 // pool exhausted (rare): walk the deferred instances in this lane, sparsely, as the plain kernel does
                 if (__ballot(need && id < 0) != 0ull) {
@@ -1997,7 +1996,6 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
                     const uint64_t mf = __ballot(freed);
                     if (mf != 0ull) {
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the slot's loads have returned before it can be reused
-                        if (lane == __ffsll((long long)mf) - 1) __hip_atomic_fetch_add(C.n_parked, 0u - (uint32_t)__popcll(mf), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                     ring_push(C.fq, freed, (uint32_t)id, lane, lanemask_lt, false);
                 }
@@ -2068,7 +2066,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
             if (!got_unit) {
                 if (ring_len(C.rq) != 0u) {
                     coop_serve(cargs, smem, stk, false COOP_STATS_PASS);
-                } else if (finished && lds_load(C.n_parked) == 0u) {
+                } else if (finished && ring_len(C.fq) == (uint32_t)rk.coop_pool) {  // every pool slot is free again: no path is parked
                     break;
                 } else {
                     COOP_STAT(5, 0ull);
@@ -2367,7 +2365,7 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
     const uint32_t stack5 = std::max(view.world_depth2, view.inst_depth2) + 2u;  // the two walks of kernel 5 never share a stack
     const size_t stack5_bytes = (size_t)stack5 * PT_BLOCK * sizeof(uint32_t);
     const size_t coop_world = coop_world_bytes(view);  // world-level tables, always in LDS for this kernel
-    const size_t coop_lds = (size_t)3 * COOP_POOL * sizeof(uint16_t) + 8 * sizeof(uint32_t) + ((sizeof(CoopArgs) + 15) & ~size_t(15)) + coop_world;  // + three rings of pool-slot ids, counters, argument block
+    const size_t coop_lds = (size_t)3 * COOP_RING * sizeof(uint16_t) + 8 * sizeof(uint32_t) + ((sizeof(CoopArgs) + 15) & ~size_t(15)) + coop_world;  // + three rings of pool-slot ids, counters, argument block
     const bool coop_usable = accel2_usable && general && !media && view.coop_data_ok != 0 && view.n_inst2 >= 1 && view.n_inst2 <= (uint32_t)COOP_MAX_INST &&
                              view.inst_depth2 <= (uint32_t)COOP_STACK_MAX && coop_world <= 16384 && stack5_bytes + coop_lds <= lds_max && plan.max_depth < (1 << 24);
     int kernel = plan.kernel;
