@@ -1202,13 +1202,13 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
 #define COOP_BATCH 32       // a wave starts serving once this many requests wait (16: -3 %, 64: -2 %, 128: -5 %)
 #endif
 #ifndef COOP_REFILL_TH
-#define COOP_REFILL_TH 48   // a serving wave goes back for more requests when fewer lanes than this still walk
+#define COOP_REFILL_TH 56   // a serving wave goes back for more requests when fewer lanes than this still walk (48: -1 %, 40: -3 %)
 #endif
 #ifndef COOP_ENTRY_NODES
 #define COOP_ENTRY_NODES 64  // depth-sorted NodeQ indices below this are walked by the parking lane itself
 #endif
 #ifndef COOP_SUSPEND_TH
-#define COOP_SUSPEND_TH 20  // ... and suspends its walks when fewer than this are left and no request waits
+#define COOP_SUSPEND_TH 24  // ... and suspends its walks when fewer than this are left and no request waits
 #endif
 static const int COOP_MAX_INST = 32;     // one pending bit per instance
 static const int COOP_STACK_MAX = 40;    // stack entries a suspended walk can save (scenes with deeper BVHs use kernel 2)
@@ -1407,7 +1407,7 @@ struct ServeCtx {
 // means the walk is complete.
 DEV void blas_pass_q(const ServeCtx& X, bool act, AS_L uint32_t* stk, const int stride, D3 o, D3 d, double t_min, Ray32& r, double& ht, int& hnode,
                      uint32_t& hkp, uint32_t& cur, int& sp) {
-    // (measured and dropped: ending the descent early once fewer than 16 / 24 / 32 / 40 lanes still descend -- 631 / 574 / 547 / 517
+    // (measured and dropped: publishing a pass's answers one pass later, behind their stores' round trip, -1 %; ending the descent early once fewer than 16 / 24 / 32 / 40 lanes still descend -- 631 / 574 / 547 / 517
     // against 632 Msamples/s -- and testing at most 1 or 2 triangles of a leaf per pass, 543 / 612)
     while (act && (cur >> REF_TAG_SHIFT) == 0u) {
         u32x4 u0, u1;  // (lox, loy, loz, hix) (hiy, hiz, c0, c1); child 0 in the low halves
