@@ -411,20 +411,23 @@ DEV Hit traverse(const Acc& A, D3 wo, D3 wd, double t_min, double t_max, Rng* rn
 // Conservative f32 slab test of one child box of a Node2: 6 fma + 6 min/max + max3/min3 + one multiply.
 //
 // Claim: if some real t in [t_min, best] (t_min >= 0) puts o + t*d inside the exact f64 box B, the test passes.
-// With e = 2^-24, of = fl32(o), iv = fl32(1/d) clamped to |iv| <= 2^90, c = fl(of*iv) (per ray, make_ray32):
+// With e = 2^-24, of = fl32(o), df = fl32(d), iv = rcp32(df) clamped to |iv| <= 2^90 (v_rcp_f32: at most 1 ulp = 2 e off;
+// no f64 division in the ray setup), c = fl(of*iv) (per ray, make_ray32):
+//   iv = (1/d)(1+d1), |d1| <= 3.001 e   (df = d (1+a), |a| <= e; rcp32 = (1/df)(1+b), |b| <= 2 e)
 //   p = fl(lo*iv - c) = (lo' - o) * iv * (1+d3),  lo' = lo - (of - o) - of*d2,  |d2|,|d3| <= e   (one fma; all operands are
 //   finite because |lo|,|of| < 2^36 (flatten.cpp refuses larger scenes) -- no inf-inf, no 0*inf, no NaN).
 //   |lo' - lo| <= 2.001 e |o|max, and the host stores lo <= B.min - pad, hi >= B.max + pad with pad = 4 e |o|max
 //   (rounded outward), so lo' <= B.min and hi' >= B.max: per axis {p, q} = {nu (1+th), phi (1+th')} where, unless iv was
-//   clamped, nu <= true slab entry, phi >= true slab exit, |th|,|th'| < 2.1 e  (iv = (1/d)(1+d1)).
+//   clamped, nu <= true slab entry, phi >= true slab exit, |th|,|th'| < 4.1 e.
 //   For t as above (nu <= t <= phi on every axis, t >= 0):
-//     tn = max3(min(p,q)) <= t (1 + 2.1 e)            (a non-positive nu gives a non-positive value)
-//     tf = min3(max(p,q)) >= t (1 - 2.1 e) >= 0,   fl(tf * W) >= t (1 - 2.1 e)(1 - e)(1 + 8 e) >= t (1 + 2.1 e),  W = 1 + 2^-21
-//   hence tn <= fl(tf*W);  tn <= best (1 + 2.1 e) <= r.best;  r.tmin <= t_min <= t <= fl(tf*W): the test passes.
-//   Only the far side is widened; r.tmin = t_min rounded down, r.best = best*(1 + 2^-21) rounded up.
-//   Clamped iv (|d_axis| < 2^-90, including d_axis = 0 where 1/d = +-inf): the axis constrains nothing for a ray that
-//   starts inside [lo', hi'] (|p|,|q| >= 2 e |o|max * 2^90, beyond any t a path can reach: directions have a
+//     tn = max3(min(p,q)) <= t (1 + 4.1 e)            (a non-positive nu gives a non-positive value)
+//     tf = min3(max(p,q)) >= t (1 - 4.1 e) >= 0,   fl(tf * W) >= t (1 - 4.1 e)(1 - e)(1 + 16 e) >= t (1 + 10 e),  W = 1 + 2^-20
+//   hence tn <= fl(tf*W);  tn <= best (1 + 4.1 e) <= r.best = best (1 + 8 e) rounded up;  r.tmin <= t_min <= t <= fl(tf*W):
+//   the test passes.  Only the far side is widened; r.tmin = t_min rounded down.
+//   Clamped iv (|d_axis| < 2^-90, including d_axis = +-0 where rcp32 = +-inf, and f32-denormal df): the axis constrains nothing
+//   for a ray that starts inside [lo', hi'] (|p|,|q| >= 2 e |o|max * 2^90, beyond any t a path can reach: directions have a
 //   component >= 1e-8, so t <= 2e8 * extent) and culls a ray that starts outside it, which is what the exact test does.
+//   A NaN component gives iv = -2^90 through the clamp (fmaxf drops the NaN), as the f64 division did.
 //   A negative t_min is outside this proof: the host then renders with kernel 1 (render_tiles, accel_usable).
 struct Ray32 {
     float cx, cy, cz, ix, iy, iz;  // c = fl(of * iv)
@@ -433,14 +436,14 @@ struct Ray32 {
 DEV float f32_down(double x) { float f = (float)x; return __builtin_fmaf(-fabsf(f), 1.1920929e-7f, f); }
 DEV float f32_up(double x) { float f = (float)x; return __builtin_fmaf(fabsf(f), 1.1920929e-7f, f); }
 DEV float ray32_best(double best) { return f32_up(best * (1.0 + 4.76837158203125e-7)); }
-DEV float inv32(double inv) {  // |iv| <= 2^90 keeps lo*iv and of*iv finite
-    float f = (float)inv;
+DEV float inv32(double d) {  // |iv| <= 2^90 keeps lo*iv and of*iv finite
+    float f = __builtin_amdgcn_rcpf((float)d);
     const float L = 1.2379400e27f;
     return fminf(fmaxf(f, -L), L);
 }
-DEV Ray32 make_ray32(D3 o, D3 inv, double t_min, double best) {
+DEV Ray32 make_ray32(D3 o, D3 d, double t_min, double best) {  // d: the ray's direction
     Ray32 r;
-    r.ix = inv32(inv.x); r.iy = inv32(inv.y); r.iz = inv32(inv.z);
+    r.ix = inv32(d.x); r.iy = inv32(d.y); r.iz = inv32(d.z);
     r.cx = (float)o.x * r.ix; r.cy = (float)o.y * r.iy; r.cz = (float)o.z * r.iz;
     r.tmin = f32_down(t_min);
     r.best = ray32_best(best);
@@ -455,7 +458,7 @@ DEV bool box32(float lox, float loy, float loz, float hix, float hiy, float hiz,
     // NaN rays (degenerate cameras, Q2) must keep passing every box -- the reference accepts NaN hits -- hence the negated
     // compares: fminf / fmaxf drop a NaN axis as before, and an all-NaN tn or tf fails no "greater than".
     float tn = fmaxf(fmaxf(fminf(px, qx), fminf(py, qy)), fminf(pz, qz));
-    float tf = fminf(fminf(fmaxf(px, qx), fmaxf(py, qy)), fmaxf(pz, qz)) * (1.0f + 4.76837158203125e-7f);
+    float tf = fminf(fminf(fmaxf(px, qx), fmaxf(py, qy)), fmaxf(pz, qz)) * (1.0f + 9.5367431640625e-7f);
     entry = tn;
     return !(tn > tf) && !(tn > r.best) && !(r.tmin > tf);
 }
@@ -471,7 +474,6 @@ DEV bool box32(float lox, float loy, float loz, float hix, float hiy, float hiz,
 template <bool GENERAL, bool DEFER = false, bool TOP = true>
 DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, double t_min, double t_max, uint32_t* pend = nullptr) {
     D3 o = wo, d = wd;
-    D3 inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
     double a = sqlen(d);
     Hit h;
     h.t = t_max;
@@ -479,7 +481,7 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
     h.xf = -1;
     h.kp = 0;
     int cur_xf = -1;
-    Ray32 r = make_ray32(o, inv, t_min, t_max);
+    Ray32 r = make_ray32(o, d, t_min, t_max);
     int sp = 0;  // stack offset in words (a multiple of stride): avoids an integer multiply per push/pop
     uint32_t cur = A.root2;
     for (;;) {
@@ -551,10 +553,9 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
                 const double* Minv = A.xforms + 32 * in.x;
                 o = xf_point(Minv, wo);
                 d = xf_dir(Minv, wd);
-                inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
                 a = sqlen(d);
                 cur_xf = (int)in.x;
-                r = make_ray32(o, inv, t_min, h.t);
+                r = make_ray32(o, d, t_min, h.t);
                 stk[sp] = REF_RESTORE;
                 sp += stride;
                 cur = in.y;
@@ -563,10 +564,9 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
         } else {  // REF_RESTORE: leave the Transform
             o = wo;
             d = wd;
-            inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
             a = sqlen(d);
             cur_xf = -1;
-            r = make_ray32(o, inv, t_min, h.t);
+            r = make_ray32(o, d, t_min, h.t);
         }
         if (sp > 0) {
             sp -= stride;
@@ -1264,7 +1264,6 @@ __device__ unsigned long long g_coop_time[8];
     } while (0)
 #endif
 
-DEV D3 rcp3(D3 d) { return mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z); }
 // Address spaces are spelled out in the pieces that run out of line (or through volatile accesses): the compiler infers them
 // from kernel arguments and `extern __shared__`, not from pointers that went through memory, and falls back to FLAT
 // instructions (64-bit VALU address arithmetic, both wait counters, a slower path into LDS).
@@ -1602,7 +1601,7 @@ __device__ __attribute__((noinline)) void coop_serve(const CoopArgs* args, char*
             const AS_L double* g = X.qgrid + 8 * inst;  // the ray on the instance's grid: same t (QGrid, flat.h)
             const D3 og = mk((o.x - g[0]) * g[3] + g[6], (o.y - g[1]) * g[4] + g[6], (o.z - g[2]) * g[5] + g[6]);
             const D3 dg = mk(d.x * g[3], d.y * g[4], d.z * g[5]);
-            r = make_ray32(og, rcp3(dg), t_min, ht);
+            r = make_ray32(og, dg, t_min, ht);
         }
         if (__ballot(rid >= 0) == 0ull) return;
         COOP_STAT(0, __ballot(rid >= 0));  // serve rounds: lanes holding a request at the start of a round
@@ -1670,7 +1669,7 @@ __device__ __attribute__((noinline)) Hit coop_walk_inline(const CoopArgs* args, 
         const double* Minv = A.xforms + 32 * in.x;
         const D3 oo = xf_point(Minv, o), dd = xf_dir(Minv, d);
         const double a = sqlen(dd);
-        Ray32 r = make_ray32(oo, rcp3(dd), X.t_min, h.t);
+        Ray32 r = make_ray32(oo, dd, X.t_min, h.t);
         double ht = h.t;
         int hnode = h.node, sp = 0;
         uint32_t hkp = 0u, cur = in.y;
@@ -1872,7 +1871,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
                     const double* g = qgrid_lds + 8 * ni;
                     const D3 og = mk((oo.x - g[0]) * g[3] + g[6], (oo.y - g[1]) * g[4] + g[6], (oo.z - g[2]) * g[5] + g[6]);
                     const D3 dg = mk(dd.x * g[3], dd.y * g[4], dd.z * g[5]);
-                    const Ray32 r = make_ray32(og, rcp3(dg), rk.t_min, h.t);
+                    const Ray32 r = make_ray32(og, dg, rk.t_min, h.t);
                     ent_cur = A.inst2[ni].y;
                     while ((ent_cur >> REF_TAG_SHIFT) == 0u && ent_cur < entry_top) {
                         const uint4* p = n2q_lds + 2 * ent_cur;
