@@ -1179,15 +1179,20 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
 // wait (lane utilisation 0.15, profiles/r02/pmc_summary_c4.csv).  Here those walks are re-packed ACROSS the waves of a
 // workgroup, and the workgroup has more paths in flight than lanes so that no lane waits:
 //   * a lane walks the world-space BVH to the end with instance items DEFERRED (traverse2<.., DEFER>: a bit per instance);
-//   * a path with a deferred instance is PARKED: its whole state plus the request -- object-space ray (Transform::hit's
-//     M^-1 * ray, transform.rs:153-156), best t and tie-break order so far, root of the instance's BVH -- goes to a slot of a
-//     per-workgroup pool in global memory (written through to L2), the slot id to the request ring RQ in LDS; the lane is free;
-//   * when a wave's worth of requests waits, a wave SERVES: 64 lanes take 64 requests, walk the object-space BVH and refill
-//     from RQ as lanes finish; when it runs thin with nothing to refill from it SUSPENDS the remaining walks (stack to the
-//     slot, id back to RQ) instead of dragging a sparse tail; answers go to the slot, its id to the answer ring AQ;
+//   * it then ENTERS the first deferred instance itself: M^-1 * ray (Transform::hit, transform.rs:153-156), the ray mapped
+//     onto the instance's 16-bit grid, and a walk through the shallowest NodeQ (the first COOP_ENTRY_NODES of the depth-sorted
+//     array, cached in LDS).  Rays that only clip the instance's box end here (about 40 % of them) and never leave the lane;
+//   * where the walk needs a node or a leaf from memory the path is PARKED: its whole state plus the walk -- node to continue
+//     at, stack, best t and tie-break order so far -- goes to a slot of a per-workgroup pool in global memory (plain 16-byte
+//     stores; the workgroup's waves share one L1), the slot id to the request ring RQ in LDS; the lane is free at once;
+//   * when COOP_BATCH requests wait (or a wave has nothing else to do) a wave SERVES: 64 lanes take 64 requests, continue
+//     the walks over the compact object-space data (NodeQ, Tri32: flat.h) and refill from RQ as lanes finish; when it runs
+//     thin with nothing to refill from it SUSPENDS the remaining walks (stack to the slot, id back to RQ) instead of
+//     dragging a sparse tail; answers go to the slot, its id to the answer ring AQ;
 //   * free lanes ADOPT answered paths right before shading and generate new paths right before the walk, so both phases run
 //     with (almost) every lane; the answer is merged with the reference's acceptance rule (smaller t, or equal t and later
-//     in reference order) -- what the inline walk does when it reaches the instance last.
+//     in reference order) -- what the inline walk does when it reaches the instance last.  A path with a second deferred
+//     instance on the same segment is posted again instead (fresh request from that instance's root).
 // What a path computes is unchanged: every primitive still sees the reference's f64 test with [t_min, best-so-far], the
 // closest hit does not depend on the order in which candidates are met (tie rule by `order`), RNG streams belong to the
 // path, and a finished path stores its sample into the ring slot of the wave that generated it (any wave of the workgroup
@@ -1206,6 +1211,9 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
 #endif
 #ifndef COOP_ENTRY_NODES
 #define COOP_ENTRY_NODES 64  // depth-sorted NodeQ indices below this are walked by the parking lane itself
+#endif
+#ifndef COOP_ADOPT_MIN
+#define COOP_ADOPT_MIN 8     // free lanes a wave waits for before it adopts answered paths
 #endif
 #ifndef COOP_SUSPEND_TH
 #define COOP_SUSPEND_TH 24  // ... and suspends its walks when fewer than this are left and no request waits
@@ -1943,7 +1951,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
         // ---- free lanes adopt answered paths right before shading ----
         {
             uint64_t fr = __ballot(!alive);
-            if ((int)__popcll(fr) < REGEN_MIN && fr != ~0ull) fr = 0ull;
+            if ((int)__popcll(fr) < COOP_ADOPT_MIN && fr != ~0ull) fr = 0ull;
             if (fr != 0ull && ring_len(C.aq) != 0u) {
                 const int id = ring_pop(C.aq, fr, lane, lanemask_lt);
                 COOP_STAT(6, __ballot(id >= 0));
