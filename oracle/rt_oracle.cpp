@@ -22,9 +22,9 @@
 //     known-answer tests authored in this repo (tests/test_oracle_kat.py).
 //
 // DELIBERATE DIVERGENCES FROM THE REFERENCE (all documented in DESIGN.md)
-//   D1. RNG: rand::thread_rng() -> counter-based SplitMix64 stream keyed by
-//       (seed, pixel, sample); draws inside a sample are sequential in the
-//       reference's call order.
+//   D1. RNG: rand::thread_rng() -> counter-based stream keyed by (seed, pixel,
+//       sample) (spec rtamd-rng-2: SplitMix64-hashed key, xoroshiro64** draws);
+//       draws inside a sample are sequential in the reference's call order.
 //   D2. sample_ray: on a Diffuse interaction the path CONTINUES
 //       (throughput *= attenuation; ray = scattered), i.e. the two lines the
 //       reference author commented out at photon_mapper.rs:346-347, instead
@@ -97,33 +97,49 @@ static inline bool v_near_zero(Vec3 a) {  // :92-95
 static inline double v_max(Vec3 a) { return std::fmax(std::fmax(a.x, a.y), a.z); }  // :57-59
 
 // ----------------------------------------------------------------------------
-// RNG (divergence D1).  Spec "rtamd-rng-1" -- restated independently in the
+// RNG (divergence D1).  Spec "rtamd-rng-2" -- restated independently in the
 // product (rust-raytracer_amd/csrc/common/rng.h); pinned against each other by
 // tests/golden/rng_kat.json.
-//   SplitMix64 (Steele, Lea, Flood 2014; public-domain reference by Vigna).
-//   stream key:  s0 = mix(mix(seed + G*(pixel+1)) + H*(sample+1))
-//   gen::<f64>() = (u64 >> 11) * 2^-53            in [0,1)
+//   stream key (SplitMix64 finaliser; Steele, Lea, Flood 2014; public-domain reference by Vigna):
+//                state = mix(mix(seed + G*(pixel+1)) + H*(sample+1)), G if that is 0; (s0, s1) = its (low, high) halves
+//   generator:   xoroshiro64** (Blackman & Vigna 2018; public-domain reference), 32 bits per draw
+//   gen::<f64>() = u32 * 2^-32                     in [0,1)
 //   gen_range(lo..hi) = lo + (hi - lo) * gen::<f64>()
+//   gen_range(0..3)   = (u32 * 3) >> 32
+//   u64 draws (debug / KAT entry points only) = two u32 draws, the first in the high half
 // ----------------------------------------------------------------------------
 struct Rng {
-    uint64_t s;
+    uint32_t s0, s1;
+    uint64_t draws = 0;  // numbers drawn so far (orc_hit_rng reports it)
     static inline uint64_t mix(uint64_t z) {
         z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
         z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
         return z ^ (z >> 31);
     }
-    Rng() : s(0) {}
+    static inline uint32_t rotl(uint32_t x, int k) { return (x << k) | (x >> (32 - k)); }
+    Rng() : s0(0x7F4A7C15u), s1(0x9E3779B9u) {}
     Rng(uint64_t seed, uint64_t pixel, uint64_t sample) {
         uint64_t h = mix(seed + 0x9E3779B97F4A7C15ULL * (pixel + 1));
-        s = mix(h + 0xD1B54A32D192ED03ULL * (sample + 1));
+        uint64_t s = mix(h + 0xD1B54A32D192ED03ULL * (sample + 1));
+        if (s == 0) s = 0x9E3779B97F4A7C15ULL;
+        s0 = (uint32_t)s;
+        s1 = (uint32_t)(s >> 32);
+    }
+    inline uint32_t next_u32() {
+        draws++;
+        const uint32_t r = rotl(s0 * 0x9E3779BBu, 5) * 5u;
+        s1 ^= s0;
+        s0 = rotl(s0, 26) ^ s1 ^ (s1 << 9);
+        s1 = rotl(s1, 13);
+        return r;
     }
     inline uint64_t next_u64() {
-        s += 0x9E3779B97F4A7C15ULL;
-        return mix(s);
+        const uint64_t hi = next_u32();
+        return (hi << 32) | (uint64_t)next_u32();
     }
-    inline double gen_f64() { return (double)(next_u64() >> 11) * (1.0 / 9007199254740992.0); }
+    inline double gen_f64() { return (double)next_u32() * (1.0 / 4294967296.0); }
     inline double gen_range(double lo, double hi) { return lo + (hi - lo) * gen_f64(); }
-    inline uint32_t gen_below3() { return (uint32_t)(((next_u64() >> 32) * 3ULL) >> 32); }  // gen_range(0..3)
+    inline uint32_t gen_below3() { return (uint32_t)(((uint64_t)next_u32() * 3ULL) >> 32); }  // gen_range(0..3)
 };
 
 // vec3.rs:111-129 -- Marsaglia; returns a point ON the unit sphere (quirk Q3).
@@ -1471,7 +1487,7 @@ int orc_bvh_new(void* s, int n, const int* ids, uint64_t seed) {
         v.push_back(obj(sc, ids[i]));
     }
     try {
-        Rng rng(seed, 0xB7E151628AED2A6AULL, 0);  // BVH-build stream (spec rtamd-rng-1, "bvh" key)
+        Rng rng(seed, 0xB7E151628AED2A6AULL, 0);  // BVH-build stream (spec rtamd-rng-2, "bvh" key)
         return bvh_new(sc, v, rng)->id;
     } catch (const std::exception& e) {
         sc.err = e.what();
@@ -1649,7 +1665,6 @@ int orc_hit_rng(void* s, int o, const double* orig, const double* dir, double t_
     if (!h) return ORC_ERR_ARG;
     Ctx cx;
     cx.rng = Rng(seed, pixel, sample);
-    const uint64_t s0 = cx.rng.s;
     HitRecord rec;
     Ray r{Vec3(orig[0], orig[1], orig[2]), Vec3(dir[0], dir[1], dir[2])};
     bool ok;
@@ -1658,7 +1673,7 @@ int orc_hit_rng(void* s, int o, const double* orig, const double* dir, double t_
     } catch (const UnitZero&) {
         return ORC_ERR_UNIT_ZERO;
     }
-    if (draws) *draws = (int)((cx.rng.s - s0) * 0xF1DE83E19937733DULL);  // the stream advances by 0x9E3779B97F4A7C15 per draw; this is its inverse mod 2^64
+    if (draws) *draws = (int)cx.rng.draws;
     out12[0] = ok ? 1. : 0.;
     if (ok) {
         out12[1] = rec.t;

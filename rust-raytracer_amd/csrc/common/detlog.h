@@ -6,7 +6,7 @@
 // x = 2^k (1 + f), sqrt(2)/2 < 1 + f < sqrt(2), s = f / (2 + f), log(1 + f) = 2 s + s R(s^2) with a degree-14 minimax R,
 // as published for fdlibm's e_log.c; error < 1 ulp) with IEEE +, -, *, / only and contraction off.  The test oracle restates it
 // independently, and tests/test_medium.py pins both against numpy's log to 1 ulp.
-// Domain here: x in [0, 1) from gen::<f64>() (multiples of 2^-53, so never subnormal); x == 0 -> -inf; also correct for any
+// Domain here: x in [0, 1) from gen::<f64>() (multiples of 2^-32, so never subnormal); x == 0 -> -inf; also correct for any
 // finite normal x > 0.
 #pragma once
 #include <stdint.h>

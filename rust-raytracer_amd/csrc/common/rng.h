@@ -1,4 +1,4 @@
-// rtamd-rng-1: the counter-based integer RNG that replaces rand::thread_rng()
+// rtamd-rng-2: the counter-based integer RNG that replaces rand::thread_rng()
 // (vec3.rs:98,103,112,154; material.rs:37,172; camera.rs:90; bvh.rs:61-62).
 //
 // Spec (shared by host and device code of the product; restated independently
@@ -7,14 +7,20 @@
 //            z = (z ^ (z >> 27)) * 0x94D049BB133111EB
 //            z ^ (z >> 31)                                  (SplitMix64 finaliser)
 //   stream(seed, pixel, sample):
-//            h  = mix(seed + 0x9E3779B97F4A7C15 * (pixel + 1))
-//            s0 = mix(h    + 0xD1B54A32D192ED03 * (sample + 1))
-//   next_u64: s += 0x9E3779B97F4A7C15 ; return mix(s)
-//   gen::<f64>()       = (next_u64 >> 11) * 2^-53            in [0,1)
+//            h = mix(seed + 0x9E3779B97F4A7C15 * (pixel + 1))
+//            s = mix(h    + 0xD1B54A32D192ED03 * (sample + 1)) ;  s == 0 -> 0x9E3779B97F4A7C15
+//            state (s0, s1) = (low, high) 32 bits of s
+//   next_u32 (xoroshiro64**, Blackman & Vigna 2018):
+//            r  = rotl(s0 * 0x9E3779BB, 5) * 5
+//            s1 ^= s0 ; s0 = rotl(s0, 26) ^ s1 ^ (s1 << 9) ; s1 = rotl(s1, 13) ; return r
+//   next_u64 = next_u32 << 32 | next_u32                     (first draw in the high half; debug / KAT entry points only)
+//   gen::<f64>()       = next_u32 * 2^-32                    in [0,1)
 //   gen_range(lo..hi)  = lo + (hi - lo) * gen::<f64>()
-//   gen_range(0..3)    = ((next_u64 >> 32) * 3) >> 32
+//   gen_range(0..3)    = (next_u32 * 3) >> 32
 // pixel = y * width + x of the FULL frame, sample = index in 0..spp: the value of
 // a sample never depends on how the image is tiled, chunked or spread over GPUs.
+// (rtamd-rng-1, round 1, drew every number through the SplitMix64 finaliser: two 64-bit multiplies = eight quarter-rate
+// 32-bit multiplies per draw on CDNA, 11 % of the path tracer's issue cycles; the stream seeding keeps it, once per path.)
 #pragma once
 #include <stdint.h>
 
@@ -36,14 +42,25 @@ struct Rng {
     RT_HD void seed_stream(uint64_t seed, uint64_t pixel, uint64_t sample) {
         uint64_t h = mix(seed + 0x9E3779B97F4A7C15ULL * (pixel + 1));
         s = mix(h + 0xD1B54A32D192ED03ULL * (sample + 1));
+        if (s == 0) s = 0x9E3779B97F4A7C15ULL;  // the all-zero state is xoroshiro's fixed point
+    }
+    static RT_HD uint32_t rotl32(uint32_t x, int k) { return (x << k) | (x >> (32 - k)); }
+    RT_HD uint32_t next_u32() {
+        uint32_t s0 = (uint32_t)s, s1 = (uint32_t)(s >> 32);
+        const uint32_t r = rotl32(s0 * 0x9E3779BBu, 5) * 5u;
+        s1 ^= s0;
+        s0 = rotl32(s0, 26) ^ s1 ^ (s1 << 9);
+        s1 = rotl32(s1, 13);
+        s = ((uint64_t)s1 << 32) | (uint64_t)s0;
+        return r;
     }
     RT_HD uint64_t next_u64() {
-        s += 0x9E3779B97F4A7C15ULL;
-        return mix(s);
+        const uint64_t hi = next_u32();
+        return (hi << 32) | (uint64_t)next_u32();
     }
-    RT_HD double gen_f64() { return (double)(next_u64() >> 11) * (1.0 / 9007199254740992.0); }
+    RT_HD double gen_f64() { return (double)next_u32() * (1.0 / 4294967296.0); }
     RT_HD double gen_range(double lo, double hi) { return lo + (hi - lo) * gen_f64(); }
-    RT_HD uint32_t gen_below3() { return (uint32_t)(((next_u64() >> 32) * 3ULL) >> 32); }
+    RT_HD uint32_t gen_below3() { return (uint32_t)(((uint64_t)next_u32() * 3ULL) >> 32); }
 };
 
 // key of the BVHNode::new split-axis stream: stream(bvh_seed, RT_BVH_STREAM_KEY, 0)

@@ -116,7 +116,7 @@ def test_host_rng_matches_oracle_spec():
 
 
 def test_rng_golden_vector():
-    """tests/golden/rng_kat.json pins spec rtamd-rng-1 for both restatements."""
+    """tests/golden/rng_kat.json pins spec rtamd-rng-2 for both restatements."""
     import json
     import oracle
     import rtamd

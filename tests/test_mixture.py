@@ -98,18 +98,19 @@ def test_hip_cornell_mixture_bit_exact_and_unbiased():
     assert np.array_equal(img, exp)
     coop, st = w.render(cam, width=40, height=40, spp=8, seed=1, integrator=1, kernel=5)   # the mesh instance through the request queue
     assert st["kernel_used"] == 5 and np.array_equal(coop, exp)
-    # equality in expectation on the GPU at a sample count the oracle could not afford: 8 independent renders per
+    # equality in expectation on the GPU at a sample count the oracle could not afford: 16 independent renders per
     # estimator give block means and their standard errors; the two estimators must agree within Monte-Carlo error
     def blocks(integrator, spp, seeds):
         runs = np.stack([w.render(cam, width=64, height=64, spp=spp, seed=s, integrator=integrator)[0] for s in seeds])
         b = runs.reshape(len(seeds), 8, 8, 8, 8, 3).mean(axis=(2, 4, 5))          # [run, 8, 8] block means
         return b.mean(axis=0), b.std(axis=0, ddof=1) / np.sqrt(len(seeds)), runs.mean()
-    bm, bse, btot = blocks(0, 1024, range(10, 18))
-    mm, mse, mtot = blocks(1, 256, range(20, 28))
+    bm, bse, btot = blocks(0, 1024, range(10, 26))
+    mm, mse, mtot = blocks(1, 256, range(60, 76))
     assert mtot == pytest.approx(btot, rel=0.01)
     z = (mm - bm) / np.sqrt(bse ** 2 + mse ** 2 + 1e-30)
     assert np.abs(z).max() < 6.0 and np.abs(z).mean() < 1.6, (np.abs(z).max(), np.abs(z).mean())
-    # per-sample variance: the mixture estimator is the less noisy one (standard errors at 256 vs 1024 spp)
+    # per-sample variance: the mixture estimator is the less noisy one (standard errors at 256 vs 1024 spp; the ratio is
+    # 0.72 ... 0.87 over five disjoint seed sets at 16 runs each -- 8 runs are not enough to tell)
     assert (mse ** 2).mean() * 256 < (bse ** 2).mean() * 1024
 
 
