@@ -1248,6 +1248,8 @@ struct CoopStats {
     unsigned long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = 0;  // shader-clock cycles per phase of the main loop
 };
 __device__ unsigned long long g_coop_time[8];
+#define COOP_RING_T0 const unsigned long long t_ring0 = __builtin_amdgcn_s_memtime()
+#define COOP_RING_T1 cs.tm[7] += __builtin_amdgcn_s_memtime() - t_ring0
 #define COOP_TIME(i)                                                      \
     do {                                                                  \
         const unsigned long long t_now = __builtin_amdgcn_s_memtime();    \
@@ -1270,6 +1272,8 @@ __device__ unsigned long long g_coop_time[8];
 #define COOP_TIME(i) \
     do {             \
     } while (0)
+#define COOP_RING_T0
+#define COOP_RING_T1
 #endif
 
 // Address spaces are spelled out in the pieces that run out of line (or through volatile accesses): the compiler infers them
@@ -1912,7 +1916,9 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
                     }
                 }
                 const bool need = want && ent_cur != REF_DONE;
+                COOP_RING_T0;
                 const int id = ring_pop(C.fq, __ballot(need), lane, lanemask_lt);
+                COOP_RING_T1;
                 const bool park = need && id >= 0;
                 if (park) {
                     pend &= pend - 1u;
@@ -1953,7 +1959,9 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
             uint64_t fr = __ballot(!alive);
             if ((int)__popcll(fr) < COOP_ADOPT_MIN && fr != ~0ull) fr = 0ull;
             if (fr != 0ull && ring_len(C.aq) != 0u) {
+                COOP_RING_T0;
                 const int id = ring_pop(C.aq, fr, lane, lanemask_lt);
+                COOP_RING_T1;
                 COOP_STAT(6, __ballot(id >= 0));
                 bool repost = false, freed = false, hit_inside = false;
                 if (id >= 0) {
@@ -2516,9 +2524,9 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
         HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_coop_stats), z, sizeof(z)));
         unsigned long long tm[8], tot = 0;
         HIP_CHECK(hipMemcpyFromSymbol(tm, HIP_SYMBOL(g_coop_time), sizeof(tm)));
-        for (int i = 0; i < 8; i++) tot += tm[i];
-        const char* tn[7] = {"fold + regenerate", "world-space walk", "park", "adopt", "shade", "serve (batch)", "tail: serve rest / idle"};
-        for (int i = 0; i < 7; i++) fprintf(stderr, "[coop time] %-26s %5.1f %%\n", tn[i], tot ? 100. * (double)tm[i] / (double)tot : 0.);
+        for (int i = 0; i < 7; i++) tot += tm[i];
+        const char* tn[8] = {"fold + regenerate", "world-space walk", "park", "adopt", "shade", "serve (batch)", "tail: serve rest / idle", "(of park + adopt: the two ring pops)"};
+        for (int i = 0; i < 8; i++) fprintf(stderr, "[coop time] %-26s %5.1f %%\n", tn[i], tot ? 100. * (double)tm[i] / (double)tot : 0.);
         HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_coop_time), z, sizeof(tm)));
     }
 #endif
