@@ -1418,7 +1418,8 @@ struct ServeCtx {
 // means the walk is complete.
 DEV void blas_pass_q(const ServeCtx& X, bool act, AS_L uint32_t* stk, const int stride, D3 o, D3 d, double t_min, Ray32& r, double& ht, int& hnode,
                      uint32_t& hkp, uint32_t& cur, int& sp) {
-    // (measured and dropped: publishing a pass's answers one pass later, behind their stores' round trip, -1 %; ending the descent early once fewer than 16 / 24 / 32 / 40 lanes still descend -- 631 / 574 / 547 / 517
+    // (measured and dropped: speculative descent -- a leaf reached early is set aside while the lane walks on -- 805 against 924;
+    // publishing a pass's answers one pass later, behind their stores' round trip, -1 %; ending the descent early once fewer than 16 / 24 / 32 / 40 lanes still descend -- 631 / 574 / 547 / 517
     // against 632 Msamples/s -- and testing at most 1 or 2 triangles of a leaf per pass, 543 / 612)
     while (act && (cur >> REF_TAG_SHIFT) == 0u) {
         u32x4 u0, u1;  // (lox, loy, loz, hix) (hiy, hiz, c0, c1); child 0 in the low halves
