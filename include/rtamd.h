@@ -88,8 +88,8 @@ typedef struct rt_params {
     int32_t spp_chunk;   /* samples per pixel per kernel launch; 0 = all in one launch */
     int32_t kernel;      /* 0 = auto; 1 = reference-order stackless traversal; 2 = SAH-BVH2 accel traversal (auto whenever the
                             scene has a usable accel); 5 = kernel 2's BVH with the cooperative instance service: the walks
-                            through large mesh instances are queued per workgroup and served by full waves (auto when an
-                            instance's object-space BVH has >= 8192 nodes; needs 1..32 instances, integrators 0..2).
+                            through mesh instances are queued per workgroup and served by full waves (auto when an
+                            instance's object-space BVH has >= 64 nodes; needs 1..32 instances of f32-vertex triangles).
                             All give bit-identical images (same f64 primitive tests, same tie rule). */
     int32_t device;      /* HIP device ordinal; -1 = current */
     int32_t integrator;  /* 0 = sample_ray as the reference structures it (BSDF sampling only; default);

@@ -2385,9 +2385,10 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
     const bool coop_usable = accel2_usable && general && !media && view.coop_data_ok != 0 && view.n_inst2 >= 1 && view.n_inst2 <= (uint32_t)COOP_MAX_INST &&
                              view.inst_depth2 <= (uint32_t)COOP_STACK_MAX && coop_world <= 16384 && stack5_bytes + coop_lds <= lds_max && plan.max_depth < (1 << 24);
     int kernel = plan.kernel;
-    // auto: the cooperative kernel from ~8k object-space nodes per instance (measured on the Cornell box + torus instance, 64 spp:
-    // 6,400 triangles / 4.3k nodes 597 vs 606 Msamples/s for kernel 2, 25,600 / 17k 557 vs 508, 102,400 / 68k 508 vs 434, 409,600 437 vs 383)
-    if (kernel == 0) kernel = accel2_usable ? ((coop_usable && view.max_inst_nodes2 >= 8192u) ? 5 : 2) : 1;
+    // auto: the cooperative kernel as soon as an instance is more than a handful of triangles (Cornell box + torus instance, 64 spp,
+    // kernel 5 / kernel 2 in Msamples/s: 120 triangles 1351 / 1182 (kernel 2 LDS-resident), 1 600: 1263 / 822, 25 600: 1035 / 517,
+    // 102 400: 861 / 427, 409 600: 746 / 370; the 12-triangle cube of the reference's Cornell box: 2507 / 2533)
+    if (kernel == 0) kernel = accel2_usable ? ((coop_usable && view.max_inst_nodes2 >= 64u) ? 5 : 2) : 1;
     if (kernel == 5 && !coop_usable)
         throw RtError(RT_ERR_UNSUPPORTED, "kernel 5 (cooperative instance service) needs a usable accel and 1..32 instances that hold only triangles with f32 vertices (OBJ meshes), of BVH depth <= 40");
     if ((kernel == 2 || kernel == 5) && !accel2_usable)
