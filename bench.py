@@ -151,7 +151,7 @@ def main():
     ap.add_argument("--height", type=int, default=1200)
     ap.add_argument("--spp", type=int, default=1000)
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--kernel", type=int, default=0, help="0 = library default; 1/2 force a traversal (A/B runs only)")
+    ap.add_argument("--kernel", type=int, default=0, help="0 = library default; 1 / 2 / 5 force a traversal (A/B runs only)")
     ap.add_argument("--cpu-spp", type=int, default=32, help="spp of the bounded CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
     if args.gpus < 1:
