@@ -47,21 +47,44 @@ N_SIMDS = 256 * 4      # 256 CUs x 4 SIMDs
 CPU_BASELINE_THREADS = 16
 
 
+def cpu_model():
+    """CPU model string of the box (BASELINE.md s3 asks for it beside the baseline)."""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.lower().startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(width, height, spp_cpu, seed):
-    """Oracle timed on the host cores (test infrastructure used as the reported CPU baseline)."""
+    """Oracle timed on the host cores (test infrastructure used as the reported CPU baseline).  Two points, as BASELINE.md s3
+    asks: the reference's own default `n_workers = 8` (main.rs:42) and every core this box gives one GPU (16)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle
     # the GPU box gives one GPU's share of the host (16 threads, see the task's process guard); never more
     # threads than that even though the host shows 256
     cores = min(len(os.sched_getaffinity(0)), CPU_BASELINE_THREADS)
     sc = oracle.load_scene_file(SCENE)
-    t0 = time.perf_counter()
-    _, cnt = sc.render(width, height, spp_cpu, seed=seed, n_jobs=64, n_workers=cores)
-    dt = time.perf_counter() - t0
+
+    def timed(spp, workers):
+        t0 = time.perf_counter()
+        sc.render(width, height, spp, seed=seed, n_jobs=64, n_workers=workers)  # 64 row bands = camera.rs:79
+        dt = time.perf_counter() - t0
+        return width * height * spp / dt / 1e6, dt
+
+    v_all, dt_all = timed(spp_cpu, cores)
+    ref_workers = min(8, cores)
+    spp_ref = max(1, spp_cpu // 2)
+    v_ref, dt_ref = timed(spp_ref, ref_workers)
     return {
-        "value": width * height * spp_cpu / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+        "value": v_all, "unit": "Msamples/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
         "sample": "scene_500 %dx%d at %d spp (%.1f s), 64 row-band jobs on %d threads; C++ restatement of the "
-                  "reference, not the Rust binary" % (width, height, spp_cpu, dt, cores),
+                  "reference, not the Rust binary" % (width, height, spp_cpu, dt_all, cores),
+        "reference_default": {"value": v_ref, "unit": "Msamples/s", "cores": ref_workers,
+                              "sample": "same frame at %d spp (%.1f s) with the reference's default n_workers = 8 (main.rs:42)" % (spp_ref, dt_ref)},
     }
 
 
@@ -153,6 +176,10 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--kernel", type=int, default=0, help="0 = library default; 1 / 2 / 5 force a traversal (A/B runs only)")
     ap.add_argument("--cpu-spp", type=int, default=32, help="spp of the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--force-pg", action="store_true",
+                    help="world 1 only: create the RCCL process group anyway and drive the N-rank exchange through it (init, gather of "
+                         "the f64 device rows, barrier, all_reduce(MAX)); also RTAMD_BENCH_FORCE_PG=1")
+    ap.add_argument("--frame-out", default=None, help="rank 0 writes the stitched f64 frame [H, W, 3] of the last step to this .npy file")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
@@ -182,10 +209,18 @@ def main():
     torch.cuda.set_device(dev_index)  # before the process group: RCCL binds the communicator to the current device
     dev = torch.device("cuda", dev_index)
     dist = None
-    if world_size > 1:
+    force_pg = world_size == 1 and (args.force_pg or os.environ.get("RTAMD_BENCH_FORCE_PG") == "1")
+    backend = None
+    if world_size > 1 or force_pg:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo" if rehearse else "nccl", rank=rank, world_size=world_size)
+        if force_pg and "MASTER_PORT" not in os.environ:  # plain `python bench.py --force-pg`: a one-rank rendezvous of its own
+            s = socket.socket()
+            s.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(s.getsockname()[1])
+            s.close()
+        backend = "gloo" if rehearse else "nccl"
+        dist.init_process_group(backend=backend, rank=rank, world_size=world_size)
 
     world, cam = rtamd.load_scene_file(SCENE)
     params = rtamd.default_params(width=args.width, height=args.height, spp=args.spp, max_depth=50, t_min=1e-3, seed=args.seed,
@@ -197,7 +232,7 @@ def main():
     assert stride == rtamd.tiles_owned(p0)
     d_tiles = torch.zeros(stride * 64 * 3, dtype=torch.float64, device=dev)
     frame = torch.zeros(args.height * args.width * 3, dtype=torch.float64, device=dev) if rank == 0 else None
-    gather = TileGather(layout, rank, dist, d_tiles, dst=0, host_staged=rehearse)  # receive buffer allocated once, outside the loop
+    gather = TileGather(layout, rank, dist, d_tiles, dst=0, host_staged=rehearse, force=force_pg)  # receive buffer allocated once, outside the loop
     stream = torch.cuda.current_stream().cuda_stream
 
     stats_acc = {"kernel_ms": 0.0, "launches": 0, "samples": 0}
@@ -243,7 +278,7 @@ def main():
             "metric": "Msamples/sec (px*spp), scene_500 %dx%d %dspp" % (args.width, args.height, args.spp),
             "value": value, "unit": "Msamples/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "f64", "data": "the reference's own scene file data/scene_500.json (committed copy, minified); no dataset or checkpoint involved",
             "config": {"workload": "tests/golden/scenes/scene_500.json (data/scene_500.json of the reference, minified): 1005 spheres, "
                                    "999-node file BVH, %dx%d, %d spp, depth 50, seed %d" % (args.width, args.height, args.spp, args.seed),
                        "parallelism": "image tiles 8x8 dealt round-robin to %d GPU(s), RCCL framebuffer gather" % world_size,
@@ -256,6 +291,12 @@ def main():
         }
         if hbm is not None:
             out["roofline_hbm"] = hbm
+        if backend is not None:
+            out["process_group"] = {"backend": backend + (" (RCCL)" if backend == "nccl" else ""), "world": world_size, "forced_at_world_1": bool(force_pg),
+                                    "calls": ["init_process_group", "gather", "barrier", "all_reduce(MAX)"]}
+        if args.frame_out:
+            import numpy as np
+            np.save(args.frame_out, frame.cpu().numpy().reshape(args.height, args.width, 3))
         if rehearse:
             out["rehearsal"] = "all %d ranks share HIP device 0, gather over gloo through host memory: NOT a scaling measurement" % world_size
         if world_size == 1 and args.cpu_spp > 0:

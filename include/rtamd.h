@@ -48,7 +48,8 @@ typedef enum rt_status {
     RT_ERR_NOT_COMMITTED = -8,
     RT_ERR_NO_DEVICE = -9,    /* no HIP device / HIP runtime error: there is no CPU fallback */
     RT_ERR_UNSUPPORTED = -10,
-    RT_ERR_HIP = -11
+    RT_ERR_HIP = -11,
+    RT_ERR_INTERNAL = -12     /* a device-side invariant failed (an instance below an instance reached the serving waves; a request ring overran) */
 } rt_status;
 
 typedef struct rt_scene rt_scene; /* opaque: World's object graph + its flattened device form */
@@ -125,7 +126,7 @@ typedef struct rt_tuning {
     int32_t no_lds;                /* 1: keep scene tables in global memory even when they fit LDS (A/B runs)            */
     int32_t top_nodes;             /* >= 0: cap on the BVH nodes cached in LDS when the scene lives in L2/HBM; -1 auto  */
     int32_t sub_spp;               /* 1..8: sample indices per work unit (a wave's pool = 64 px x sub_spp); 0 auto      */
-    int32_t coop_pool;             /* 1..2048: parked-path slots per workgroup in kernel 5 (small values force its in-lane fallback); 0 auto */
+    int32_t coop_pool;             /* 1..1024: parked-path slots per workgroup in kernel 5 (small values force its in-lane fallback); 0 auto */
     int32_t max_leaf;              /* 1..4: accel builder, items per leaf; 0 auto (read at rt_scene_commit)             */
     int32_t sppm_photon_capacity;  /* > 0: initial photon-buffer capacity (forces the grow-and-retry path); 0 auto      */
     int32_t sppm_knn_candidates;   /* >= 0: k-nearest candidates kept in LDS (0 forces the out-of-LDS selection); -1 auto */

@@ -457,6 +457,29 @@ def load_obj(path):
     return P, N, np.array(idx, dtype=np.uint32).reshape(-1, 3)
 
 
+def synthesize_normals(P, I):
+    """Area-weighted smooth vertex normals for a mesh that ships none (bun315.obj) -- the product's documented extension
+    (include/rtamd.h, rt_object_mesh: synthesize_normals), restated independently in plain Python floats: per triangle, in
+    index order, n = (pb - pa) x (pc - pa) is added to its three vertices (a, b, c in that order); each sum is divided by its
+    length (0 -> (0, 1, 0)).  The reference itself would panic on such a mesh (mesh.rs:62)."""
+    import math
+    acc = [[0.0, 0.0, 0.0] for _ in range(len(P))]
+    Pl = [[float(x) for x in p] for p in P]
+    for tri in I:
+        a, b, c = int(tri[0]), int(tri[1]), int(tri[2])
+        e0 = [Pl[b][i] - Pl[a][i] for i in range(3)]
+        e1 = [Pl[c][i] - Pl[a][i] for i in range(3)]
+        n = [e0[1] * e1[2] - e0[2] * e1[1], e0[2] * e1[0] - e0[0] * e1[2], e0[0] * e1[1] - e0[1] * e1[0]]
+        for v in (a, b, c):
+            for i in range(3):
+                acc[v][i] += n[i]
+    out = np.zeros((len(P), 3))
+    for v, n in enumerate(acc):
+        l = math.sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2])
+        out[v] = (0.0, 1.0, 0.0) if l == 0.0 else (n[0] / l, n[1] / l, n[2] / l)
+    return out
+
+
 def cornell_box_scene(cube_obj_path, aspect_ratio=1.0, seed=1):
     """scene.rs:16-112 (cornell_box_scene), numbers verbatim."""
     sc = Scene()

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 
 #include "common/rng.h"
@@ -17,8 +18,14 @@ using namespace rtamd;
 
 static thread_local std::string g_err;
 static Tuning g_tuning;
+static std::mutex g_tuning_mu;
 namespace rtamd {
-const Tuning& tuning() { return g_tuning; }
+// a consistent snapshot: callers take ONE copy per API call (render_tiles, render_sppm, accel_build_bvh, make_plan) and pass
+// it down, so a concurrent rt_tuning_set can never make one render see two different settings
+Tuning tuning() {
+    std::lock_guard<std::mutex> g(g_tuning_mu);
+    return g_tuning;
+}
 }  // namespace rtamd
 
 rt_scene::~rt_scene() { free_device_copies(*this); }
@@ -99,7 +106,10 @@ int rt_tuning_set(const rt_tuning* t) {
         n.sppm_cap = std::max(0, t->sppm_photon_capacity);
         n.knn_cand = t->sppm_knn_candidates < 0 ? -1 : t->sppm_knn_candidates;
         n.c_box = t->sah_box_cost;
-        g_tuning = n;
+        {
+            std::lock_guard<std::mutex> g(g_tuning_mu);
+            g_tuning = n;
+        }
         return (int)RT_OK;
     });
 }
@@ -469,7 +479,8 @@ static RenderPlan make_plan(const rt_params* p) {
     int64_t subs = std::max<int64_t>(1, want_units / std::max<int64_t>(1, pl.tiles_owned));
     int sub = (int)((chunk + subs - 1) / subs);
     pl.sub_spp = std::max(std::min(chunk, 4), std::min(sub, 8));
-    if (tuning().sub_spp > 0) pl.sub_spp = std::max(1, std::min(std::min(chunk, 8), tuning().sub_spp));  // rt_tuning (A/B runs)
+    const int tun_sub_spp = tuning().sub_spp;
+    if (tun_sub_spp > 0) pl.sub_spp = std::max(1, std::min(std::min(chunk, 8), tun_sub_spp));  // rt_tuning (A/B runs)
     {   // at most 2^31 work units per launch
         const int64_t max_chunk = ((int64_t(1) << 31) - 1) / std::max<int64_t>(1, pl.tiles_owned) * pl.sub_spp;
         if (max_chunk < 1) throw RtError(RT_ERR_UNSUPPORTED, "image too large for one rank");

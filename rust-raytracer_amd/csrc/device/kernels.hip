@@ -1203,6 +1203,13 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
 // Ring capacity: twice the pool, so that a ring position is written again only after 1024 further pops have gone by since a
 // consumer reserved it (a consumer reads its entry a few instructions after it has advanced the head).
 #define COOP_RING (2 * COOP_POOL)
+static_assert(COOP_RING >= 2 * COOP_POOL && COOP_POOL <= 32768 && (COOP_RING & (COOP_RING - 1)) == 0,
+              "kernel 5's rings: 16-bit entries (id + 1), power-of-two capacity of at least twice the pool (see ring_pop)");
+// Build requirement (not checkable here): no -mtgsplit -- the waves of a workgroup must share one CU's L1 (record visibility
+// after s_waitcnt vmcnt(0), see COOP_REC below).
+#ifndef COOP_SPIN_MAX
+#define COOP_SPIN_MAX (1u << 16)  // LDS polls a consumer spends on an unpublished ring entry before it declares the ring overrun
+#endif
 #ifndef COOP_BATCH
 #define COOP_BATCH 32       // a wave starts serving once this many requests wait (16: -3 %, 64: -2 %, 128: -5 %)
 #endif
@@ -1282,6 +1289,7 @@ __device__ unsigned long long g_coop_time[8];
 struct CoopRing {  // multi-producer multi-consumer ring of slot ids in LDS; entries are id + 1 (16 bit), 0 = not yet written
     volatile AS_L uint16_t* buf;
     AS_L uint32_t* ht;  // {head, tail}: monotonic counters
+    AS_L uint32_t* abort_flag;  // workgroup-wide: set when an entry was not published in time (ring overrun): every wave leaves
 };
 DEV uint32_t lds_load(const AS_L uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 DEV uint32_t ring_len(const CoopRing& R) { return lds_load(&R.ht[1]) - lds_load(&R.ht[0]); }
@@ -1319,10 +1327,17 @@ DEV int ring_pop(const CoopRing& R, uint64_t want, int lane, uint64_t lanemask_l
     int id = -1;
     if (((want >> lane) & 1ull) != 0ull && rank < (int)k) {
         const uint32_t slot = (h0 + (uint32_t)rank) & (COOP_RING - 1);
-        uint32_t v;
-        do { v = R.buf[slot]; } while (v == 0u);  // its producer reserved the slot and writes it within a few instructions
-        R.buf[slot] = (uint16_t)0;
-        id = (int)v - 1;
+        // its producer reserved the slot and writes it within a few instructions.  The poll is bounded: if the entry never
+        // shows up (a consumer so late that the ring wrapped over its position would have consumed another slot's id), the
+        // workgroup gives up -- error bit 4, RT_ERR_INTERNAL -- instead of spinning for ever.
+        uint32_t v, spins = 0u;
+        do { v = R.buf[slot]; } while (v == 0u && ++spins < COOP_SPIN_MAX);
+        if (v == 0u) {
+            __hip_atomic_store(R.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+            R.buf[slot] = (uint16_t)0;
+            id = (int)v - 1;
+        }
     }
     return id;
 }
@@ -1504,6 +1519,7 @@ DEV CoopLds coop_rings(AS_L char* at) {  // [RQ | AQ | FQ: COOP_RING 16-bit entr
     C.rq.ht = cnt;
     C.aq.ht = cnt + 2;
     C.fq.ht = cnt + 4;
+    C.rq.abort_flag = C.aq.abort_flag = C.fq.abort_flag = cnt + 6;
     return C;
 }
 struct CoopCtx {
@@ -2084,6 +2100,9 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
                     coop_serve(cargs, smem, stk, false COOP_STATS_PASS);
                 } else if (finished && ring_len(C.fq) == (uint32_t)rk.coop_pool) {  // every pool slot is free again: no path is parked
                     break;
+                } else if (lds_load(C.rq.abort_flag) != 0u) {  // a ring overran (ring_pop): the frame is lost, leave instead of hanging
+                    if (lane == 0) atomicOr(err, 4);
+                    break;
                 } else {
                     COOP_STAT(5, 0ull);
                     __builtin_amdgcn_s_sleep(8);  // other waves hold what this one waits for
@@ -2359,6 +2378,7 @@ static pt_fn pick_pt_kernel(bool lds, bool general, int integ) {
 
 void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& plan_in, double* d_tiles, void* stream_, rt_stats* st) {
     if (!s.committed) throw RtError(RT_ERR_NOT_COMMITTED, "scene not committed");
+    const Tuning tun = tuning();  // one snapshot per call
     const RenderPlan& plan = plan_in;
     hipStream_t stream = (hipStream_t)stream_;
     int dev = 0;
@@ -2397,7 +2417,7 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
     const size_t ring_meta = ((size_t)(PT_BLOCK / 64) * (RING_UNITS * 4 + 8) + CFG_WORDS) * sizeof(uint32_t);  // ring / job bookkeeping, behind the stacks
     const size_t stack_bytes = ((kernel == 2) ? stack2_bytes : (kernel == 5) ? stack5_bytes : 0) + ring_meta + ((kernel == 5) ? coop_lds : 0);
     const size_t hot_bytes = (kernel == 2 || kernel == 5) ? hot2 : hot1;
-    const bool lds = hot_bytes > 0 && hot_bytes + stack_bytes <= lds_max && !tuning().no_lds && kernel != 5;  // kernel 5: scene in L2/HBM always
+    const bool lds = hot_bytes > 0 && hot_bytes + stack_bytes <= lds_max && !tun.no_lds && kernel != 5;  // kernel 5: scene in L2/HBM always
     const int integ = plan.integrator;
     if (integ == 1 && view.n_lights == 0) throw RtError(RT_ERR_ARG, "integrator 1 (light importance sampling) needs rt_scene_set_lights");
     if (integ == 2 && !plan.sppm_est) throw RtError(RT_ERR_ARG, "integrator 2 (SPPM) is reached through rt_render_sppm");
@@ -2413,16 +2433,16 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
     int n_top = 0, n_topq = 0;
     if (kernel == 2 && !lds && lds_max > stack_bytes) {
         size_t room = (lds_max - stack_bytes) / sizeof(Node2);
-        if (tuning().n_top >= 0) room = std::min<size_t>(room, (size_t)tuning().n_top);
+        if (tun.n_top >= 0) room = std::min<size_t>(room, (size_t)tun.n_top);
         n_top = (int)std::min<size_t>(room, view.n_nodes2);
     }
     if (kernel == 5 && lds_max > stack_bytes) {  // f32 nodes for the world-space walk (at most 128), the rest of LDS for the compact object-space nodes
         size_t room = lds_max - stack_bytes;
         n_top = (int)std::min<size_t>(std::min<size_t>(room / sizeof(Node2), 128), view.world_top2);
-        if (tuning().n_top >= 0) n_top = std::min(n_top, tuning().n_top);
+        if (tun.n_top >= 0) n_top = std::min(n_top, tun.n_top);
         room -= (size_t)n_top * sizeof(Node2);
         n_topq = (int)std::min<size_t>(room / sizeof(NodeQ), view.n_nodes2);
-        if (tuning().n_top >= 0) n_topq = std::min(n_topq, tuning().n_top);
+        if (tun.n_top >= 0) n_topq = std::min(n_topq, tun.n_top);
     }
     const size_t smem = (lds ? hot_bytes : (size_t)n_top * sizeof(Node2) + (size_t)n_topq * sizeof(NodeQ)) + stack_bytes;
     const void* fptr = (kernel == 5) ? (const void*)fn_coop : (const void*)fn;
@@ -2470,7 +2490,7 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
         rk.n_top = n_top;
         rk.n_topq = n_topq;
         rk.coop_stack = (int)stack5;
-        rk.coop_pool = tuning().coop_pool > 0 ? std::min(tuning().coop_pool, (int)COOP_POOL) : (int)COOP_POOL;
+        rk.coop_pool = tun.coop_pool > 0 ? std::min(tun.coop_pool, (int)COOP_POOL) : (int)COOP_POOL;
         HIP_CHECK(hipMemsetAsync(counter.p, 0, sizeof(unsigned int), stream));
         HIP_CHECK(hipMemsetAsync(tickets.p, 0, std::max<size_t>(16, (size_t)plan.tiles_owned * sizeof(unsigned int)), stream));
         hipEvent_t e0 = events.make(), e1 = events.make();
@@ -2541,7 +2561,9 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
         HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_fold_stats), z, sizeof(z)));
     }
 #endif
-    if (h_err) throw RtError(RT_ERR_UNIT_ZERO, "unitizing zero vector (device)");
+    if (h_err & 1) throw RtError(RT_ERR_UNIT_ZERO, "unitizing zero vector (device)");
+    if (h_err & ~1) throw RtError(RT_ERR_INTERNAL, "device invariant failed (error bits " + std::to_string(h_err) + ": 2 = an instance below an instance "
+                                                   "reached an object-space walk, 4 = a kernel 5 ring entry was not published in time)");
 }
 
 // ---------------------------------------------------------------- SPPM driver ----
@@ -2646,6 +2668,7 @@ struct PhotonStore {
 void render_sppm(const rt_scene& s, const CameraDev& cam, RenderPlan plan, const rt_sppm_config& cfg, double* d_tiles, double* stats_host,
                  void* stream_, rt_stats* st, uint64_t* totals2) {
     if (!s.committed) throw RtError(RT_ERR_NOT_COMMITTED, "scene not committed");
+    const Tuning tun = tuning();  // one snapshot per call
     if (s.lights.empty()) throw RtError(RT_ERR_ARG, "SPPM needs lights (rt_scene_set_lights)");
     if (s.flat.view.kinds_mask & (1u << NK_MEDIUM_BEGIN))
         throw RtError(RT_ERR_UNSUPPORTED, "the SPPM pre-pass does not support ConstantMedium (volume events have no photon-map estimate)");
@@ -2663,7 +2686,7 @@ void render_sppm(const rt_scene& s, const CameraDev& cam, RenderPlan plan, const
     // photon pass: stage the accel's hot tables into LDS when at least two 256-thread blocks still fit on a CU
     const size_t hot2 = (size_t)(view.stage2_end - view.stage2_begin);
     const size_t smem_photon = hot2 + smem;
-    const bool photon_lds = accel && hot2 > 0 && 2 * smem_photon <= di.lds_max && !tuning().no_lds;
+    const bool photon_lds = accel && hot2 > 0 && 2 * smem_photon <= di.lds_max && !tun.no_lds;
     if (photon_lds && smem_photon > 48 * 1024)
         HIP_CHECK(hipFuncSetAttribute((const void*)photon_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_photon));
 
@@ -2724,7 +2747,7 @@ void render_sppm(const rt_scene& s, const CameraDev& cam, RenderPlan plan, const
     PhotonStore pg[2], pc[2];
     unsigned int cap_g = (unsigned int)std::min<uint64_t>((uint64_t)cfg.photons_per_iter * 8 + 1024, 0x7FFFFFFFu);
     unsigned int cap_c = (unsigned int)std::min<uint64_t>((uint64_t)cfg.photons_per_iter * 2 + 1024, 0x7FFFFFFFu);
-    if (tuning().sppm_cap > 0) cap_g = cap_c = (unsigned int)tuning().sppm_cap;  // rt_tuning test hook: forces the grow-and-retry path
+    if (tun.sppm_cap > 0) cap_g = cap_c = (unsigned int)tun.sppm_cap;  // rt_tuning test hook: forces the grow-and-retry path
     for (int j = 0; j < 2; j++) {
         pg[j].alloc(cap_g);
         pc[j].alloc(cap_c);
@@ -2738,7 +2761,7 @@ void render_sppm(const rt_scene& s, const CameraDev& cam, RenderPlan plan, const
     sk.k_global = cfg.k_global; sk.k_caustic = cfg.k_caustic; sk.max_bounces = cfg.max_bounces; sk.alpha = cfg.alpha;
     sk.seed = plan.seed; sk.S = S; sk.iteration = 0;
     sk.knn_cand = KNN_CAND;
-    if (tuning().knn_cand >= 0) sk.knn_cand = std::min(KNN_CAND, tuning().knn_cand);  // rt_tuning test hook: forces the out-of-LDS selection
+    if (tun.knn_cand >= 0) sk.knn_cand = std::min(KNN_CAND, tun.knn_cand);  // rt_tuning test hook: forces the out-of-LDS selection
     // persistent photon waves: enough 256-thread blocks to fill every CU at 4 waves per SIMD, never more waves than chunks
     const int pblocks = (int)std::max<int64_t>(1, std::min<int64_t>(((int64_t)cfg.photons_per_iter + 4 * PHOTON_CHUNK - 1) / (4 * PHOTON_CHUNK), (int64_t)di.cus * 4));
     const int eblocks = (int)std::min<size_t>((npix + 255) / 256, (size_t)di.cus * 8);

@@ -45,16 +45,16 @@ struct Ctx {
     AccelBuild& out;
     std::vector<AccelItem>& items;
     double pad;
+    double c_box;  // rt_tuning.sah_box_cost and .max_leaf, snapshotted once per build (read at commit time)
+    int max_leaf;
 };
 
 const double C_PRIM = 2.0;  // relative costs of a child-box pair test (c_box()) and a primitive test
-double c_box() { return tuning().c_box > 0. ? tuning().c_box : 1.0; }  // rt_tuning.sah_box_cost, read at commit time
 #ifndef RT_SAH_BINS
 #define RT_SAH_BINS 32  // (16: headline -0.4 %, 64: +-0)
 #endif
 const int BINS = RT_SAH_BINS;
-int max_leaf() {  // items per leaf, 1..ACCEL_DEFAULT_LEAF (rt_tuning.max_leaf, read at commit time)
-    const int m = tuning().max_leaf;
+int clamp_max_leaf(int m) {  // items per leaf, 1..ACCEL_DEFAULT_LEAF
     return m < 1 ? ACCEL_DEFAULT_LEAF : (m > ACCEL_DEFAULT_LEAF ? ACCEL_DEFAULT_LEAF : m);
 }
 
@@ -71,7 +71,9 @@ uint32_t make_leaf(Ctx& c, int begin, int end) {
     return REF_LEAF | ((uint32_t)(end - begin - 1) << REF_LEAF_COUNT_SHIFT) | first;
 }
 
-uint32_t build(Ctx& c, int begin, int end, int depth) {
+// force_split: the root of a BVH with >= 2 items is always an inner node with two real children, so that every BVH starts with
+// a box test and no node needs an "empty" child
+uint32_t build(Ctx& c, int begin, int end, int depth, bool force_split = false) {
     if (depth > c.out.max_depth) c.out.max_depth = depth;
     const int n = end - begin;
     bool has_instance = false;  // an instance must sit alone in its leaf (the traversal enters one instance per leaf)
@@ -130,12 +132,12 @@ uint32_t build(Ctx& c, int begin, int end, int depth) {
             acc = merge(acc, bb[b]);
             k += cnt[b];
             if (k == 0 || right_cnt[b + 1] == 0) continue;
-            double cost = c_box() + C_PRIM * (area(acc) * k + right_area[b + 1] * right_cnt[b + 1]) / parent_area;
+            double cost = c.c_box + C_PRIM * (area(acc) * k + right_area[b + 1] * right_cnt[b + 1]) / parent_area;
             if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = b; }
         }
     }
     int mid = -1;
-    if (best_axis >= 0 && (n > max_leaf() || has_instance || best_cost < C_PRIM * n)) {
+    if (best_axis >= 0 && (n > c.max_leaf || has_instance || force_split || best_cost < C_PRIM * n)) {
         double lo = cb.mn[best_axis], ext = cb.mx[best_axis] - cb.mn[best_axis];
         auto it = std::stable_partition(c.items.begin() + begin, c.items.begin() + end, [&](const AccelItem& it2) {
             double ctr = 0.5 * (it2.box.mn[best_axis] + it2.box.mx[best_axis]);
@@ -148,7 +150,7 @@ uint32_t build(Ctx& c, int begin, int end, int depth) {
         if (mid == begin || mid == end) mid = -1;
     }
     if (mid < 0) {
-        if (n <= max_leaf() && !has_instance) return make_leaf(c, begin, end);
+        if (n <= c.max_leaf && !has_instance && !force_split) return make_leaf(c, begin, end);
         mid = begin + n / 2;  // identical centroids (e.g. concentric spheres): split by index
     }
     uint32_t idx = (uint32_t)c.out.nodes.size();
@@ -183,46 +185,32 @@ uint32_t accel_build_bvh(AccelBuild& out, std::vector<AccelItem>& items, double 
                 out.ok = false;
                 return REF_DONE;
             }
-    Ctx c{out, items, pad};
+    const Tuning tun = tuning();
+    Ctx c{out, items, pad, tun.c_box > 0. ? tun.c_box : 1.0, clamp_max_leaf(tun.max_leaf)};
     if (items.size() == 1) {
-        // a single item still needs one inner node so that the root is box-tested like everything else
+        // A single item still gets one inner node so that the root is box-tested like everything else.  Its second child is a
+        // ZERO-SIZE box at the low corner of the first (finite, inside the BVH's bounds, quantisable like any other box): a ray
+        // passes the slab test of a point only when it goes through it to within the test's 1e-6 relative slack, and if one
+        // ever does, re-testing the same item changes nothing (tie rule by order).  An inverted or infinite "empty" box does
+        // NOT work here: the slab test takes min/max per axis, so +-inf bounds pass every ray.
         uint32_t idx = (uint32_t)out.nodes.size();
         out.nodes.push_back(Node2{});
         uint32_t leaf = make_leaf(c, 0, 1);
         Node2& nd = out.nodes[idx];
         const Box& b = items[0].box;
-        const float inf = std::numeric_limits<float>::infinity();
         nd.lo_x[0] = round_down(b.mn[0] - pad); nd.hi_x[0] = round_up(b.mx[0] + pad);
         nd.lo_y[0] = round_down(b.mn[1] - pad); nd.hi_y[0] = round_up(b.mx[1] + pad);
         nd.lo_z[0] = round_down(b.mn[2] - pad); nd.hi_z[0] = round_up(b.mx[2] + pad);
-        nd.lo_x[1] = nd.lo_y[1] = nd.lo_z[1] = inf;  // empty second child: never hit
-        nd.hi_x[1] = nd.hi_y[1] = nd.hi_z[1] = -inf;
+        nd.lo_x[1] = nd.hi_x[1] = nd.lo_x[0];
+        nd.lo_y[1] = nd.hi_y[1] = nd.lo_y[0];
+        nd.lo_z[1] = nd.hi_z[1] = nd.lo_z[0];
         nd.child[0] = leaf;
-        nd.child[1] = leaf;  // never reached (empty box); if it ever were, re-testing the same item is harmless
-        if (depth0 + 1 > out.max_depth) out.max_depth = depth0 + 1;
-        return idx;
-    }
-    uint32_t root = build(c, 0, (int)items.size(), depth0);
-    if (out.ok && (root >> REF_TAG_SHIFT) == 1u) {
-        // the SAH kept everything in one leaf: still give the BVH an inner root so that every BVH starts with a box test
-        Box all = empty_box();
-        for (auto& it : items) all = merge(all, it.box);
-        uint32_t idx = (uint32_t)out.nodes.size();
-        out.nodes.push_back(Node2{});
-        Node2& nd = out.nodes[idx];
-        const float inf = std::numeric_limits<float>::infinity();
-        nd.lo_x[0] = round_down(all.mn[0] - pad); nd.hi_x[0] = round_up(all.mx[0] + pad);
-        nd.lo_y[0] = round_down(all.mn[1] - pad); nd.hi_y[0] = round_up(all.mx[1] + pad);
-        nd.lo_z[0] = round_down(all.mn[2] - pad); nd.hi_z[0] = round_up(all.mx[2] + pad);
-        nd.lo_x[1] = nd.lo_y[1] = nd.lo_z[1] = inf;
-        nd.hi_x[1] = nd.hi_y[1] = nd.hi_z[1] = -inf;
-        nd.child[0] = root;
-        nd.child[1] = root;
+        nd.child[1] = leaf;
         nd.pad[0] = nd.pad[1] = 0;
         if (depth0 + 1 > out.max_depth) out.max_depth = depth0 + 1;
         return idx;
     }
-    return root;
+    return build(c, 0, (int)items.size(), depth0, true);
 }
 
 }  // namespace rtamd

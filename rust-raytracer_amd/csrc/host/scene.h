@@ -96,7 +96,7 @@ struct Tuning {
     int no_lds = 0, n_top = -1, sub_spp = 0, max_leaf = 0, sppm_cap = 0, knn_cand = -1, coop_pool = 0;
     double c_box = 0.;
 };
-const Tuning& tuning();
+Tuning tuning();  // a snapshot (copied under a mutex): take one per API call
 
 // builders (throw RtError)
 int add_texture_constant(rt_scene& s, const double c[3]);

@@ -20,7 +20,7 @@ RT_OK = 0
 ERR_NAMES = {
     -1: "RT_ERR_ARG", -2: "RT_ERR_UNIT_ZERO", -3: "RT_ERR_NO_BBOX", -4: "RT_ERR_SINGULAR", -5: "RT_ERR_IO",
     -6: "RT_ERR_SCHEMA", -7: "RT_ERR_NO_NORMALS", -8: "RT_ERR_NOT_COMMITTED", -9: "RT_ERR_NO_DEVICE",
-    -10: "RT_ERR_UNSUPPORTED", -11: "RT_ERR_HIP",
+    -10: "RT_ERR_UNSUPPORTED", -11: "RT_ERR_HIP", -12: "RT_ERR_INTERNAL",
 }
 
 

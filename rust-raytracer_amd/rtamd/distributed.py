@@ -57,25 +57,28 @@ class TileGather:
     The receive side is ONE rank-major buffer [world, stride*192] allocated once; `dist.gather` writes straight into its
     rows and `gathered` is handed to the stitch as it is (no per-frame allocation, no torch.cat copy).
     host_staged=True moves the payload through host memory -- only for rehearsing world > 1 on a box whose ranks share
-    one GPU (RCCL refuses two ranks on one device, so the rehearsal runs over gloo)."""
+    one GPU (RCCL refuses two ranks on one device, so the rehearsal runs over gloo).
+    force=True runs the exchange even at world 1 (a one-row gather into the receive buffer): the way to execute the
+    RCCL calls of the N-rank path -- communicator init, gather of f64 device rows -- on a box with a single GPU."""
 
-    def __init__(self, layout, rank, dist, like, dst=0, host_staged=False):
+    def __init__(self, layout, rank, dist, like, dst=0, host_staged=False, force=False):
         import torch
         self.layout, self.rank, self.dist, self.dst, self.host_staged = layout, rank, dist, dst, host_staged
+        self.exchange = layout.world > 1 or (force and dist is not None)
         self.gathered = None
         self.rows = None
         self._host_in = None
         n = layout.stride * TILE_PIX * 3
-        if layout.world > 1 and rank == dst:
+        if self.exchange and rank == dst:
             dev = torch.device("cpu") if host_staged else like.device
             self.gathered = torch.empty((layout.world, n), dtype=like.dtype, device=dev)
             self.rows = list(self.gathered.unbind(0))
             self._dev_out = torch.empty((layout.world, n), dtype=like.dtype, device=like.device) if host_staged else None
-        if layout.world > 1 and host_staged:
+        if self.exchange and host_staged:
             self._host_in = torch.empty(n, dtype=like.dtype, device="cpu")
 
     def __call__(self, local_tiles):
-        if self.layout.world == 1:
+        if not self.exchange:
             return local_tiles
         src = local_tiles
         if self.host_staged:

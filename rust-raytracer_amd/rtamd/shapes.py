@@ -30,19 +30,23 @@ def torus(nu=160, nv=320, R=1.0, r=0.4):
 
 
 def cornell_with_mesh(world_or_scene, positions, normals, indices, scale=120.0, translate=(278.0, 200.0, 278.0), rotate=(30.0, 20.0, 0.0),
-                      seed=1):
+                      seed=1, mesh_fn=None):
     """scene.rs:16-112 with the cube.obj mesh replaced by a given mesh (C4).  Works on both builders
     (rtamd.World and the oracle's Scene) since they share the reference's constructor names.
+    mesh_fn(builder, material) -> mesh object replaces the Mesh(positions, normals, indices) call (e.g. Mesh::load_obj on a file).
     Returns the list of top-level hitables (to be passed to World::new)."""
     w = world_or_scene
     red = w.Lambertian(w.ConstantTexture((0.75, 0.25, 0.25)))
     white = w.Lambertian(w.ConstantTexture((0.75, 0.75, 0.75)))
     blue = w.Lambertian(w.ConstantTexture((0.25, 0.25, 0.75)))
     light = w.DiffuseLight(w.ConstantTexture((1.0, 1.0, 1.0)))
-    try:
-        mesh = w.Mesh(positions, normals, indices, white, bvh_seed=seed)
-    except TypeError:
-        mesh = w.Mesh(positions, normals, indices, white, seed)
+    if mesh_fn is not None:
+        mesh = mesh_fn(w, white)
+    else:
+        try:
+            mesh = w.Mesh(positions, normals, indices, white, bvh_seed=seed)
+        except TypeError:
+            mesh = w.Mesh(positions, normals, indices, white, seed)
     return [
         w.YZRectangle((0.0, 0.0), (555.0, 555.0), 555.0, red),
         w.YZRectangle((0.0, 0.0), (555.0, 555.0), 0.0, blue),

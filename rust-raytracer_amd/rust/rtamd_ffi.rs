@@ -120,7 +120,7 @@ pub struct rt_sppm_config {
 }
 
 #[repr(C)]
-#[derive(Clone, Copy, Default)]
+#[derive(Clone, Copy)]
 pub struct rt_tuning {
     pub no_lds: i32,
     pub top_nodes: i32,
@@ -130,6 +130,17 @@ pub struct rt_tuning {
     pub sppm_photon_capacity: i32,
     pub sppm_knn_candidates: i32,
     pub sah_box_cost: c_double,
+}
+
+/// The library's defaults (`rt_tuning_default`): "automatic" is -1 for `top_nodes` and `sppm_knn_candidates`, NOT zero, so
+/// this cannot be derived -- an all-zero block would cap the LDS node cache at 0 and force the out-of-LDS k-nearest selection.
+impl Default for rt_tuning {
+    fn default() -> Self {
+        let mut t = rt_tuning { no_lds: 0, top_nodes: -1, sub_spp: 0, coop_pool: 0, max_leaf: 0, sppm_photon_capacity: 0,
+                                sppm_knn_candidates: -1, sah_box_cost: 0.0 };
+        unsafe { rt_tuning_default(&mut t) };
+        t
+    }
 }
 
 #[repr(C)]

@@ -93,3 +93,43 @@ def test_two_rank_branch_of_bench_rehearsed_on_one_gpu():
     import rtamd
     if rtamd.device_count() < 2:
         assert r.returncode != 0 and "only 1 HIP device" in r.stderr
+
+
+def _plain_frame(width, height, spp):
+    import rtamd
+    world, cam = rtamd.load_scene_file(os.path.join(ROOT, "tests", "golden", "scenes", "scene_500.json"))
+    img, _ = world.render(cam, width=width, height=height, spp=spp, seed=1)
+    return img
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("how", ["flag", "torchrun_env"])
+def test_forced_process_group_runs_the_rccl_exchange_at_world_1(how, tmp_path):
+    """The N-rank path's RCCL calls executed on the one GPU there is: init_process_group("nccl"), dist.gather of the f64 device
+    rows into the receive buffer, barrier, all_reduce(MAX), then the device stitch -- in a child process that starts before this
+    one touches the GPU for it.  The stitched frame must equal the plain render bit for bit (camera.rs:77,108,115-123)."""
+    import numpy as np
+    out_npy = str(tmp_path / "frame.npy")
+    args = ["--gpus", "1", "--steps", "2", "--warmup", "1", "--width", "96", "--height", "72", "--spp", "8", "--cpu-spp", "0", "--frame-out", out_npy]
+    env = {}
+    if how == "flag":
+        args.append("--force-pg")
+    else:  # the environment torch.distributed.run gives a rank
+        import socket
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        env = {"RTAMD_BENCH_FORCE_PG": "1", "RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)}
+    env_all = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "RTAMD_BENCH_FORCE_PG"):
+        env_all.pop(k, None)
+    env_all.update(env)
+    r = subprocess.run([sys.executable, BENCH] + args, capture_output=True, text=True, env=env_all, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    pg = out["process_group"]
+    assert pg["backend"].startswith("nccl") and pg["world"] == 1 and pg["forced_at_world_1"] is True
+    assert out["n_gpus"] == 1 and out["value"] > 0
+    got = np.load(out_npy)
+    assert got.shape == (72, 96, 3) and np.array_equal(got, _plain_frame(96, 72, 8))
