@@ -211,7 +211,13 @@ def main():
     dist = None
     force_pg = world_size == 1 and (args.force_pg or os.environ.get("RTAMD_BENCH_FORCE_PG") == "1")
     backend = None
+    json_fd = None
     if world_size > 1 or force_pg:
+        # RCCL prints its version banner on stdout when the communicator is created (NCCL_DEBUG=VERSION/WARN on these boxes):
+        # everything the libraries write to fd 1 goes to stderr, and the ONE JSON line goes to the real stdout at the end
+        sys.stdout.flush()
+        json_fd = os.dup(1)
+        os.dup2(2, 1)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if force_pg and "MASTER_PORT" not in os.environ:  # plain `python bench.py --force-pg`: a one-rank rendezvous of its own
@@ -301,7 +307,11 @@ def main():
             out["rehearsal"] = "all %d ranks share HIP device 0, gather over gloo through host memory: NOT a scaling measurement" % world_size
         if world_size == 1 and args.cpu_spp > 0:
             out["cpu_baseline"] = cpu_baseline(args.width, args.height, args.cpu_spp, args.seed)
-        print(json.dumps(out))
+        if json_fd is not None:
+            sys.stdout.flush()
+            os.write(json_fd, (json.dumps(out) + "\n").encode())
+        else:
+            print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
 
