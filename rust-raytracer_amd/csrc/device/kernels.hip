@@ -129,6 +129,7 @@ struct Acc {  // typed views into the blob (LDS or global; the address space is 
                                // typed with its address space: a generic pointer here lets the compiler fold the cached / uncached
                                // node loads into one FLAT load of a selected address
     uint32_t n2_top_count;
+    uint32_t n2w_lds;        // LDS byte address of the NodeW table (kernel 2 with the scene in LDS; see box32w)
     const double* xforms;    // 32 per transform: M^-1 then M, row-major
     const MatDev* mats;
     const TexDev* texs;
@@ -163,6 +164,7 @@ DEV Acc make_acc(P hot, const char* gbase, const FlatView& v) {  // hot: LDS cop
     a.tripre2 = (const double2*)(hot + v.off_tripre2);
     a.n2_top = nullptr;
     a.n2_top_count = 0;
+    a.n2w_lds = 0;
     a.xforms = (const double*)(hot + v.off_xforms);
     a.vpos = (const double*)(gbase + v.off_vpos);
     a.sphere_mat = (const int*)(gbase + v.off_sphere_mat);
@@ -432,6 +434,7 @@ DEV Hit traverse(const Acc& A, D3 wo, D3 wd, double t_min, double t_max, Rng* rn
 struct Ray32 {
     float cx, cy, cz, ix, iy, iz;  // c = fl(of * iv)
     float tmin, best;  // rounded outward
+    uint32_t ax, ay, az;  // WIDE nodes only: LDS byte address of the node table + 8 * axis + 32 * (iv_axis < 0), see NodeW
 };
 DEV float f32_down(double x) { float f = (float)x; return __builtin_fmaf(-fabsf(f), 1.1920929e-7f, f); }
 DEV float f32_up(double x) { float f = (float)x; return __builtin_fmaf(fabsf(f), 1.1920929e-7f, f); }
@@ -448,6 +451,49 @@ DEV Ray32 make_ray32(D3 o, D3 d, double t_min, double best) {  // d: the ray's d
     r.tmin = f32_down(t_min);
     r.best = ray32_best(best);
     return r;
+}
+// WIDE node table (LDS-resident scenes): the lanes pick each axis' NEAR and FAR plane by ADDRESS instead of by min / max.
+// A NodeW is three 32-byte blocks [x pair, y pair, z pair, child refs] = {lo, hi, lo again}, a pair = (child 0, child 1),
+// NODEW_FAR bytes apart: the block at + NODEW_FAR * s (s = 1 iff the ray runs down that axis, iv < 0) holds the near planes, the
+// block NODEW_FAR further the far planes, so one address per axis (cur + r.a?) and the immediate offsets 0 / + NODEW_FAR read them,
+// and the child refs sit at +24 of every block.  With lo <= hi (host) and fma monotonic in its first operand, fma(near) =
+// min(fma(lo), fma(hi)) and fma(far) = max(...) value for value (a NaN c gives NaN on both sides either way), so the test decides
+// exactly as box32 does with 12 fewer VALU instructions per node.  Nodes are stored in chunks of NODEW_CHUNK: chunk c holds the
+// three block rows of its nodes, each row NODEW_FAR bytes; inner refs in this table are BYTE offsets (wide_ref).  NODEW_FAR is
+// beyond the reach of ds_read2_b64's 8-bit offsets on purpose: merged, a near / far pair costs 8 LDS cycles instead of 2 + 2
+// (MI355X_MICROARCH.md, LDS table), and the LDS was 47 % busy with the merged form.
+static const uint32_t NODEW_CHUNK = 129;  // (129, not 128: a row stride of 4096 is within reach of ds_read2st64_b64)
+static const uint32_t NODEW_FAR = NODEW_CHUNK * 32;  // 4128
+DEV uint32_t nodew_bytes(uint32_t n_nodes) { return ((n_nodes + NODEW_CHUNK - 1) / NODEW_CHUNK) * 3u * NODEW_FAR; }
+DEV void ray32_wide_addr(Ray32& r, uint32_t n2w_lds) {
+    r.ax = n2w_lds + (r.ix < 0.f ? NODEW_FAR : 0u);
+    r.ay = n2w_lds + 8u + (r.iy < 0.f ? NODEW_FAR : 0u);
+    r.az = n2w_lds + 16u + (r.iz < 0.f ? NODEW_FAR : 0u);
+}
+DEV uint32_t wide_ref(uint32_t ref) {
+    return (ref >> REF_TAG_SHIFT) == 0u ? (ref / NODEW_CHUNK) * (3u * NODEW_FAR) + (ref % NODEW_CHUNK) * 32u : ref;
+}
+// one child of a NodeW: near / far planes already selected
+DEV bool box32w(float nx, float ny, float nz, float fx, float fy, float fz, const Ray32& r, float& entry) {
+    const float px = __builtin_fmaf(nx, r.ix, -r.cx), qx = __builtin_fmaf(fx, r.ix, -r.cx);
+    const float py = __builtin_fmaf(ny, r.iy, -r.cy), qy = __builtin_fmaf(fy, r.iy, -r.cy);
+    const float pz = __builtin_fmaf(nz, r.iz, -r.cz), qz = __builtin_fmaf(fz, r.iz, -r.cz);
+    // No widening factor W here (box32 multiplies tf by 1 + 2^-20): the pad is 12 e |o|max since round 3 (flatten.cpp), of which
+    // 2.001 e |o|max cover lo' - lo as in the proof above box32, leaving a margin m >= 9.99 e |o|max between [lo', hi'] and the
+    // exact box B on every side.  For a real t >= 0 with o + t d in B, on every axis: nu <= t - m/|d| and phi >= t + m/|d|, and
+    // t |d| = the distance travelled along the axis <= 2 |o|max (|o|max bounds origins AND item coordinates: flatten.cpp's
+    // origin_limit / oo), so nu (1 + th) <= t - m/|d| + 4.1 e t <= t and phi (1 + th') >= (t + m/|d|)(1 - 4.1 e) >= t because
+    // 4.1 e * 2 |o|max (1 + 4.1 e) < m.  Hence tn <= t <= tf, tn <= best <= r.best, r.tmin <= t_min <= t <= tf: the test passes.
+    // (non-positive nu, clamped iv, NaN: as for box32.)
+    const float tn = fmaxf(fmaxf(px, py), pz);
+    const float tf = fminf(fminf(qx, qy), qz);
+    entry = tn;
+    // tn <= min(tf, best): the compiler merges the two compares against tf and best into a v_min + one compare by itself, but
+    // then re-quiets r.best (a loop-carried value from another block: v_max_f32 v, v, v) in front of it on every node; the
+    // v_min_f32 is spelled out instead (IEEE mode: the non-NaN operand wins, as fminf)
+    float m;
+    asm("v_min_f32 %0, %1, %2" : "=v"(m) : "v"(tf), "v"(r.best));
+    return !(tn > m) && !(r.tmin > tf);
 }
 DEV bool box32(float lox, float loy, float loz, float hix, float hiy, float hiz, const Ray32& r, float& entry) {
     float px = __builtin_fmaf(lox, r.ix, -r.cx), qx = __builtin_fmaf(hix, r.ix, -r.cx);
@@ -471,7 +517,8 @@ DEV bool box32(float lox, float loy, float loz, float hix, float hiy, float hiz,
 // walked later by whichever wave serves the workgroup's request ring (coop_serve), starting from this walk's result.
 // TOP: the scene lives in L2/HBM and the shallowest nodes are cached in LDS (A.n2_top); false for LDS-resident scenes, which then
 // carry no test for it in the node loop.
-template <bool GENERAL, bool DEFER = false, bool TOP = true>
+// WIDE: the node table is the LDS-resident NodeW form (A.n2w_lds; implies !TOP).
+template <bool GENERAL, bool DEFER = false, bool TOP = true, bool WIDE = false>
 DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, double t_min, double t_max, uint32_t* pend = nullptr) {
     D3 o = wo, d = wd;
     double a = sqlen(d);
@@ -482,10 +529,53 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
     h.kp = 0;
     int cur_xf = -1;
     Ray32 r = make_ray32(o, d, t_min, t_max);
+    if (WIDE) ray32_wide_addr(r, A.n2w_lds);
     int sp = 0;  // stack offset in words (a multiple of stride): avoids an integer multiply per push/pop
-    uint32_t cur = A.root2;
+    // WIDE: the stack pointer is the LDS byte address itself (one add per push / pop instead of shift-add + add)
+    const uint32_t spw0 = WIDE ? (uint32_t)(uintptr_t)(AS_L uint32_t*)stk : 0u;
+    const uint32_t spw_step = 4u * (uint32_t)stride;
+    uint32_t spw = spw0;
+    uint32_t cur = WIDE ? wide_ref(A.root2) : A.root2;
     for (;;) {
         while ((cur >> REF_TAG_SHIFT) == 0u) {  // inner node: test both children
+            if (WIDE) {
+                const uint32_t axx = cur + r.ax, ayy = cur + r.ay, azz = cur + r.az;
+                // seven 8-byte LDS reads, spelled out: left to itself the compiler pairs them into ds_read2_b64 / ds_read2st64_b64
+                // (8 LDS cycles per pair instead of 2 + 2) wherever two offsets are in reach of each other
+                f32x2 nx, fx, ny, fy, nz, fz, cc;
+                asm volatile(
+                    "ds_read_b64 %0, %7\n\t"
+                    "ds_read_b64 %1, %7 offset:%10\n\t"
+                    "ds_read_b64 %2, %8\n\t"
+                    "ds_read_b64 %3, %8 offset:%10\n\t"
+                    "ds_read_b64 %4, %9\n\t"
+                    "ds_read_b64 %5, %9 offset:%10\n\t"
+                    "ds_read_b64 %6, %7 offset:24\n\t"
+                    "s_waitcnt lgkmcnt(0)"
+                    : "=&v"(nx), "=&v"(fx), "=&v"(ny), "=&v"(fy), "=&v"(nz), "=&v"(fz), "=&v"(cc)
+                    : "v"(axx), "v"(ayy), "v"(azz), "n"(NODEW_FAR)
+                    : "memory");
+                float e0, e1;
+                const bool h0 = box32w(nx.x, ny.x, nz.x, fx.x, fy.x, fz.x, r, e0);
+                const bool h1 = box32w(nx.y, ny.y, nz.y, fx.y, fy.y, fz.y, r, e1);
+                const uint32_t c0 = __float_as_uint(cc.x), c1 = __float_as_uint(cc.y);
+                if (h0 && h1) {
+                    const bool swap = e1 < e0;
+                    *(AS_L uint32_t*)(uintptr_t)spw = swap ? c0 : c1;
+                    spw += spw_step;
+                    cur = swap ? c1 : c0;
+                } else if (h0) {
+                    cur = c0;
+                } else if (h1) {
+                    cur = c1;
+                } else if (spw != spw0) {
+                    spw -= spw_step;
+                    cur = *(const AS_L uint32_t*)(uintptr_t)spw;
+                } else {
+                    cur = REF_DONE;
+                }
+                continue;
+            }
             f32x4 q0, q1, q2;  // (lox0,lox1,loy0,loy1) (loz0,loz1,hix0,hix1) (hiy0,hiy1,hiz0,hiz1) (c0,c1,-,-)
             f32x2 q3;          // (only the two child refs of the fourth quad: an 8-byte read)
             if (TOP && cur < A.n2_top_count) {  // the shallowest levels are cached in LDS when the scene lives in L2/HBM
@@ -556,9 +646,15 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
                 a = sqlen(d);
                 cur_xf = (int)in.x;
                 r = make_ray32(o, d, t_min, h.t);
-                stk[sp] = REF_RESTORE;
-                sp += stride;
-                cur = in.y;
+                if (WIDE) {
+                    ray32_wide_addr(r, A.n2w_lds);
+                    *(AS_L uint32_t*)(uintptr_t)spw = REF_RESTORE;
+                    spw += spw_step;
+                } else {
+                    stk[sp] = REF_RESTORE;
+                    sp += stride;
+                }
+                cur = WIDE ? wide_ref(in.y) : in.y;
                 continue;
             }
         } else {  // REF_RESTORE: leave the Transform
@@ -567,8 +663,16 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
             a = sqlen(d);
             cur_xf = -1;
             r = make_ray32(o, d, t_min, h.t);
+            if (WIDE) ray32_wide_addr(r, A.n2w_lds);
         }
-        if (sp > 0) {
+        if (WIDE) {
+            if (spw != spw0) {
+                spw -= spw_step;
+                cur = *(const AS_L uint32_t*)(uintptr_t)spw;
+            } else {
+                cur = REF_DONE;
+            }
+        } else if (sp > 0) {
             sp -= stride;
             cur = stk[sp];
         } else {
@@ -1026,7 +1130,33 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
     const uint32_t st_end = (ACCEL == 2) ? sv.stage2_end : sv.stage_bytes;
     uint32_t staged = 0;  // bytes of LDS in front of the stacks
     Acc A;
-    if (LDS) {
+    if (LDS && ACCEL == 2) {
+        // [spheres .. n2) as it is (the Node2 array is the last staged section, flatten.cpp); the Node2 array itself is EXPANDED
+        // into the NodeW form behind it
+        const uint32_t lo_bytes = sv.off_n2 - st_begin;
+        {
+            const uint4* src = (const uint4*)(sv.base + st_begin);
+            uint4* dst = (uint4*)smem;
+            for (uint32_t i = threadIdx.x; i < lo_bytes / 16; i += blockDim.x) dst[i] = src[i];
+        }
+        char* n2w = smem + lo_bytes;
+        for (uint32_t i = threadIdx.x; i < sv.n_nodes2; i += blockDim.x) {
+            const uint4* nd = (const uint4*)(sv.base + sv.off_n2) + (size_t)i * NODE2_F4;
+            const uint4 a = nd[0], b = nd[1], c = nd[2], d = nd[3];  // (lox0,lox1,loy0,loy1) (loz0,loz1,hix0,hix1) (hiy0,hiy1,hiz0,hiz1) (c0,c1,-,-)
+            const uint32_t c0 = wide_ref(d.x), c1 = wide_ref(d.y);
+            char* w = n2w + wide_ref(i);
+            const uint4 lo0 = make_uint4(a.x, a.y, a.z, a.w), lo1 = make_uint4(b.x, b.y, c0, c1);
+            const uint4 hi0 = make_uint4(b.z, b.w, c.x, c.y), hi1 = make_uint4(c.z, c.w, c0, c1);
+            ((uint4*)w)[0] = lo0; ((uint4*)w)[1] = lo1;
+            ((uint4*)(w + NODEW_FAR))[0] = hi0; ((uint4*)(w + NODEW_FAR))[1] = hi1;
+            ((uint4*)(w + 2 * NODEW_FAR))[0] = lo0; ((uint4*)(w + 2 * NODEW_FAR))[1] = lo1;
+        }
+        staged = lo_bytes + nodew_bytes(sv.n_nodes2);
+        __syncthreads();
+        A = make_acc(smem - st_begin, sv.base, sv);
+        A.n2 = nullptr;
+        A.n2w_lds = (uint32_t)(uintptr_t)(AS_L char*)n2w;
+    } else if (LDS) {
         const uint4* src = (const uint4*)(sv.base + st_begin);
         uint4* dst = (uint4*)smem;
         for (uint32_t i = threadIdx.x; i < (st_end - st_begin) / 16; i += blockDim.x) dst[i] = src[i];
@@ -1131,7 +1261,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
             }
             // ---- one path segment: sample_ray's loop body, photon_mapper.rs:335-362 ----
             if (alive) {
-                Hit h = (ACCEL == 2) ? traverse2<GENERAL, false, !LDS>(A, stk, stk_stride, o, d, rk.t_min, INFINITY)
+                Hit h = (ACCEL == 2) ? traverse2<GENERAL, false, !LDS, LDS>(A, stk, stk_stride, o, d, rk.t_min, INFINITY)
                                      : traverse<GENERAL, MEDIA>(A, o, d, rk.t_min, INFINITY, &rng);
                 bool done = true;
                 if (h.node >= 0 && depth > 0) {  // Q12: depth test after the hit, before emission
@@ -2416,7 +2546,9 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
                                           "larger than LDS, negative t_min, or camera farther than 64x the scene extent); use kernel 0/1");
     const size_t ring_meta = ((size_t)(PT_BLOCK / 64) * (RING_UNITS * 4 + 8) + CFG_WORDS) * sizeof(uint32_t);  // ring / job bookkeeping, behind the stacks
     const size_t stack_bytes = ((kernel == 2) ? stack2_bytes : (kernel == 5) ? stack5_bytes : 0) + ring_meta + ((kernel == 5) ? coop_lds : 0);
-    const size_t hot_bytes = (kernel == 2 || kernel == 5) ? hot2 : hot1;
+    // kernel 2 expands the Node2 array (64 B per node) into the NodeW form (96 B) while staging it
+    const size_t nodew = ((size_t)(view.n_nodes2 + NODEW_CHUNK - 1) / NODEW_CHUNK) * 3 * NODEW_FAR;
+    const size_t hot_bytes = (kernel == 2 || kernel == 5) ? hot2 - (size_t)view.n_nodes2 * sizeof(Node2) + nodew : hot1;
     const bool lds = hot_bytes > 0 && hot_bytes + stack_bytes <= lds_max && !tun.no_lds && kernel != 5;  // kernel 5: scene in L2/HBM always
     const int integ = plan.integrator;
     if (integ == 1 && view.n_lights == 0) throw RtError(RT_ERR_ARG, "integrator 1 (light importance sampling) needs rt_scene_set_lights");

@@ -324,8 +324,10 @@ void flatten(rt_scene& s) {
     if (ab.ok && !b.actx[0].items.empty()) {
         // E_w: largest |coordinate| of the world items; boxes are padded so that rounding a ray origin with
         // max-abs coordinate <= 64*E_w to f32 (relative error 2^-24) can never make the f32 slab test cull a box
-        // the exact test keeps: pad = 4 * 2^-24 * |o|max covers of = fl32(o) and c = fl32(of * iv)  (derivation above box32
-        // in csrc/device/kernels.hip, which also needs every coordinate below 2^36 in magnitude)
+        // the exact test keeps: 4 * 2^-24 * |o|max covers of = fl32(o) and c = fl32(of * iv)  (derivation above box32
+        // in csrc/device/kernels.hip, which also needs every coordinate below 2^36 in magnitude); the pad is THREE times that
+        // (12 * 2^-24 * |o|max) since round 3 so that box32w, the test of the LDS-resident node table, needs no widening factor
+        // on the far side (its proof, above box32w, uses the extra margin against the relative error of the slab parameters)
         double ew = 0.;
         for (auto& it : b.actx[0].items)
             for (int a = 0; a < 3; a++) ew = std::fmax(ew, std::fmax(std::fabs(it.box.mn[a]), std::fabs(it.box.mx[a])));
@@ -333,7 +335,7 @@ void flatten(rt_scene& s) {
             ab.ok = false;
         } else {
             origin_limit = 64. * ew;
-            const double pad_w = std::ldexp(origin_limit, -22);  // 4 * 2^-24 * |o|max
+            const double pad_w = 3. * std::ldexp(origin_limit, -22);  // 12 * 2^-24 * |o|max
             if (!(origin_limit < 68719476736.)) ab.ok = false;  // 2^36
             root2 = accel_build_bvh(ab, b.actx[0].items, pad_w, 0);
             const int depth_tlas = ab.max_depth;
@@ -352,7 +354,7 @@ void flatten(rt_scene& s) {
                 if (!(oo < 68719476736.)) { ab.ok = false; break; }
                 inst_oo.push_back(oo);
                 const size_t nodes_before = ab.nodes.size();
-                uint32_t r = accel_build_bvh(ab, c.items, std::ldexp(oo, -22), depth_tlas + 1);
+                uint32_t r = accel_build_bvh(ab, c.items, 3. * std::ldexp(oo, -22), depth_tlas + 1);
                 max_inst_nodes = std::max<uint32_t>(max_inst_nodes, (uint32_t)(ab.nodes.size() - nodes_before));
                 inst_depth = (uint32_t)std::max(1, ab.max_depth - depth_tlas + 1);  // bound for every instance built so far
                 ab.inst[2 * (i - 1)] = c.xform;
