@@ -456,7 +456,7 @@ static RenderPlan make_plan(const rt_params* p) {
     REQUIRE(p->spp > 0, "spp must be positive");
     REQUIRE(p->max_depth >= 0, "max_depth must be >= 0");
     REQUIRE(p->world >= 1 && p->rank >= 0 && p->rank < p->world, "bad rank/world");
-    REQUIRE((p->kernel >= 0 && p->kernel <= 2) || p->kernel == 5, "unknown kernel id (0 auto, 1, 2, 5)");
+    REQUIRE((p->kernel >= 0 && p->kernel <= 2) || p->kernel == 5 || p->kernel == 6, "unknown kernel id (0 auto, 1, 2, 5, 6)");
     REQUIRE(p->integrator >= 0 && p->integrator <= 2, "unknown integrator id");
     RenderPlan pl;
     pl.width = p->width; pl.height = p->height; pl.spp = p->spp; pl.max_depth = p->max_depth;

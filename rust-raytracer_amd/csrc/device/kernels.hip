@@ -518,8 +518,8 @@ DEV bool box32(float lox, float loy, float loz, float hix, float hiy, float hiz,
 // TOP: the scene lives in L2/HBM and the shallowest nodes are cached in LDS (A.n2_top); false for LDS-resident scenes, which then
 // carry no test for it in the node loop.
 // WIDE: the node table is the LDS-resident NodeW form (A.n2w_lds; implies !TOP).
-template <bool GENERAL, bool DEFER = false, bool TOP = true, bool WIDE = false>
-DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, double t_min, double t_max, uint32_t* pend = nullptr) {
+template <bool GENERAL, bool DEFER = false, bool TOP = true, bool WIDE = false, class PEND = uint32_t>
+DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, double t_min, double t_max, PEND* pend = nullptr) {
     D3 o = wo, d = wd;
     double a = sqlen(d);
     Hit h;
@@ -623,8 +623,8 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
                     } else if (kind == NK_TRI) {
                         double b1, b2;
                         got = tri_hit(A.tripre2 + 5 * (first + i), o, d, t_min, h.t, t, b1, b2);
-                    } else if (DEFER) {  // NK_INSTANCE, deferred (at most 32 instances, checked on the host)
-                        *pend |= 1u << pl;
+                    } else if (DEFER) {  // NK_INSTANCE, deferred (at most 32 / 64 instances, checked on the host)
+                        *pend |= (PEND)1 << pl;
                     } else {  // NK_INSTANCE: descend into its object-space BVH after the remaining items
                         enter = pl;
                     }
@@ -966,7 +966,7 @@ DEV void st_agent(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_R
 __device__ unsigned long long g_fold_stats[8];
 #endif
 __device__ __attribute__((noinline)) int fold_units(const uint32_t* rmeta, const double* wring, double* accum, unsigned int* tickets, bool first_launch,
-                                                    int r_head, int r_cnt, bool idle, int lane) {
+                                                    int r_head, int r_cnt, bool idle, int lane, int ring_units) {
 #ifdef RT_FOLD_STATS
     const unsigned long long t_in = __builtin_amdgcn_s_memtime();
     unsigned long long n_mis = 0, n_sleep = 0;
@@ -1011,7 +1011,7 @@ __device__ __attribute__((noinline)) int fold_units(const uint32_t* rmeta, const
             az = az + __longlong_as_double(ld_agent(p + 2));
             p += TILE_PIX * 3;
         }
-        r_head = (r_head + 1 == RING_UNITS) ? 0 : r_head + 1;
+        r_head = (r_head + 1 == ring_units) ? 0 : r_head + 1;
         r_cnt--;
         folded++;
         // the next unit continues this job iff it exists, is complete and is not the first of another job
@@ -1051,7 +1051,7 @@ __device__ __attribute__((noinline)) int fold_units(const uint32_t* rmeta, const
 // per 512 paths).
 //   wst: {r_head, r_cnt, job_tile, job_blk0, job_n, job_k, more_jobs, -}      cfg: see CFG_* below
 enum { CFG_N_JOBS, CFG_TILES_OWNED, CFG_JOB_UNITS, CFG_SUBS_PER_TILE, CFG_WORLD, CFG_RANK, CFG_TILES_X, CFG_S_BEGIN, CFG_S_END, CFG_SUB_SPP,
-       CFG_WIDTH, CFG_HEIGHT, CFG_WORDS = 16 };
+       CFG_WIDTH, CFG_HEIGHT, CFG_RING_UNITS /* unit buffers per wave: RING_UNITS, kernel 6: WF_RING_UNITS */, CFG_WORDS = 16 };
 struct UnitInfo {
     int pool;      // paths of the unit that was started (0: none was)
     int s0, tx, ty, cur_slot;
@@ -1061,21 +1061,22 @@ __device__ __attribute__((noinline)) UnitInfo next_unit(uint32_t* wst, uint32_t*
                                                         unsigned int* tickets, unsigned int* counter, bool all_dead, int lane) {
     int r_head = (int)wst[0], r_cnt = (int)wst[1], job_tile = (int)wst[2], job_blk0 = (int)wst[3], job_n = (int)wst[4], job_k = (int)wst[5];
     bool more_jobs = wst[6] != 0u;
+    const int ring_units = cfg[CFG_RING_UNITS];
     UnitInfo u;
     u.pool = 0; u.s0 = 0; u.tx = 0; u.ty = 0; u.cur_slot = 0; u.finished = 0;
     if (r_cnt > 0 && __hip_atomic_load(&rmeta[4 * r_head + 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) {
-        const bool idle = all_dead && (r_cnt == RING_UNITS || (job_k >= job_n && !more_jobs));  // nothing can be started: wait for the ticket
+        const bool idle = all_dead && (r_cnt == ring_units || (job_k >= job_n && !more_jobs));  // nothing can be started: wait for the ticket
 #ifdef RT_NOFOLD_TEST  // timing experiment only: results are wrong
         const int folded = 1;
         (void)idle;
 #else
-        const int folded = fold_units(rmeta, wring, accum, tickets, cfg[CFG_S_BEGIN] == 0, r_head, r_cnt, idle, lane);
+        const int folded = fold_units(rmeta, wring, accum, tickets, cfg[CFG_S_BEGIN] == 0, r_head, r_cnt, idle, lane, ring_units);
 #endif
         r_head += folded;
-        if (r_head >= RING_UNITS) r_head -= RING_UNITS;
+        if (r_head >= ring_units) r_head -= ring_units;
         r_cnt -= folded;
     }
-    if (r_cnt < RING_UNITS && (job_k < job_n || more_jobs)) {
+    if (r_cnt < ring_units && (job_k < job_n || more_jobs)) {
         if (job_k >= job_n) {  // next job: job_units consecutive sample blocks of one tile
             unsigned int job = 0;
             if (lane == 0) job = atomicAdd(counter, 1u);
@@ -1098,7 +1099,7 @@ __device__ __attribute__((noinline)) UnitInfo next_unit(uint32_t* wst, uint32_t*
             const int s1 = min(u.s0 + cfg[CFG_SUB_SPP], cfg[CFG_S_END]);
             u.pool = (s1 - u.s0) * TILE_PIX;
             u.cur_slot = r_head + r_cnt;
-            if (u.cur_slot >= RING_UNITS) u.cur_slot -= RING_UNITS;
+            if (u.cur_slot >= ring_units) u.cur_slot -= ring_units;
             r_cnt++;
             if (lane == 0) {
                 uint32_t* m = rmeta + 4 * u.cur_slot;
@@ -1192,6 +1193,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
         cfg[CFG_SUBS_PER_TILE] = rk.subs_per_tile; cfg[CFG_WORLD] = rk.world; cfg[CFG_RANK] = rk.rank; cfg[CFG_TILES_X] = rk.tiles_x;
         cfg[CFG_S_BEGIN] = rk.s_begin; cfg[CFG_S_END] = rk.s_end; cfg[CFG_SUB_SPP] = rk.sub_spp; cfg[CFG_WIDTH] = rk.width;
         cfg[CFG_HEIGHT] = rk.height;
+        cfg[CFG_RING_UNITS] = RING_UNITS;
     }
     __syncthreads();
     double* wring = ring + ((size_t)blockIdx.x * (PT_BLOCK / 64) + (size_t)wave) * RING_UNITS * UNIT_DOUBLES;
@@ -1917,6 +1919,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
         cfg[CFG_SUBS_PER_TILE] = rk.subs_per_tile; cfg[CFG_WORLD] = rk.world; cfg[CFG_RANK] = rk.rank; cfg[CFG_TILES_X] = rk.tiles_x;
         cfg[CFG_S_BEGIN] = rk.s_begin; cfg[CFG_S_END] = rk.s_end; cfg[CFG_SUB_SPP] = rk.sub_spp; cfg[CFG_WIDTH] = rk.width;
         cfg[CFG_HEIGHT] = rk.height;
+        cfg[CFG_RING_UNITS] = RING_UNITS;
         cargs->base = sv.base;
         cargs->pool = coop + (size_t)blockIdx.x * COOP_POOL * COOP_REC;
         cargs->err = err;
@@ -2284,6 +2287,7 @@ __global__ void assemble_kernel(const double* __restrict__ gathered, int64_t str
     frame[3 * i + 2] = src[2];
 }
 
+#include "wavefront.inc"
 #include "sppm.inc"
 
 // ------------------------------------------------------- debug kernels ----
@@ -2506,6 +2510,10 @@ static pt_fn pick_pt_kernel(bool lds, bool general, int integ) {
                : (general ? pt_kernel<false, true, ACCEL, 0> : pt_kernel<false, false, ACCEL, 0>);
 }
 
+static void render_tiles_wf(const rt_scene& s, const FlatView& view, const CameraDev& cam, const RenderPlan& plan, const Tuning& tun, double* d_tiles,
+                            hipStream_t stream, rt_stats* st, int dev, const DevInfo& di, uint32_t stack6, uint32_t n_entry6, size_t lds_pt, uint32_t stack6w,
+                            size_t tables_w);
+
 void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& plan_in, double* d_tiles, void* stream_, rt_stats* st) {
     if (!s.committed) throw RtError(RT_ERR_NOT_COMMITTED, "scene not committed");
     const Tuning tun = tuning();  // one snapshot per call
@@ -2534,6 +2542,16 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
     const size_t coop_lds = (size_t)3 * COOP_RING * sizeof(uint16_t) + 8 * sizeof(uint32_t) + ((sizeof(CoopArgs) + 15) & ~size_t(15)) + coop_world;  // + three rings of pool-slot ids, counters, argument block
     const bool coop_usable = accel2_usable && general && !media && view.coop_data_ok != 0 && view.n_inst2 >= 1 && view.n_inst2 <= (uint32_t)COOP_MAX_INST &&
                              view.inst_depth2 <= (uint32_t)COOP_STACK_MAX && coop_world <= 16384 && stack5_bytes + coop_lds <= lds_max && plan.max_depth < (1 << 24);
+    // kernel 6 = the same instance service across the whole GPU and across launches (wavefront.inc)
+    const uint32_t stack6 = std::max<uint32_t>(view.world_depth2 + 2u, (uint32_t)WF_ENTRY_STACK + 1u);
+    const uint32_t n_entry6 = std::min<uint32_t>((uint32_t)COOP_ENTRY_NODES, view.n_nodes2);
+    const size_t wf_lds_pt = coop_world + (size_t)std::min<uint32_t>(128u, view.world_top2) * sizeof(Node2) + (size_t)n_entry6 * sizeof(NodeQ) +
+                             (size_t)stack6 * PT_BLOCK * sizeof(uint32_t) + ((size_t)WF_BOOK_WORDS + CFG_WORDS + 8) * sizeof(uint32_t);
+    const uint32_t stack6w = view.inst_depth2 + 2u;
+    const size_t wf_tables_w = coop_a16(view.stage_bytes - view.off_xforms) + coop_a16(8u * view.n_inst2) + coop_a16((uint32_t)sizeof(QGrid) * view.n_inst2);
+    const size_t wf_lds_walk_min = wf_tables_w + (size_t)stack6w * WF_WALK_BLOCK * sizeof(uint32_t);
+    const bool wf_usable = accel2_usable && general && !media && view.coop_data_ok != 0 && view.n_inst2 >= 1 && view.n_inst2 <= (uint32_t)WF_MAX_INST &&
+                           coop_world <= 32768 && wf_lds_pt <= lds_max && wf_lds_walk_min <= lds_max && plan.max_depth < (1 << 24);
     int kernel = plan.kernel;
     // auto: the cooperative kernel as soon as an instance is more than a handful of triangles (Cornell box + torus instance, 64 spp,
     // kernel 5 / kernel 2 in Msamples/s: 120 triangles 1351 / 1182 (kernel 2 LDS-resident), 1 600: 1263 / 822, 25 600: 1035 / 517,
@@ -2541,11 +2559,17 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
     if (kernel == 0) kernel = accel2_usable ? ((coop_usable && view.max_inst_nodes2 >= 64u) ? 5 : 2) : 1;
     if (kernel == 5 && !coop_usable)
         throw RtError(RT_ERR_UNSUPPORTED, "kernel 5 (cooperative instance service) needs a usable accel and 1..32 instances that hold only triangles with f32 vertices (OBJ meshes), of BVH depth <= 40");
+    if (kernel == 6 && !wf_usable)
+        throw RtError(RT_ERR_UNSUPPORTED, "kernel 6 (wavefront instance service) needs a usable accel and 1..64 instances that hold only triangles with f32 vertices (OBJ meshes)");
     if ((kernel == 2 || kernel == 5) && !accel2_usable)
         throw RtError(RT_ERR_UNSUPPORTED, "kernel 2 requested but no usable accel for this scene/camera (unbounded item, depth overflow, stacks "
                                           "larger than LDS, negative t_min, or camera farther than 64x the scene extent); use kernel 0/1");
     const size_t ring_meta = ((size_t)(PT_BLOCK / 64) * (RING_UNITS * 4 + 8) + CFG_WORDS) * sizeof(uint32_t);  // ring / job bookkeeping, behind the stacks
     const size_t stack_bytes = ((kernel == 2) ? stack2_bytes : (kernel == 5) ? stack5_bytes : 0) + ring_meta + ((kernel == 5) ? coop_lds : 0);
+    if (kernel == 6) {
+        render_tiles_wf(s, view, cam, plan, tun, d_tiles, stream, st, dev, di, stack6, n_entry6, wf_lds_pt, stack6w, wf_tables_w);
+        return;
+    }
     // kernel 2 expands the Node2 array (64 B per node) into the NodeW form (96 B) while staging it
     const size_t nodew = ((size_t)(view.n_nodes2 + NODEW_CHUNK - 1) / NODEW_CHUNK) * 3 * NODEW_FAR;
     const size_t hot_bytes = (kernel == 2 || kernel == 5) ? hot2 - (size_t)view.n_nodes2 * sizeof(Node2) + nodew : hot1;
@@ -2696,6 +2720,160 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
     if (h_err & 1) throw RtError(RT_ERR_UNIT_ZERO, "unitizing zero vector (device)");
     if (h_err & ~1) throw RtError(RT_ERR_INTERNAL, "device invariant failed (error bits " + std::to_string(h_err) + ": 2 = an instance below an instance "
                                                    "reached an object-space walk, 4 = a kernel 5 ring entry was not published in time)");
+}
+
+// ---------------------------------------------------------------- kernel 6 driver ----
+// Cycles of {pt_kernel_wf, wf_walk_kernel} on `stream` until every workgroup reports that it is done with the frame.  The host
+// looks at the "unfinished" words once per batch of WF_BATCH cycles (a cycle enqueued after the frame is complete costs two empty
+// launches), so there is one synchronisation per batch, not per cycle.
+static const int WF_BATCH = 8;
+static void render_tiles_wf(const rt_scene& s, const FlatView& view, const CameraDev& cam, const RenderPlan& plan, const Tuning& tun, double* d_tiles,
+                            hipStream_t stream, rt_stats* st, int dev, const DevInfo& di, uint32_t stack6, uint32_t n_entry6, size_t lds_pt, uint32_t stack6w,
+                            size_t tables_w) {
+    const size_t lds_max = di.lds_max;
+    const int integ = plan.integrator;
+    if (integ == 1 && view.n_lights == 0) throw RtError(RT_ERR_ARG, "integrator 1 (light importance sampling) needs rt_scene_set_lights");
+    if (integ == 2 && !plan.sppm_est) throw RtError(RT_ERR_ARG, "integrator 2 (SPPM) is reached through rt_render_sppm");
+    typedef void (*pt_wf_fn)(FlatView, CamK, RenderK, double*, double*, unsigned int*, unsigned int*, int*, WfArgs);
+    pt_wf_fn fn = (integ == 1) ? pt_kernel_wf<1> : (integ == 2) ? pt_kernel_wf<2> : pt_kernel_wf<0>;
+    if (lds_pt > 48 * 1024) HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pt));
+    int bpc = 0;
+    HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)fn, PT_BLOCK, lds_pt));
+    if (bpc < 1) bpc = 1;
+    const int grid = di.cus * bpc;
+    // the walk launch: two 512-thread workgroups per CU when the stacks allow it; what is left of that share of LDS caches NodeQ
+    const size_t stacks_w = (size_t)stack6w * WF_WALK_BLOCK * sizeof(uint32_t);
+    size_t share = lds_max / 2;
+    if (tables_w + stacks_w > share) share = lds_max;
+    uint32_t n_topq_w = (uint32_t)std::min<size_t>((share - tables_w - stacks_w) / sizeof(NodeQ), view.n_nodes2);
+    if (tun.n_top >= 0) n_topq_w = std::min<uint32_t>(n_topq_w, (uint32_t)tun.n_top);
+    const size_t lds_walk = tables_w + coop_a16(n_topq_w * (uint32_t)sizeof(NodeQ)) + stacks_w;
+    if (lds_walk > 48 * 1024) HIP_CHECK(hipFuncSetAttribute((const void*)wf_walk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_walk));
+    int bpc_w = 0;
+    HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc_w, (const void*)wf_walk_kernel, WF_WALK_BLOCK, lds_walk));
+    if (bpc_w < 1) bpc_w = 1;
+    const int grid_w = di.cus * bpc_w;
+    uint32_t seg = WF_SEG_DEFAULT;
+    if (tun.coop_pool > 0) seg = std::max<uint32_t>(2 * WF_GATE, ((uint32_t)tun.coop_pool + WF_CHUNK - 1) / WF_CHUNK * WF_CHUNK);  // rt_tuning test hook: small segments
+
+    const int64_t n_pix = plan.tiles_owned * TILE_PIX;
+    const size_t ring_bytes = (size_t)grid * (PT_BLOCK / 64) * WF_RING_UNITS * UNIT_DOUBLES * sizeof(double);
+    const size_t pool_bytes = (size_t)grid * seg * WF_REC_U * 16;
+    const size_t off_cnt = 2 * pool_bytes, off_book = off_cnt + 2 * (size_t)grid * 4, off_misc = off_book + (size_t)grid * WF_BOOK_WORDS * 4;
+    const size_t wf_bytes = off_misc + 256;  // misc: cursor, WF_BATCH unfinished words
+    WorkspaceLease lease(dev, ring_bytes, std::max<size_t>(16, (size_t)n_pix * 3 * sizeof(double)),
+                         std::max<size_t>(16, (size_t)plan.tiles_owned * sizeof(unsigned int)), wf_bytes);
+    char* small = (char*)lease.w->small;
+    char* wfb = (char*)lease.w->coop;
+    unsigned int* counter = (unsigned int*)small;
+    int* err = (int*)(small + 16);
+    uint32_t* cursor = (uint32_t*)(wfb + off_misc);
+    uint32_t* unf = (uint32_t*)(wfb + off_misc + 64);
+    HIP_CHECK(hipMemsetAsync(small, 0, WS_SMALL, stream));
+    Events events;
+    CamK ck = to_camk(cam);
+    int launches = 0;
+    double kms = 0.;
+    for (int s0 = 0; s0 < plan.spp; s0 += plan.spp_chunk) {
+        const int s1 = std::min(s0 + plan.spp_chunk, plan.spp);
+        RenderK rk;
+        rk.width = plan.width; rk.height = plan.height; rk.max_depth = plan.max_depth;
+        rk.t_min = plan.t_min; rk.seed = plan.seed;
+        rk.s_begin = s0; rk.s_end = s1;
+        rk.sub_spp = plan.sub_spp;
+        rk.subs_per_tile = (s1 - s0 + plan.sub_spp - 1) / plan.sub_spp;
+        rk.job_units = 1;  // kernel 6 deals single units (next_unit_wf)
+        int64_t units = plan.tiles_owned * (int64_t)rk.subs_per_tile;
+        if (units > 0x7FFFFFFF) throw RtError(RT_ERR_UNSUPPORTED, "too many work units per launch");
+        rk.n_units = (int)units;
+        rk.tiles_x = plan.tiles_x; rk.rank = plan.rank; rk.world = plan.world;
+        rk.tiles_owned = (int)std::max<int64_t>(1, plan.tiles_owned);
+        rk.sppm_est = plan.sppm_est;
+        rk.n_top = (int)std::min<uint32_t>(128u, view.world_top2);
+        rk.n_topq = (int)n_entry6;
+        rk.coop_stack = (int)stack6;
+        rk.coop_pool = 0;
+        HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(unsigned int), stream));
+        HIP_CHECK(hipMemsetAsync(lease.w->tickets, 0, std::max<size_t>(16, (size_t)plan.tiles_owned * sizeof(unsigned int)), stream));
+        if (rk.n_units <= 0) continue;
+        hipEvent_t e0 = events.make(), e1 = events.make();
+        HIP_CHECK(hipEventRecord(e0, stream));
+        int cycle = 0;
+        for (;;) {
+            HIP_CHECK(hipMemsetAsync(unf, 0, WF_BATCH * sizeof(uint32_t), stream));
+            for (int b = 0; b < WF_BATCH; b++, cycle++) {
+                WfArgs wa;
+                wa.pool_a = (U2*)(wfb + (size_t)((cycle + 1) & 1) * pool_bytes);
+                wa.pool_b = (U2*)(wfb + (size_t)(cycle & 1) * pool_bytes);
+                wa.cnt_a = (const uint32_t*)(wfb + off_cnt) + (size_t)((cycle + 1) & 1) * grid;
+                wa.cnt_b = (uint32_t*)(wfb + off_cnt) + (size_t)(cycle & 1) * grid;
+                wa.book = (uint32_t*)(wfb + off_book);
+                wa.unfinished = unf + b;
+                wa.seg = seg;
+                wa.first = cycle == 0 ? 1 : 0;
+                hipLaunchKernelGGL(fn, dim3(grid), dim3(PT_BLOCK), lds_pt, stream, view, ck, rk, (double*)lease.w->ring, (double*)lease.w->accum,
+                                   (unsigned int*)lease.w->tickets, counter, err, wa);
+                HIP_CHECK(hipGetLastError());
+                HIP_CHECK(hipMemsetAsync(cursor, 0, sizeof(uint32_t), stream));
+                WfWalkK wk;
+                wk.pool = wa.pool_b;
+                wk.cnt = wa.cnt_b;
+                wk.cursor = cursor;
+                wk.grid_pt = (uint32_t)grid;
+                wk.seg = seg;
+                wk.n_topq = n_topq_w;
+                wk.stack = stack6w;
+                wk.t_min = plan.t_min;
+                hipLaunchKernelGGL(wf_walk_kernel, dim3(grid_w), dim3(WF_WALK_BLOCK), lds_walk, stream, view, wk);
+                HIP_CHECK(hipGetLastError());
+                launches++;
+            }
+            uint32_t h_unf[WF_BATCH];
+            HIP_CHECK(hipMemcpyAsync(h_unf, unf, sizeof(h_unf), hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipStreamSynchronize(stream));
+            if (h_unf[WF_BATCH - 1] == 0u) break;
+            if (cycle > (1 << 22)) throw RtError(RT_ERR_INTERNAL, "kernel 6 made no progress");
+        }
+        HIP_CHECK(hipEventRecord(e1, stream));
+        HIP_CHECK(hipEventSynchronize(e1));
+        float ms = 0;
+        HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        kms += ms;
+    }
+    if (n_pix > 0) {
+        hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((n_pix + 255) / 256)), dim3(256), 0, stream, (const double*)lease.w->accum, d_tiles,
+                           n_pix, plan.spp, plan.width, plan.height, plan.tiles_x, plan.rank, plan.world);
+        HIP_CHECK(hipGetLastError());
+    }
+    int h_err = 0;
+    HIP_CHECK(hipMemcpyAsync(&h_err, err, sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    if (st) {
+        st->kernel_ms = kms;
+        st->reduce_ms = 0.;
+        st->launches = launches;
+        st->kernel_used = 6;
+        st->scene_in_lds = 0;
+        st->block_threads = PT_BLOCK;
+        st->grid_blocks = grid;
+        st->spp_chunk = plan.spp_chunk;
+        st->scene_bytes = s.flat.blob.size();
+        st->reserved[1] = (uint64_t)(ring_bytes + (size_t)n_pix * 3 * sizeof(double) + (size_t)plan.tiles_owned * sizeof(unsigned int) + wf_bytes);
+        st->reserved[2] = (uint64_t)grid_w | ((uint64_t)n_topq_w << 32);
+    }
+#ifdef RTAMD_WF_STATS
+    {
+        unsigned long long hs[16], z[16] = {0};
+        HIP_CHECK(hipMemcpyFromSymbol(hs, HIP_SYMBOL(g_wf_stats), sizeof(hs)));
+        const char* names[12] = {"parks", "adoptions", "generated", "wave iterations", "wave exits: ring full / no unit", "wave exits: gate closed", "wave exits: finished",
+                                 "wave cycles in launches", "alive lanes summed", "entry walks", "walk passes", "walk pass lanes"};
+        fprintf(stderr, "[wf stats] cycles %d  grid %d x %d  walk grid %d  seg %u  n_topq_w %u\n", launches, grid, PT_BLOCK, grid_w, seg, n_topq_w);
+        for (int i = 0; i < 12; i++) fprintf(stderr, "[wf stats] %-34s %14llu\n", names[i], hs[i]);
+        HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_wf_stats), z, sizeof(z)));
+    }
+#endif
+    if (h_err & 1) throw RtError(RT_ERR_UNIT_ZERO, "unitizing zero vector (device)");
+    if (h_err & ~1) throw RtError(RT_ERR_INTERNAL, "device invariant failed (error bits " + std::to_string(h_err) + ")");
 }
 
 // ---------------------------------------------------------------- SPPM driver ----

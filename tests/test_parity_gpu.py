@@ -314,7 +314,7 @@ def test_accel_is_conservative_fuzz(scale):
         assert 0.25 < a[:, 0].mean() < 0.95
 
 
-@pytest.mark.parametrize("kernel", [1, 2, 5])
+@pytest.mark.parametrize("kernel", [1, 2, 5, 6])
 def test_large_mesh_instance_outside_lds_bit_exact(kernel):
     """C4's shape at test size: the Cornell box with a 6,400-triangle torus instance (rtamd.shapes).  Its tables exceed
     LDS, so this runs the global-memory variants (kernel 2: depth-sorted Node2 array with the top levels cached in LDS,
@@ -358,7 +358,7 @@ def _c4_scene():
     return _C4
 
 
-@pytest.mark.parametrize("kernel", [0, 1, 2, 5])
+@pytest.mark.parametrize("kernel", [0, 1, 2, 5, 6])
 def test_c4_full_size_mesh_bit_exact(kernel):
     """Config C4 (Cornell box + ~100k-triangle mesh) at the configured mesh size, every traversal against the oracle:
     64 x 64 x 4 spp of the 102,400-triangle torus instance (mesh.rs:57-137,144-208; transform.rs:152-165)."""
@@ -393,7 +393,7 @@ def test_c4_several_instances_of_one_mesh_bit_exact():
     o.Camera((278, 278, -800), (278, 278, 278), (0, 1, 0), 50, 1.0, 0.0, 10.0)
     assert w.info()["accel_instances"] == 5
     exp, _ = o.render(96, 96, 4, seed=5)
-    for k in (1, 2, 5):
+    for k in (1, 2, 5, 6):
         img, _ = w.render(cam, width=96, height=96, spp=4, seed=5, kernel=k)
         _assert_same(img, exp, "five instances, kernel %d" % k)
 
@@ -448,6 +448,9 @@ def test_coop_kernel_equals_kernel2_on_random_instances():
         b, sb = w.render(cam, width=96, height=96, spp=6, seed=trial, kernel=5)
         assert sb["kernel_used"] == 5 and sa["kernel_used"] == 2
         _assert_same(b, a, "random instances, trial %d" % trial)
+        c6, s6 = w.render(cam, width=96, height=96, spp=6, seed=trial, kernel=6)
+        assert s6["kernel_used"] == 6
+        _assert_same(c6, a, "random instances, trial %d, kernel 6" % trial)
         assert a.max() > 0
         if trial == 0:  # and against the oracle once
             import oracle
@@ -467,6 +470,9 @@ def test_coop_kernel_full_size_equals_kernel2_at_more_samples():
     b, st = c["world"].render(c["cam"], width=256, height=256, spp=8, seed=3, kernel=5)
     assert st["kernel_used"] == 5
     _assert_same(b, a, "C4 256x256x8, kernel 5 against kernel 2")
+    b6, st6 = c["world"].render(c["cam"], width=256, height=256, spp=8, seed=3, kernel=6)
+    assert st6["kernel_used"] == 6
+    _assert_same(b6, a, "C4 256x256x8, kernel 6 against kernel 2")
 
 
 def test_coop_kernel_image_does_not_depend_on_partition_chunking_or_unit_size(tuning):
@@ -685,7 +691,7 @@ def _bunny_scene():
     return _BUNNY
 
 
-@pytest.mark.parametrize("kernel", [0, 1, 2, 5])
+@pytest.mark.parametrize("kernel", [0, 1, 2, 5, 6])
 def test_reference_bunny_obj_in_the_cornell_box_bit_exact(kernel):
     b = _bunny_scene()
     info = b["world"].info()
@@ -705,3 +711,65 @@ def test_mesh_obj_without_normals_is_refused_through_the_c_abi():
     with pytest.raises(rtamd.RtError) as e:
         w.Mesh_load_obj(scene_path("bun315.obj"), m)
     assert e.value.code == -7   # RT_ERR_NO_NORMALS (mesh.rs:62 would panic)
+
+
+def test_wavefront_kernel_image_does_not_depend_on_partition_chunking_unit_size_or_segment_size(tuning):
+    """kernel 6 (cycles of path-tracing and walk launches, parked paths in HBM) under the schedule knobs: tile partition over
+    ranks, spp chunking, work-unit size, one tile with many units, and SMALL pool segments (4 096 records per workgroup: the gate
+    that keeps a segment from overflowing closes and opens many times, units are generated across launch boundaries)."""
+    c = _c4_scene()
+    world, cam = c["world"], c["cam"]
+    w, h, spp = 72, 56, 12
+    full, _ = world.render(cam, width=w, height=h, spp=spp, seed=6, kernel=2)
+    wf, st6 = world.render(cam, width=w, height=h, spp=spp, seed=6, kernel=6)
+    assert st6["kernel_used"] == 6 and st6["launches"] >= 2
+    _assert_same(wf, full, "kernel 6 against kernel 2")
+    for world_size in (2, 3):
+        acc = np.zeros_like(full)
+        for r in range(world_size):
+            part, _ = world.render(cam, width=w, height=h, spp=spp, seed=6, rank=r, world=world_size, kernel=6)
+            assert np.count_nonzero(acc[part != 0]) == 0
+            acc += part
+        assert np.array_equal(acc, full), "kernel 6: partition over %d ranks changed the image" % world_size
+    for sub, chunk in ((3, 0), (1, 5), (8, 7)):
+        tuning(sub_spp=sub)
+        other, _ = world.render(cam, width=w, height=h, spp=spp, seed=6, spp_chunk=chunk, kernel=6)
+        assert np.array_equal(other, full), (sub, chunk)
+    tuning()
+    a, _ = world.render(cam, width=8, height=8, spp=400, seed=2, kernel=2)   # one tile, 50 units
+    b, _ = world.render(cam, width=8, height=8, spp=400, seed=2, kernel=6)
+    _assert_same(b, a, "one tile, 50 units, kernel 6")
+    tuning(coop_pool=4096)
+    a, _ = world.render(cam, width=400, height=400, spp=16, seed=4, kernel=2)    # 2.6 M paths: ~10 k per workgroup
+    b, st = world.render(cam, width=400, height=400, spp=16, seed=4, kernel=6)
+    _assert_same(b, a, "kernel 6 with 4 096-record segments")
+    assert st["launches"] > 8
+
+
+def test_wavefront_kernel_64_instances_bit_exact():
+    """64 Transform instances of three meshes (one pending bit per instance: the limit of kernel 6; kernel 5 stops at 32)."""
+    import rtamd
+    from rtamd import shapes
+    rng = np.random.default_rng(64)
+    meshes = [shapes.torus(8, 12), shapes.torus(10, 16), shapes.torus(12, 20)]
+    w = rtamd.World()
+    white = w.Lambertian(w.ConstantTexture((0.73, 0.73, 0.73)))
+    glass = w.Dielectric(1.5, w.ConstantTexture((1.0, 1.0, 1.0)))
+    objs = [w.Mesh(P, N, I, white if i else glass, bvh_seed=i + 1) for i, (P, N, I) in enumerate(meshes)]
+    items = shapes.cornell_with_mesh(w, *meshes[0], scale=30.0, translate=(100.0, 480.0, 100.0))
+    for k in range(63):
+        pos = (60.0 + 62.0 * (k % 8), 60.0 + 55.0 * (k // 8), 120.0 + 45.0 * (k % 5))
+        items.append(w.Transform((float(rng.uniform(0, 360)), float(rng.uniform(0, 360)), 0.0), (22.0, 30.0, 22.0), pos, objs[k % 3]))
+    w.new(items, bvh_seed=9)
+    info = w.info()
+    assert info["accel_instances"] == 64 and info["accel_compact"] == 1
+    cam = _c4_scene()["cam"]
+    a, _ = w.render(cam, width=128, height=128, spp=4, seed=8, kernel=2)
+    b, st = w.render(cam, width=128, height=128, spp=4, seed=8, kernel=6)
+    assert st["kernel_used"] == 6
+    _assert_same(b, a, "64 instances, kernel 6 against kernel 2")
+    k1, _ = w.render(cam, width=48, height=48, spp=2, seed=8, kernel=1)
+    k6, _ = w.render(cam, width=48, height=48, spp=2, seed=8, kernel=6)
+    _assert_same(k6, k1, "64 instances, kernel 6 against the reference-order kernel")
+    with pytest.raises(rtamd.RtError):
+        w.render(cam, width=32, height=32, spp=1, seed=8, kernel=5)   # more than 32 instances
