@@ -2556,7 +2556,10 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
     // auto: the cooperative kernel as soon as an instance is more than a handful of triangles (Cornell box + torus instance, 64 spp,
     // kernel 5 / kernel 2 in Msamples/s: 120 triangles 1351 / 1182 (kernel 2 LDS-resident), 1 600: 1263 / 822, 25 600: 1035 / 517,
     // 102 400: 861 / 427, 409 600: 746 / 370; the 12-triangle cube of the reference's Cornell box: 2507 / 2533)
-    if (kernel == 0) kernel = accel2_usable ? ((coop_usable && view.max_inst_nodes2 >= 64u) ? 5 : 2) : 1;
+    // (kernel 6, the wavefront form of the same service, reaches 766 Msamples/s on C4 where kernel 5 reaches 891 and kernel 2 469: it is
+    // the automatic choice only where kernel 5 does not apply -- 33..64 instances -- and otherwise by request)
+    if (kernel == 0)
+        kernel = accel2_usable ? ((coop_usable && view.max_inst_nodes2 >= 64u) ? 5 : (wf_usable && !coop_usable && view.max_inst_nodes2 >= 64u) ? 6 : 2) : 1;
     if (kernel == 5 && !coop_usable)
         throw RtError(RT_ERR_UNSUPPORTED, "kernel 5 (cooperative instance service) needs a usable accel and 1..32 instances that hold only triangles with f32 vertices (OBJ meshes), of BVH depth <= 40");
     if (kernel == 6 && !wf_usable)
