@@ -18,8 +18,8 @@ single-GPU run.
 
 Extra objects on the JSON line (definitions and formulas: DESIGN.md s5):
   roofline          -- the bound that binds pt_kernel: VALU issue.  achieved = VALU wave-instructions/s,
-                       peak = SIMDs x clock / minimum issue cycles per instruction of the kernel's own mix (f32 2, f64 4,
-                       transcendental 8 / 16 cycles per wave64 on a SIMD-32); lane_utilisation beside it.
+                       peak = SIMDs x clock / issue cycles per instruction of the kernel's own mix (4 cycles per wave64
+                       instruction, f32 and f64 alike; transcendental 8 / 16: tools/make_pt_model.py); lane_utilisation beside it.
                        Per-sample instruction counts come from the PMC passes committed under profiles/ (model
                        file named in `source`); the kernel time is measured live (HIP events on the launch stream).
   roofline_contract -- SURVEY s8d: algorithmic bytes per sample in the REFERENCE's traversal order / kernel time
@@ -44,6 +44,7 @@ ALG_BYTES = os.path.join(ROOT, "tests", "golden", "alg_bytes_scene_500.json")
 MODEL = os.path.join(ROOT, "profiles", "pt_kernel_model.json")
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 N_SIMDS = 256 * 4      # 256 CUs x 4 SIMDs
+MAX_CLOCK_GHZ = 2.4    # MI355X max engine clock (MI355X_MICROARCH.md): the roofline PEAK is priced at it, not at the clock a profiled pass happened to hold
 CPU_BASELINE_THREADS = 16
 
 
@@ -123,21 +124,24 @@ def launch_ranks(args, argv):
     return subprocess.call(rank_command(args.gpus, argv, port), env=env)
 
 
-def roofline_objects(stats_acc, dt_kernel_s, clock_note=None):
-    """roofline / roofline_contract / roofline_hbm for pt_kernel (see the module docstring and DESIGN.md s5)."""
+def roofline_objects(stats_acc, dt_kernel_s, clock_note=None, model_path=None, alg_path=None):
+    """roofline / roofline_contract / roofline_hbm for pt_kernel (see the module docstring and DESIGN.md s5).  model_path / alg_path:
+    another configuration's PMC model and algorithmic-bytes fixture (tools/config_bench.py); default: the bench workload's."""
+    model_path = model_path or MODEL
+    alg_path = alg_path or ALG_BYTES
     launches = max(1, stats_acc["launches"])
     samples_per_launch = stats_acc["samples"] / launches
     ms_per_launch = stats_acc["kernel_ms"] / launches
     sps = stats_acc["samples"] / (stats_acc["kernel_ms"] * 1e-3) if stats_acc["kernel_ms"] > 0 else 0.0  # samples/s inside pt_kernel
-    with open(ALG_BYTES) as f:
+    with open(alg_path) as f:
         b_alg = json.load(f)["bytes_per_sample"]
     contract = {"bound": "hbm", "achieved": sps * b_alg / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sps * b_alg / 1e9 / HBM_PEAK_GBS,
                 "alg_bytes_per_sample": b_alg,
                 "note": "SURVEY s8d contract figure: bytes the REFERENCE's traversal order would touch; served from LDS here and mostly "
                         "never touched (near-first SAH traversal), so frac > 1 is expected and is not a physical utilisation"}
     model = None
-    if os.path.exists(MODEL):
-        with open(MODEL) as f:
+    if os.path.exists(model_path):
+        with open(model_path) as f:
             model = json.load(f)
     roof = {"bound": "valu_issue", "achieved": None, "peak": None, "unit": "G wave-instructions/s", "frac": None, "traffic": None,
             "kernel": "pt_kernel", "samples_per_launch": samples_per_launch, "ms_per_launch": ms_per_launch}
@@ -145,13 +149,13 @@ def roofline_objects(stats_acc, dt_kernel_s, clock_note=None):
     if model:
         ipc = model["valu_insts_per_sample"]            # VALU wave-instructions per sample (SQ_INSTS_VALU / samples)
         cyc = model["valu_issue_cycles_per_inst"]       # minimum SIMD cycles per wave64 instruction of the kernel's own mix (f32 2, f64 4, transcendental 8 / 16, ...: tools/make_pt_model.py)
-        clk = model["clock_ghz"]                        # GRBM_GUI_ACTIVE / 8 / kernel time of the PMC pass
+        clk = MAX_CLOCK_GHZ                             # (the PMC pass itself held model["clock_ghz"], 2.37: profiled passes clock lower)
         achieved = sps * ipc / 1e9
         peak = N_SIMDS * clk / cyc
         frac = achieved / peak if peak > 0 else None
         roof.update({"achieved": achieved, "peak": peak, "frac": frac, "lane_utilisation": model["lane_utilisation"],
                      "useful_frac": frac * model["lane_utilisation"] if frac else None,
-                     "valu_insts_per_sample": ipc, "valu_issue_cycles_per_inst": cyc, "clock_ghz": clk,
+                     "valu_insts_per_sample": ipc, "valu_issue_cycles_per_inst": cyc, "clock_ghz": clk, "clock_ghz_in_pmc_pass": model["clock_ghz"],
                      "valu_mix_per_sample": model.get("valu_mix_per_sample"),
                      "source": "per-sample counts carried over from %s; kernel time measured in this run" % model.get("source", "profiles/")})
         if frac is not None and not (0.0 < frac <= 1.05):

@@ -65,7 +65,7 @@ def test_roofline_objects_are_physical():
     import bench
     model = json.load(open(bench.MODEL))
     # a launch at exactly the modelled rate: samples/s = SIMDs * clock / (insts/sample * cycles/inst) * valu_busy
-    sps = bench.N_SIMDS * model["clock_ghz"] * 1e9 / (model["valu_insts_per_sample"] * model["valu_issue_cycles_per_inst"]) * 0.9
+    sps = bench.N_SIMDS * bench.MAX_CLOCK_GHZ * 1e9 / (model["valu_insts_per_sample"] * model["valu_issue_cycles_per_inst"]) * 0.9
     acc = {"kernel_ms": 100.0, "launches": 2, "samples": int(sps * 0.1)}
     roof, contract, hbm = bench.roofline_objects(acc, 0.1)
     assert roof["bound"] == "valu_issue" and 0.0 < roof["frac"] <= 1.05 and abs(roof["frac"] - 0.9) < 1e-6

@@ -6,13 +6,15 @@ pt_kernel dispatches of ONE pass (every pass runs the same command).
 
 Formulas:
   valu_insts_per_sample      = SQ_INSTS_VALU / N
-  valu_issue_cycles_per_inst = sum_class(count_class * cycles_class) / SQ_INSTS_VALU, the MINIMUM SIMD cycles the kernel's own
-                               instruction mix needs per wave64 instruction on a SIMD-32: f32 add/mul/fma 2 (157.3 TFLOP/s vector
-                               peak = 32 fma lanes/clk/SIMD), f64 add/mul/fma 4 (78.6 TFLOP/s), f32 transcendental 8, f64
-                               transcendental (rcp, rsq, sqrt) 16, 64-bit integer 4, conversions 4, everything else (32-bit
-                               integer / logic / moves / compares / selects) 2.  Classes from SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F{32,64},
-                               _INT64, _CVT; "else" = SQ_INSTS_VALU minus their sum (so 32-bit multiplies, quarter rate, are
-                               under-priced: the peak is an upper bound, the fraction a lower bound)
+  valu_issue_cycles_per_inst = sum_class(count_class * cycles_class) / SQ_INSTS_VALU, the SIMD cycles the kernel's own instruction
+                               mix needs per wave64 instruction.  Round 3: every non-transcendental VALU instruction is priced at 4
+                               cycles -- f32 as well as f64, integer, compare, select, move -- as MI355X_MICROARCH.md lists them
+                               ("v_add_f32 / v_fma_f32 / v_max3_f32 4 cycles", f64 fma at the same 16 lanes per clock: 78.6 TFLOP/s)
+                               and as this kernel measures them (SQ_ACTIVE_INST_VALU: 4.17 cycles per instruction on a mix that is
+                               two thirds f32 / integer / compare).  Rounds 1-2 priced f32 and "other" at 2 (the 157 TFLOP/s f32 peak
+                               needs packed instructions, which these kernels do not use and which measured slower): that put the
+                               peak 1.5x too high.  f32 transcendental 8, f64 transcendental (rcp, rsq, sqrt) 16.  Classes from
+                               SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F{32,64}, _INT64, _CVT; "other" = SQ_INSTS_VALU minus their sum
   valu_busy_measured         = 4 * SQ_ACTIVE_INST_VALU / (1024 SIMDs * GRBM_GUI_ACTIVE / 8)   (can exceed 1: active intervals of the
                                waves of one SIMD overlap)
   lane_utilisation           = SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU)
@@ -54,19 +56,20 @@ for d in a.dirs:
 
 N = a.samples
 m = {"kernel": sorted(names), "samples_in_pass": N, "source": a.source, "counters": {k: tot[k] for k in sorted(tot)}}
-CLASS_CYCLES = {"SQ_INSTS_VALU_ADD_F32": 2, "SQ_INSTS_VALU_MUL_F32": 2, "SQ_INSTS_VALU_FMA_F32": 2, "SQ_INSTS_VALU_TRANS_F32": 8,
+OTHER_CYCLES = 4.0
+CLASS_CYCLES = {"SQ_INSTS_VALU_ADD_F32": 4, "SQ_INSTS_VALU_MUL_F32": 4, "SQ_INSTS_VALU_FMA_F32": 4, "SQ_INSTS_VALU_TRANS_F32": 8,
                 "SQ_INSTS_VALU_ADD_F64": 4, "SQ_INSTS_VALU_MUL_F64": 4, "SQ_INSTS_VALU_FMA_F64": 4, "SQ_INSTS_VALU_TRANS_F64": 16,
                 "SQ_INSTS_VALU_INT64": 4, "SQ_INSTS_VALU_CVT": 4}
 if "SQ_INSTS_VALU" in tot:
     m["valu_insts_per_sample"] = tot["SQ_INSTS_VALU"] / N
     if all(c in tot for c in CLASS_CYCLES):
         classed = sum(tot[c] for c in CLASS_CYCLES)
-        cyc = sum(tot[c] * k for c, k in CLASS_CYCLES.items()) + 2.0 * (tot["SQ_INSTS_VALU"] - classed)
+        cyc = sum(tot[c] * k for c, k in CLASS_CYCLES.items()) + OTHER_CYCLES * (tot["SQ_INSTS_VALU"] - classed)
         m["valu_issue_cycles_per_inst"] = cyc / tot["SQ_INSTS_VALU"]
         m["valu_mix_per_sample"] = {c.replace("SQ_INSTS_VALU_", "").lower(): tot[c] / N for c in CLASS_CYCLES}
         m["valu_mix_per_sample"]["other"] = (tot["SQ_INSTS_VALU"] - classed) / N
         m["valu_class_cycles"] = {c.replace("SQ_INSTS_VALU_", "").lower(): k for c, k in CLASS_CYCLES.items()}
-        m["valu_class_cycles"]["other"] = 2
+        m["valu_class_cycles"]["other"] = OTHER_CYCLES
     if "SQ_ACTIVE_INST_VALU" in tot:
         m["valu_active_cycles_per_inst_measured"] = 4.0 * tot["SQ_ACTIVE_INST_VALU"] / tot["SQ_INSTS_VALU"]
 if "SQ_THREAD_CYCLES_VALU" in tot and "SQ_ACTIVE_INST_VALU" in tot:
