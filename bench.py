@@ -18,8 +18,9 @@ single-GPU run.
 
 Extra objects on the JSON line (definitions and formulas: DESIGN.md s5):
   roofline          -- the bound that binds pt_kernel: VALU issue.  achieved = VALU wave-instructions/s,
-                       peak = SIMDs x clock / issue cycles per instruction of the kernel's own mix (4 cycles per wave64
-                       instruction, f32 and f64 alike; transcendental 8 / 16: tools/make_pt_model.py); lane_utilisation beside it.
+                       peak = SIMDs x max clock / issue cycles per instruction of the kernel's own mix, class costs MEASURED on
+                       this GPU (tools/microbench/valu_cost.hip: f32 fma 2.5, f64 4, compare / select / integer / min / max 3.5,
+                       transcendental 7 / 14 cycles per wave64 instruction); lane_utilisation beside it.
                        Per-sample instruction counts come from the PMC passes committed under profiles/ (model
                        file named in `source`); the kernel time is measured live (HIP events on the launch stream).
   roofline_contract -- SURVEY s8d: algorithmic bytes per sample in the REFERENCE's traversal order / kernel time

@@ -7,14 +7,15 @@ pt_kernel dispatches of ONE pass (every pass runs the same command).
 Formulas:
   valu_insts_per_sample      = SQ_INSTS_VALU / N
   valu_issue_cycles_per_inst = sum_class(count_class * cycles_class) / SQ_INSTS_VALU, the SIMD cycles the kernel's own instruction
-                               mix needs per wave64 instruction.  Round 3: every non-transcendental VALU instruction is priced at 4
-                               cycles -- f32 as well as f64, integer, compare, select, move -- as MI355X_MICROARCH.md lists them
-                               ("v_add_f32 / v_fma_f32 / v_max3_f32 4 cycles", f64 fma at the same 16 lanes per clock: 78.6 TFLOP/s)
-                               and as this kernel measures them (SQ_ACTIVE_INST_VALU: 4.17 cycles per instruction on a mix that is
-                               two thirds f32 / integer / compare).  Rounds 1-2 priced f32 and "other" at 2 (the 157 TFLOP/s f32 peak
-                               needs packed instructions, which these kernels do not use and which measured slower): that put the
-                               peak 1.5x too high.  f32 transcendental 8, f64 transcendental (rcp, rsq, sqrt) 16.  Classes from
-                               SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F{32,64}, _INT64, _CVT; "other" = SQ_INSTS_VALU minus their sum
+                               mix needs per wave64 instruction.  Round 3: the class costs are MEASURED on the MI355X
+                               (tools/microbench/valu_cost.hip, profiles/r03/valu_cost_microbench.txt: streams of independent
+                               instructions at this kernel's occupancy, 4 waves per SIMD; f64 fma anchored at 4 cycles = the 78.6
+                               TFLOP/s f64 vector peak): f32 add/mul/fma 2.5, f64 add/mul/fma/ldexp/div_fixup 4, conversions 4,
+                               f32 transcendental 7, f64 rcp/rsq/sqrt 14, 64-bit integer 6.6 (two 32-bit halves), everything else 3.5
+                               (measured: integer add/xor/shift/alignbit 3.3, compare + select 3.3, f32 min/max 3.9, v_mul_lo_u32 4.0).
+                               Rounds 1-2 priced f32 and "other" at 2 cycles (the 157 TFLOP/s f32 figure needs packed
+                               instructions): that put the peak 1.4x too high.  Classes from SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F{32,64},
+                               _INT64, _CVT; "other" = SQ_INSTS_VALU minus their sum.
   valu_busy_measured         = 4 * SQ_ACTIVE_INST_VALU / (1024 SIMDs * GRBM_GUI_ACTIVE / 8)   (can exceed 1: active intervals of the
                                waves of one SIMD overlap)
   lane_utilisation           = SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU)
@@ -56,10 +57,10 @@ for d in a.dirs:
 
 N = a.samples
 m = {"kernel": sorted(names), "samples_in_pass": N, "source": a.source, "counters": {k: tot[k] for k in sorted(tot)}}
-OTHER_CYCLES = 4.0
-CLASS_CYCLES = {"SQ_INSTS_VALU_ADD_F32": 4, "SQ_INSTS_VALU_MUL_F32": 4, "SQ_INSTS_VALU_FMA_F32": 4, "SQ_INSTS_VALU_TRANS_F32": 8,
-                "SQ_INSTS_VALU_ADD_F64": 4, "SQ_INSTS_VALU_MUL_F64": 4, "SQ_INSTS_VALU_FMA_F64": 4, "SQ_INSTS_VALU_TRANS_F64": 16,
-                "SQ_INSTS_VALU_INT64": 4, "SQ_INSTS_VALU_CVT": 4}
+OTHER_CYCLES = 3.5
+CLASS_CYCLES = {"SQ_INSTS_VALU_ADD_F32": 2.5, "SQ_INSTS_VALU_MUL_F32": 2.5, "SQ_INSTS_VALU_FMA_F32": 2.5, "SQ_INSTS_VALU_TRANS_F32": 7,
+                "SQ_INSTS_VALU_ADD_F64": 4, "SQ_INSTS_VALU_MUL_F64": 4, "SQ_INSTS_VALU_FMA_F64": 4, "SQ_INSTS_VALU_TRANS_F64": 14,
+                "SQ_INSTS_VALU_INT64": 6.6, "SQ_INSTS_VALU_CVT": 4}
 if "SQ_INSTS_VALU" in tot:
     m["valu_insts_per_sample"] = tot["SQ_INSTS_VALU"] / N
     if all(c in tot for c in CLASS_CYCLES):

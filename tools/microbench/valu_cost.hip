@@ -1,0 +1,75 @@
+// Issue cost of VALU instructions on gfx950 at the occupancy of the path-tracing kernels (1024-thread workgroup per CU = 4 waves per
+// SIMD): shader cycles per wave64 instruction PER SIMD (all four waves of a SIMD run the same stream of independent instructions).
+// Build / run: hipcc --offload-arch=gfx950 -O2 tools/microbench/valu_cost.hip -o /tmp/valu_cost && /tmp/valu_cost
+// Basis of the roofline's cycle table (tools/make_pt_model.py).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#define REP8(x) x x x x x x x x
+#define REP64(x) REP8(REP8(x))
+template <int OP>
+__global__ void __launch_bounds__(1024) k(unsigned long long* out, int iters, double seed) {
+    double a = seed + threadIdx.x, b = seed * 3.0 + 1.0, c0 = 1.0, c1 = 2.0, c2 = 3.0, c3 = 4.0;
+    float fa = (float)a, fb = (float)b, f0 = 1.f, f1 = 2.f, f2 = 3.f, f3 = 4.f;
+    unsigned int ua = (unsigned)threadIdx.x * 2654435761u + 12345u, u0 = 1, u1 = 2, u2 = 3, u3 = 4;
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < iters; i++) {
+        if (OP == 0) { REP64(asm volatile("v_fma_f32 %0, %4, %5, %0\n v_fma_f32 %1, %4, %5, %1\n v_fma_f32 %2, %4, %5, %2\n v_fma_f32 %3, %4, %5, %3" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3) : "v"(fa), "v"(fb));) }
+        if (OP == 1) { REP64(asm volatile("v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %1, %4, %5, %1\n v_fma_f64 %2, %4, %5, %2\n v_fma_f64 %3, %4, %5, %3" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(a), "v"(b));) }
+        if (OP == 2) { REP64(asm volatile("v_min_f32 %0, %4, %0\n v_max_f32 %1, %4, %1\n v_min_f32 %2, %5, %2\n v_max_f32 %3, %5, %3" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3) : "v"(fa), "v"(fb));) }
+        if (OP == 3) { REP64(asm volatile("v_rcp_f64 %0, %4\n v_rcp_f64 %1, %5\n v_rcp_f64 %2, %4\n v_rcp_f64 %3, %5" : "=v"(c0), "=v"(c1), "=v"(c2), "=v"(c3) : "v"(a), "v"(b));) }
+        if (OP == 4) { REP64(asm volatile("v_sqrt_f64 %0, %4\n v_rsq_f64 %1, %5\n v_sqrt_f64 %2, %4\n v_rsq_f64 %3, %5" : "=v"(c0), "=v"(c1), "=v"(c2), "=v"(c3) : "v"(a), "v"(b));) }
+        if (OP == 5) { REP64(asm volatile("v_mul_lo_u32 %0, %4, %0\n v_mul_lo_u32 %1, %4, %1\n v_mul_lo_u32 %2, %4, %2\n v_mul_lo_u32 %3, %4, %3" : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3) : "v"(ua));) }
+        if (OP == 6) { REP64(asm volatile("v_xor_b32 %0, %4, %0\n v_add_u32 %1, %4, %1\n v_lshlrev_b32 %2, 3, %2\n v_alignbit_b32 %3, %3, %3, 5" : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3) : "v"(ua));) }
+        if (OP == 7) { REP64(asm volatile("v_cvt_f64_u32 %0, %4\n v_cvt_f32_f64 %2, %5\n v_cvt_f64_u32 %1, %4\n v_cvt_f32_u32 %3, %4" : "=v"(c0), "=v"(c1), "=v"(f0), "=v"(f1) : "v"(ua), "v"(a));) }
+        if (OP == 8) { REP64(asm volatile("v_rcp_f32 %0, %4\n v_rcp_f32 %1, %5\n v_sqrt_f32 %2, %4\n v_rsq_f32 %3, %5" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : "v"(fa), "v"(fb));) }
+        if (OP == 9) { REP64(asm volatile("v_add_f64 %0, %4, %0\n v_mul_f64 %1, %4, %1\n v_add_f64 %2, %5, %2\n v_mul_f64 %3, %5, %3" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(a), "v"(b));) }
+        if (OP == 10) { REP64(asm volatile("v_cmp_lt_f32 vcc, %4, %0\n v_cndmask_b32 %1, %4, %1, vcc\n v_cmp_lt_f64 vcc, %6, %7\n v_cndmask_b32 %3, %5, %3, vcc" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3) : "v"(fa), "v"(fb), "v"(a), "v"(b) : "vcc");) }
+        if (OP == 11) { REP64(asm volatile("v_ldexp_f64 %0, %4, 3\n v_div_fixup_f64 %1, %4, %5, %1\n v_ldexp_f64 %2, %5, 2\n v_div_fixup_f64 %3, %5, %4, %3" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(a), "v"(b));) }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if ((threadIdx.x & 63) == 0) out[(blockIdx.x * 16 + (threadIdx.x >> 6)) * 2] = t1 - t0;
+    if (c0 + c1 + c2 + c3 + f0 + f1 + f2 + f3 + (double)(u0 ^ u1 ^ u2 ^ u3) == 1.2345) out[1] = 1;
+}
+template <int OP>
+static void run(const char* name) {
+    const int blocks = 256, iters = 200;
+    unsigned long long* d;
+    hipMalloc(&d, blocks * 16 * 2 * 8);
+    hipMemset(d, 0, blocks * 16 * 2 * 8);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(1024), 0, 0, d, 10, 1.5);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(1024), 0, 0, d, iters, 1.5);
+    hipEventRecord(e1);
+    hipDeviceSynchronize();
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    std::vector<unsigned long long> h(blocks * 16 * 2);
+    hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
+    double mean = 0;
+    for (int i = 0; i < blocks * 16; i++) mean += (double)h[2 * i];
+    mean /= blocks * 16;
+    const double n_inst = (double)iters * 64 * 4;           // per wave
+    // 4 waves share a SIMD: SIMD cycles per wave-instruction = wave's elapsed cycles / (4 waves * n_inst)
+    printf("%-44s %8.3f s_memtime ticks per wave-instruction per SIMD   (kernel %.3f ms -> %.3f ns per wave-instruction per SIMD)\n", name, mean / (4.0 * n_inst), ms,
+           ms * 1e6 / (4.0 * n_inst));
+    hipFree(d);
+}
+int main() {
+    run<0>("v_fma_f32");
+    run<1>("v_fma_f64");
+    run<9>("v_add_f64 / v_mul_f64");
+    run<2>("v_min_f32 / v_max_f32");
+    run<6>("v_xor / v_add_u32 / v_lshlrev / v_alignbit");
+    run<10>("v_cmp_lt_f32|f64 + v_cndmask");
+    run<5>("v_mul_lo_u32");
+    run<7>("v_cvt_f64_u32 / v_cvt_f32_f64 / v_cvt_f32_u32");
+    run<11>("v_ldexp_f64 / v_div_fixup_f64");
+    run<8>("v_rcp_f32 / v_sqrt_f32 / v_rsq_f32");
+    run<3>("v_rcp_f64");
+    run<4>("v_sqrt_f64 / v_rsq_f64");
+    return 0;
+}
