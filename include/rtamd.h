@@ -90,7 +90,10 @@ typedef struct rt_params {
     int32_t kernel;      /* 0 = auto; 1 = reference-order stackless traversal; 2 = SAH-BVH2 accel traversal (auto whenever the
                             scene has a usable accel); 5 = kernel 2's BVH with the cooperative instance service: the walks
                             through mesh instances are queued per workgroup and served by full waves (auto when an
-                            instance's object-space BVH has >= 64 nodes; needs 1..32 instances of f32-vertex triangles).
+                            instance's object-space BVH has >= 64 nodes; needs 1..32 instances of f32-vertex triangles);
+                            6 = the same service across the whole GPU and across launches (parked paths in HBM pools, a
+                            dedicated walk launch per cycle; 1..64 instances; auto only for 33..64 large instances -- it is
+                            slower than kernel 5 where both apply; workspace ~8.6 GB).
                             All give bit-identical images (same f64 primitive tests, same tie rule). */
     int32_t device;      /* HIP device ordinal; -1 = current */
     int32_t integrator;  /* 0 = sample_ray as the reference structures it (BSDF sampling only; default);
