@@ -40,6 +40,9 @@ struct MediumDev {  // objects/medium.rs:9-13
     double neg_inv_density;  // -1 / d
     int32_t mat;             // phase function (an Isotropic material)
     int32_t pad;
+    // where the medium sits in the reference-order program (the accel kernel walks the two copies of the boundary's subtree itself:
+    // [n_begin + 1, n_mid) and [n_mid + 1, n_end)); n_end is also the node index of the medium's hit (tie rule)
+    uint32_t n_begin, n_mid, n_end, pad2;
 };
 struct MatDev {   // material.rs:88-212 (+ :213-231, the commented-out Isotropic)
     int32_t type;  // 0 Lambertian, 1 Metal, 2 Dielectric, 3 DiffuseLight, 4 Isotropic
@@ -97,7 +100,8 @@ struct FlatView {  // by-value kernel argument
     const char* base;
     uint32_t off_meta, off_boxes, off_spheres, off_sphere_mat, off_rects, off_rect_mat, off_tris, off_xforms;
     uint32_t off_mats, off_texs, off_vpos, off_vnrm, off_texels;
-    uint32_t off_media;    // cold part: MediumDev per ConstantMedium
+    uint32_t off_media;    // cold part: MediumDev per ConstantMedium, in the reference's visit order
+    uint32_t n_media;
     uint32_t n_nodes;
     uint32_t stage_bytes;  // kernel 1 stages bytes [0, stage_bytes) into LDS: [meta|boxes|spheres|rects|tris|xforms|vpos]
     uint32_t kinds_mask;   // bit k set if some node has kind k

@@ -303,8 +303,9 @@ struct Hit {
 // MEDIA: the program contains ConstantMedium brackets (NK_MEDIUM_*, common/flat.h): between BEGIN and END the walk answers the
 // two boundary queries of ConstantMedium::hit (medium.rs:26-27) in a scratch hit with its own range [lo, +inf), then END
 // restores the outer best hit and makes the medium's one random draw from the path's stream.
+// [n0, n1): the part of the program to walk (default: all of it; traverse2_media walks a medium's boundary subtree).
 template <bool GENERAL, bool MEDIA = false>
-DEV Hit traverse(const Acc& A, D3 wo, D3 wd, double t_min, double t_max, Rng* rng = nullptr) {
+DEV Hit traverse(const Acc& A, D3 wo, D3 wd, double t_min, double t_max, Rng* rng = nullptr, uint32_t n0 = 0u, uint32_t n1 = 0xFFFFFFFFu) {
     D3 o = wo, d = wd;
     D3 inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
     double a = sqlen(d);
@@ -314,8 +315,8 @@ DEV Hit traverse(const Acc& A, D3 wo, D3 wd, double t_min, double t_max, Rng* rn
     h.xf = -1;
     h.kp = 0;
     int cur_xf = -1;
-    uint32_t n = 0;
-    const uint32_t N = A.n_nodes;
+    uint32_t n = n0;
+    const uint32_t N = min(A.n_nodes, n1);
     const double t_min_outer = t_min;
     Hit h_outer = h;      // MEDIA: the outer best hit while a boundary query runs
     double t_a = 0.;      // MEDIA: t of boundary query A
@@ -520,8 +521,10 @@ DEV bool box32(float lox, float loy, float loz, float hix, float hiy, float hiz,
 // TOP: the scene lives in L2/HBM and the shallowest nodes are cached in LDS (A.n2_top); false for LDS-resident scenes, which then
 // carry no test for it in the node loop.
 // WIDE: the node table is the LDS-resident NodeW form (A.n2w_lds; implies !TOP).
-template <bool GENERAL, bool DEFER = false, bool TOP = true, bool WIDE = false, class PEND = uint32_t>
-DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, double t_min, double t_max, PEND* pend = nullptr) {
+// LIMIT: only items whose reference-order index is below order_limit take part (traverse2_media: "the closest surface the
+// reference has seen before it visits this medium").
+template <bool GENERAL, bool DEFER = false, bool TOP = true, bool WIDE = false, class PEND = uint32_t, bool LIMIT = false>
+DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, double t_min, double t_max, PEND* pend = nullptr, uint32_t order_limit = 0xFFFFFFFFu) {
     D3 o = wo, d = wd;
     double a = sqlen(d);
     Hit h;
@@ -617,7 +620,10 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
                 uint32_t kind = it.x & NK_MASK, pl = it.x >> NK_BITS;
                 double t = 0.;
                 bool got = false;
-                if (kind == NK_SPHERE) {
+                if (LIMIT && it.y >= order_limit) {
+                    // visited by the reference after the medium in question (an instance's subtree is contiguous in the program and
+                    // media are world-level, so an instance lies wholly before or wholly after it: its item's order decides)
+                } else if (kind == NK_SPHERE) {
                     got = sphere_hit(A.spheres + 2 * pl, o, d, a, t_min, h.t, t);
                 } else if (GENERAL) {
                     if (kind == NK_RECT_YZ || kind == NK_RECT_XZ || kind == NK_RECT_XY) {
@@ -682,6 +688,63 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
         }
     }
     return h;
+}
+
+// World::hit through the accel for a scene with ConstantMedium objects (objects/medium.rs:25-53).  A medium's hit() makes its
+// one random draw only if the ray is inside its boundary somewhere within [t_min, closest hit SO FAR], and "so far" means: among
+// what the reference has visited BEFORE the medium.  The accel visits things in another order, so the media are handled apart, in
+// the reference's order (A.media is in program order):
+//   S  = closest surface of all (one accel walk, the box tests merely cull);
+//   for each medium M:  S_M = closest surface among those the reference visits before M -- S itself when S comes before M in the
+//       program, otherwise a second accel walk restricted to items with a smaller index (LIMIT);
+//       t_max = min(S_M.t, t of the latest medium hit accepted so far);   rec1 / rec2 = the two boundary queries, walked over the
+//       medium's own two copies of the boundary's subtree in the reference-order program (exact f64, any sign of t);
+//       then medium.rs:28-50 literally: clip, at most one draw, accept t = rec1.t + hit_distance / |d| (it is <= t_max).
+//   result = the later-accepted of S and the last medium hit: smaller t, an exact tie to the larger program index.
+// Equivalence with the recursion: a surface is accepted by the reference iff its t <= closest so far, whatever came before, so the
+// final surface candidate is S; a medium's hit depends only on t_max at its visit = what precedes it, which is what S_M and the
+// earlier media hits give; the reference's own box tests cull a medium exactly when its clipped interval is empty (no draw
+// either way), up to rays that graze a reference box within f64 rounding (the measure-zero caveat of kernel 2).
+template <bool GENERAL, bool TOP, bool WIDE>
+DEV Hit traverse2_media(const Acc& A, uint32_t n_media, uint32_t* stk, const int stride, D3 o, D3 d, double t_min, Rng& rng) {
+    const Hit S = traverse2<GENERAL, false, TOP, WIDE>(A, stk, stride, o, d, t_min, INFINITY);
+    Hit best = S;          // running result
+    double t_med = INFINITY;  // t of the latest accepted medium hit
+    const double ray_length = sqrt(sqlen(d));
+    for (uint32_t k = 0; k < n_media; k++) {
+        const MediumDev M = A.media[k];
+        // boundary queries first: most rays miss most media, and a miss needs nothing else (medium.rs:26-27)
+        const Hit r1h = traverse<true, false>(A, o, d, -INFINITY, INFINITY, nullptr, M.n_begin + 1u, M.n_mid);
+        if (r1h.node < 0) continue;
+        const Hit r2h = traverse<true, false>(A, o, d, r1h.t + 0.0001, INFINITY, nullptr, M.n_mid + 1u, M.n_end);
+        if (r2h.node < 0) continue;
+        double t_max = t_med;
+        if (S.node >= 0) {
+            if ((uint32_t)S.node < M.n_begin) {
+                t_max = fmin(t_max, S.t);
+            } else if (S.t < r2h.t) {  // (S comes after M; a surface before M is no closer than S: if even S lies beyond the exit nothing clips)
+                const Hit SM = traverse2<GENERAL, false, TOP, WIDE, uint32_t, true>(A, stk, stride, o, d, t_min, INFINITY, nullptr, M.n_begin);
+                if (SM.node >= 0) t_max = fmin(t_max, SM.t);
+            }
+        }
+        double r1 = fmax(r1h.t, t_min);
+        const double r2 = fmin(r2h.t, t_max);
+        if (r1 >= r2) continue;
+        r1 = fmax(r1, 0.);
+        const double distance_inside_boundary = (r2 - r1) * ray_length;
+        const double hit_distance = M.neg_inv_density * det_ln(rng.gen_f64());  // the only draw, medium.rs:37-38
+        if (hit_distance > distance_inside_boundary) continue;
+        t_med = r1 + hit_distance / ray_length;
+        Hit hm;
+        hm.t = t_med;
+        hm.node = (int)M.n_end;
+        hm.xf = -1;
+        hm.kp = NK_MEDIUM_END | (k << NK_BITS);
+        // the reference accepts it (t <= its t_max); against S it wins when closer, or on an exact tie when it is visited later
+        if (S.node < 0 || hm.t < S.t || (hm.t == S.t && hm.node > S.node)) best = hm;
+        else best = S;
+    }
+    return best;
 }
 
 struct Rec {  // HitRecord, hit.rs:7-14
@@ -1159,6 +1222,10 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
         A = make_acc(smem - st_begin, sv.base, sv);
         A.n2 = nullptr;
         A.n2w_lds = (uint32_t)(uintptr_t)(AS_L char*)n2w;
+        if (MEDIA) {  // the media's boundary subtrees are walked in the reference-order program, which this kernel does not stage
+            A.meta = (const uint2*)(sv.base + sv.off_meta);
+            A.boxes = (const double2*)(sv.base + sv.off_boxes);
+        }
     } else if (LDS) {
         const uint4* src = (const uint4*)(sv.base + st_begin);
         uint4* dst = (uint4*)smem;
@@ -1265,7 +1332,8 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
             }
             // ---- one path segment: sample_ray's loop body, photon_mapper.rs:335-362 ----
             if (alive) {
-                Hit h = (ACCEL == 2) ? traverse2<GENERAL, false, !LDS, LDS>(A, stk, stk_stride, o, d, rk.t_min, INFINITY)
+                Hit h = (ACCEL == 2) ? (MEDIA ? traverse2_media<GENERAL, !LDS, LDS>(A, sv.n_media, stk, stk_stride, o, d, rk.t_min, rng)
+                                               : traverse2<GENERAL, false, !LDS, LDS>(A, stk, stk_stride, o, d, rk.t_min, INFINITY))
                                      : traverse<GENERAL, MEDIA>(A, o, d, rk.t_min, INFINITY, &rng);
                 bool done = true;
                 if (h.node >= 0 && depth > 0) {  // Q12: depth test after the hit, before emission
@@ -2536,7 +2604,7 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
     const size_t stack2_bytes = (size_t)view.stack2 * PT_BLOCK * sizeof(uint32_t);
     const size_t hot1 = (size_t)view.stage_bytes, hot2 = (size_t)(view.stage2_end - view.stage2_begin);
     const bool accel2_usable = view.accel_ok && camera_ok && stack2_bytes <= lds_max;  // per-lane stacks live in LDS
-    const bool media = (view.kinds_mask & (1u << NK_MEDIUM_BEGIN)) != 0;               // flatten.cpp: such scenes have no accel
+    const bool media = (view.kinds_mask & (1u << NK_MEDIUM_BEGIN)) != 0;               // kernel 1, or kernel 2's MEDIA variant (traverse2_media)
     // kernel 5 = kernel 2's BVH with the cooperative instance service (pt_kernel_coop): for scenes with LARGE mesh instances
     const uint32_t stack5 = std::max(view.world_depth2, view.inst_depth2) + 2u;  // the two walks of kernel 5 never share a stack
     const size_t stack5_bytes = (size_t)stack5 * PT_BLOCK * sizeof(uint32_t);
@@ -2589,7 +2657,9 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
     pt_coop_fn fn_coop = nullptr;
     if (kernel == 5)
         fn_coop = (integ == 1) ? pt_kernel_coop<1> : (integ == 2) ? pt_kernel_coop<2> : pt_kernel_coop<0>;
-    if (media) fn = lds ? pt_kernel<true, true, 1, 0, true> : pt_kernel<false, true, 1, 0, true>;
+    if (media)
+        fn = (kernel == 2) ? (lds ? pt_kernel<true, true, 2, 0, true> : pt_kernel<false, true, 2, 0, true>)
+                           : (lds ? pt_kernel<true, true, 1, 0, true> : pt_kernel<false, true, 1, 0, true>);
     // scene too large for LDS: spend what is left after the stacks on the shallowest BVH levels (the Node2 array is depth-sorted)
     int n_top = 0, n_topq = 0;
     if (kernel == 2 && !lds && lds_max > stack_bytes) {

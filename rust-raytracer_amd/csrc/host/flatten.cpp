@@ -28,6 +28,7 @@ struct Builder {
     std::vector<uint32_t> tris;
     std::vector<double> tripre;  // per triangle: pa, e0 = pb - pa, e1 = pc - pa, pad (10 doubles = 80 B)
     std::vector<MediumDev> media;
+    double media_extent = 0.;  // largest |coordinate| of the media's bounding boxes: scatter points inside a medium are ray origins too
     std::map<int, uint32_t> medium_of;
     int medium_depth = 0;
     std::map<int, uint32_t> sphere_of, rect_of, tri_of, xform_of;
@@ -49,6 +50,7 @@ struct Builder {
     bool accel_ok = true;
 
     void accel_item(int obj_id, const ObjectRec& o, uint32_t kp, uint32_t node_index, const Box* tight = nullptr) {
+        if (medium_depth > 0) return;  // the boundary of a ConstantMedium is not a surface: only the medium's own two queries see it
         InstCtx& c = actx[ctx_stack.back()];
         if (!o.has_box) {
             accel_ok = false;
@@ -155,6 +157,14 @@ struct Builder {
                 // accel: the Transform is one item of the enclosing space; its subtree gets its own object-space BVH
                 // (a Transform emitted twice -- BVHNode::new's 1-object leaf, Q14 -- re-enters its own context, so its
                 // items take the later visit's indices exactly as a re-emitted primitive does)
+                if (medium_depth > 0) {  // a Transform inside a medium's boundary: reference-order program only, no accel context
+                    xf_depth++;
+                    emit(o.children[0]);
+                    xf_depth--;
+                    node(NK_XFORM_END, it->second);
+                    meta[2 * n + 1] = (uint32_t)(meta.size() / 2);
+                    break;
+                }
                 auto ci = ctx_of_xform.find(id);
                 if (ci == ctx_of_xform.end()) {
                     actx.emplace_back();
@@ -176,21 +186,29 @@ struct Builder {
             }
             case OBJ_MEDIUM: {
                 // ConstantMedium::hit consumes a random number INSIDE hit (medium.rs:37-38), so what the path draws depends on
-                // the order in which the reference visits objects: only the reference-order program (kernel 1) is valid.
-                accel_ok = false;
+                // the order in which the reference visits objects.  Kernel 1 walks the reference-order program; the accel kernel
+                // (kernel 2) reproduces the visit order for the media only (traverse2_media in kernels.hip), which needs every
+                // medium in world space (not under a Transform).
                 if (medium_depth > 0) throw RtError(RT_ERR_UNSUPPORTED, "a ConstantMedium inside the boundary of a ConstantMedium is not supported");
-                auto it = medium_of.find(id);
-                if (it == medium_of.end()) {
-                    it = medium_of.emplace(id, (uint32_t)media.size()).first;
-                    media.push_back(MediumDev{-1. / o.density, o.material, 0});
-                }
+                // one MediumDev per VISIT: BVHNode::new duplicates a single object into both children (Q14), so the reference visits
+                // such a medium twice, and each visit may draw
+                const uint32_t mi = (uint32_t)media.size();
+                media.push_back(MediumDev{-1. / o.density, o.material, 0, 0, 0, 0, 0});
+                if (xf_depth > 0) accel_ok = false;  // a medium under a Transform: reference order only
+                if (o.has_box)
+                    for (int a = 0; a < 3; a++) media_extent = std::fmax(media_extent, std::fmax(std::fabs(o.box.mn[a]), std::fabs(o.box.mx[a])));
+                else
+                    accel_ok = false;
                 medium_depth++;
-                node(NK_MEDIUM_BEGIN, it->second);
+                uint32_t beg = node(NK_MEDIUM_BEGIN, mi);
                 emit(o.children[0]);
-                uint32_t mid = node(NK_MEDIUM_MID, it->second);
+                uint32_t mid = node(NK_MEDIUM_MID, mi);
                 emit(o.children[0]);
-                uint32_t end = node(NK_MEDIUM_END, it->second);
+                uint32_t end = node(NK_MEDIUM_END, mi);
                 meta[2 * mid + 1] = end;
+                media[mi].n_begin = beg;
+                media[mi].n_mid = mid;
+                media[mi].n_end = end;
                 medium_depth--;
                 break;
             }
@@ -328,7 +346,7 @@ void flatten(rt_scene& s) {
         // in csrc/device/kernels.hip, which also needs every coordinate below 2^36 in magnitude); the pad is THREE times that
         // (12 * 2^-24 * |o|max) since round 3 so that box32w, the test of the LDS-resident node table, needs no widening factor
         // on the far side (its proof, above box32w, uses the extra margin against the relative error of the slab parameters)
-        double ew = 0.;
+        double ew = b.media_extent;
         for (auto& it : b.actx[0].items)
             for (int a = 0; a < 3; a++) ew = std::fmax(ew, std::fmax(std::fabs(it.box.mn[a]), std::fabs(it.box.mx[a])));
         if (!(ew > 0.) || !std::isfinite(ew)) {
@@ -579,6 +597,7 @@ void flatten(rt_scene& s) {
     v.off_mats = append(f.blob, mats);
     v.off_texs = append(f.blob, texs);
     v.off_media = append(f.blob, b.media);
+    v.n_media = (uint32_t)b.media.size();
     v.off_lights = append(f.blob, lights);
     v.n_lights = (uint32_t)(lights.size() / 2);
     v.off_vpos = append(f.blob, b.vpos);  // kept for introspection; the kernels read tripre instead

@@ -124,7 +124,7 @@ def test_product_describes_and_flattens_media():
     items = _smoke_scene(w, 1)
     w.new(items, bvh_seed=1)
     info = w.info()
-    assert info["accel_ok"] == 0                      # RNG inside hit(): reference order only
+    assert info["accel_ok"] == 1                      # world-level media keep the accel (kernel 2's MEDIA variant, round 3)
     kind, d = w.describe(items[3])
     assert kind == "ConstantMedium" and d["v"][0] == 1.2 and len(d["children"]) == 1 and w.describe(d["children"][0])[0] == "Sphere"
     with pytest.raises(rtamd.RtError) as e:
@@ -165,8 +165,10 @@ def test_hip_media_bit_exact_vs_oracle():
     cam = rtamd.Camera(((0.0, 2.5, -9.0), (0.0, 1.0, 0.0)), (0, 1, 0), 40.0, 1.5, 0.02, 9.0)
     img, st = w.render(cam, width=96, height=64, spp=16, seed=3)
     exp, _ = o.render(96, 64, 16, seed=3)
-    assert st["kernel_used"] == 1
+    assert st["kernel_used"] == 2                     # the accel kernel's MEDIA variant is the automatic choice since round 3
     assert np.array_equal(img, exp), np.abs(img - exp).max()
+    img1, st1 = w.render(cam, width=96, height=64, spp=16, seed=3, kernel=1)   # the reference-order kernel stays the cross-check
+    assert st1["kernel_used"] == 1 and np.array_equal(img1, exp)
     assert img.max() > 0.5
     # the fog really scatters: the same scene without the two media renders differently
     w2 = rtamd.World()
@@ -174,10 +176,78 @@ def test_hip_media_bit_exact_vs_oracle():
     w2.new([it for i, it in enumerate(items) if i not in (3, 4)], bvh_seed=5)
     clear, _ = w2.render(cam, width=96, height=64, spp=16, seed=3)
     assert not np.array_equal(clear, img)
-    # kernel 2, light sampling and the closest-hit diagnostic refuse scenes with media
-    for kw in (dict(kernel=2), dict(integrator=1)):
+    # light sampling, kernels 5 / 6 and the closest-hit diagnostic refuse scenes with media
+    for kw in (dict(kernel=5), dict(kernel=6), dict(integrator=1)):
         with pytest.raises(rtamd.RtError) as e:
             w.render(cam, width=8, height=8, spp=1, **kw)
         assert e.value.code in (-10, -1)
     with pytest.raises(rtamd.RtError):
         w.debug_hit(np.zeros((1, 6)) + 1.0, kernel=1)
+
+
+def _fog_zoo(B, order):
+    """media that overlap each other and surfaces, a camera INSIDE a fog, a medium whose boundary is a Transform(Cube), media
+    early and late in the list (`order` permutes it: the reference's visit order decides which medium draws first)."""
+    white = B.Lambertian(B.ConstantTexture((0.8, 0.8, 0.8)))
+    red = B.Lambertian(B.ConstantTexture((0.8, 0.2, 0.2)))
+    light = B.DiffuseLight(B.ConstantTexture((5.0, 5.0, 5.0)))
+    fog_a = B.Isotropic(B.ConstantTexture((0.9, 0.9, 1.0)))
+    fog_b = B.Isotropic(B.ConstantTexture((0.3, 0.6, 0.3)))
+    glass = B.Dielectric(1.5, B.ConstantTexture((1.0, 1.0, 1.0)))
+    mirror = B.Metal(B.ConstantTexture((0.9, 0.9, 0.9)), 0.0)
+    items = [
+        B.XZRectangle((-30.0, -30.0), (30.0, 30.0), 0.0, white),
+        B.XZRectangle((-4.0, -4.0), (4.0, 4.0), 9.0, light),
+        B.ConstantMedium(0.05, B.Sphere((0.0, 3.0, -6.0), 7.0, white), fog_a),           # holds the camera
+        B.Sphere((0.0, 1.0, 0.0), 1.0, red),                                               # a surface inside the big fog
+        B.ConstantMedium(0.9, B.Sphere((0.8, 1.0, 0.2), 1.2, white), fog_b),              # overlaps the red ball and the big fog
+        B.Sphere((-2.5, 1.0, 1.0), 1.0, glass),
+        B.ConstantMedium(0.4, B.Transform((0.0, 25.0, 0.0), (1.2, 0.8, 1.2), (2.8, 0.81, -1.0), B.Cube((-1.0, -1.0, -1.0), (1.0, 1.0, 1.0), white)), fog_a),
+        B.Sphere((3.0, 1.0, 2.5), 1.0, mirror),
+        B.YZRectangle((0.0, -8.0), (6.0, 8.0), -6.0, red),
+    ]
+    return [items[i] for i in order]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("order,bvh", [((0, 1, 2, 3, 4, 5, 6, 7, 8), 2), ((8, 6, 4, 2, 7, 5, 3, 1, 0), 7), ((4, 3, 2, 6, 0, 1, 8, 7, 5), None)])
+def test_hip_media_on_the_accel_path_bit_exact(order, bvh):
+    """kernel 2's MEDIA variant (the accel finds the surfaces; the media are resolved in the reference's visit order, one draw
+    each at most) against the oracle's recursion, under different visit orders (list permutations, BVH seeds, a plain
+    HitableList without BVH) -- which medium draws first, and what clips it, changes with each."""
+    import oracle
+    import rtamd
+    w = rtamd.World()
+    o = oracle.Scene()
+    if bvh is None:
+        w.set_root(w.HitableList(_fog_zoo(w, order)))
+        o.set_root(o.HitableList(_fog_zoo(o, order)))
+    else:
+        w.new(_fog_zoo(w, order), bvh_seed=bvh)
+        o.World(_fog_zoo(o, order), bvh)
+    args = ((0.0, 2.0, -9.0), (0.0, 1.0, 0.0), (0, 1, 0), 45.0, 1.0, 0.0, 9.0)
+    o.Camera(*args)
+    cam = rtamd.Camera((args[0], args[1]), *args[2:])
+    assert w.info()["accel_ok"] == 1
+    exp, _ = o.render(64, 64, 8, seed=11)
+    for k in (2, 1):
+        img, st = w.render(cam, width=64, height=64, spp=8, seed=11, kernel=k)
+        assert st["kernel_used"] == k
+        assert np.array_equal(img, exp), (k, int((img != exp).any(axis=2).sum()))
+    assert exp.max() > 0
+
+
+def test_a_medium_under_a_transform_keeps_the_reference_order_kernel_and_a_shared_one_does_not():
+    import rtamd
+    w = rtamd.World()
+    white = w.Lambertian(w.ConstantTexture((0.8, 0.8, 0.8)))
+    fog = w.Isotropic(w.ConstantTexture((0.9, 0.9, 1.0)))
+    med = w.ConstantMedium(0.3, w.Sphere((0.0, 1.0, 0.0), 1.0, white), fog)
+    w.new([w.XZRectangle((-5.0, -5.0), (5.0, 5.0), 0.0, white), w.Transform((0.0, 10.0, 0.0), (1.0, 1.0, 1.0), (1.0, 0.0, 0.0), med)], bvh_seed=1)
+    assert w.info()["accel_ok"] == 0
+    w2 = rtamd.World()
+    white = w2.Lambertian(w2.ConstantTexture((0.8, 0.8, 0.8)))
+    fog = w2.Isotropic(w2.ConstantTexture((0.9, 0.9, 1.0)))
+    med = w2.ConstantMedium(0.3, w2.Sphere((0.0, 1.0, 0.0), 1.0, white), fog)
+    w2.set_root(w2.HitableList([w2.XZRectangle((-5.0, -5.0), (5.0, 5.0), 0.0, white), med, med]))
+    assert w2.info()["accel_ok"] == 1          # visited twice (as BVHNode::new's one-object leaves do, Q14): two visits, each may draw
