@@ -125,6 +125,17 @@ def launch_ranks(args, argv):
     return subprocess.call(rank_command(args.gpus, argv, port), env=env)
 
 
+def kernel_source_sha16():
+    """hash of the device sources of this tree (tools/make_pt_model.py stores the same hash in a PMC model file)"""
+    import hashlib
+    root = os.path.join(ROOT, "rust-raytracer_amd", "csrc")
+    h = hashlib.sha256()
+    for rel in ("device/kernels.hip", "device/wavefront.inc", "device/sppm.inc", "device/device.h", "common/flat.h", "common/rng.h", "common/detlog.h"):
+        with open(os.path.join(root, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def roofline_objects(stats_acc, dt_kernel_s, clock_note=None, model_path=None, alg_path=None):
     """roofline / roofline_contract / roofline_hbm for pt_kernel (see the module docstring and DESIGN.md s5).  model_path / alg_path:
     another configuration's PMC model and algorithmic-bytes fixture (tools/config_bench.py); default: the bench workload's."""
@@ -159,7 +170,11 @@ def roofline_objects(stats_acc, dt_kernel_s, clock_note=None, model_path=None, a
                      "valu_insts_per_sample": ipc, "valu_issue_cycles_per_inst": cyc, "clock_ghz": clk, "clock_ghz_in_pmc_pass": model["clock_ghz"],
                      "valu_mix_per_sample": model.get("valu_mix_per_sample"),
                      "source": "per-sample counts carried over from %s; kernel time measured in this run" % model.get("source", "profiles/")})
-        if frac is not None and not (0.0 < frac <= 1.05):
+        if model.get("kernel_source_sha16") not in (None, kernel_source_sha16()):
+            roof.update({"frac": None, "useful_frac": None,
+                         "note": "the PMC model was measured on other device sources (%s) than this tree's (%s): per-sample counts not carried over" %
+                                 (model.get("kernel_source_sha16"), kernel_source_sha16())})
+        elif frac is not None and not (0.0 < frac <= 1.05):
             roof.update({"frac": None, "useful_frac": None,
                          "note": "live kernel rate and the PMC model disagree (frac %.3f): the model file is stale for this build" % frac})
         bps = model.get("hbm_bytes_per_sample")

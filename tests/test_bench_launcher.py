@@ -79,6 +79,15 @@ def test_roofline_objects_are_physical():
     assert roof["frac"] is None and "stale" in roof["note"]
 
 
+def test_committed_pmc_model_belongs_to_the_committed_kernel_sources():
+    """the bench line's roofline carries per-sample counts over from profiles/pt_kernel_model.json: the model must have been
+    measured on the device sources of this tree (bench.py reports frac = None otherwise)"""
+    sys.path.insert(0, ROOT)
+    import bench
+    model = json.load(open(bench.MODEL))
+    assert model.get("kernel_source_sha16") == bench.kernel_source_sha16(), "re-run tools/r03_headline_pmc.sh and copy its pt_kernel_model.json to profiles/"
+
+
 @pytest.mark.gpu
 def test_two_rank_branch_of_bench_rehearsed_on_one_gpu():
     r = _run(["--gpus", "2", "--steps", "1", "--warmup", "1", "--width", "96", "--height", "72", "--spp", "8", "--cpu-spp", "0"],

@@ -38,6 +38,17 @@ ap.add_argument("--out", required=True)
 ap.add_argument("dirs", nargs="+")
 a = ap.parse_args()
 
+
+def kernel_source_sha16():
+    """hash of the device sources the model was measured on (bench.py compares it with the tree it runs in)"""
+    import hashlib
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rust-raytracer_amd", "csrc")
+    h = hashlib.sha256()
+    for rel in ("device/kernels.hip", "device/wavefront.inc", "device/sppm.inc", "device/device.h", "common/flat.h", "common/rng.h", "common/detlog.h"):
+        with open(os.path.join(root, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
 tot = defaultdict(float)      # counter -> sum over pt_kernel dispatches
 dur = defaultdict(float)      # counter -> kernel ns of the pass that counted it
 names = set()
@@ -56,7 +67,8 @@ for d in a.dirs:
                 dur[c] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
 
 N = a.samples
-m = {"kernel": sorted(names), "samples_in_pass": N, "source": a.source, "counters": {k: tot[k] for k in sorted(tot)}}
+m = {"kernel": sorted(names), "samples_in_pass": N, "source": a.source, "kernel_source_sha16": kernel_source_sha16(),
+     "counters": {k: tot[k] for k in sorted(tot)}}
 OTHER_CYCLES = 3.5
 CLASS_CYCLES = {"SQ_INSTS_VALU_ADD_F32": 2.5, "SQ_INSTS_VALU_MUL_F32": 2.5, "SQ_INSTS_VALU_FMA_F32": 2.5, "SQ_INSTS_VALU_TRANS_F32": 7,
                 "SQ_INSTS_VALU_ADD_F64": 4, "SQ_INSTS_VALU_MUL_F64": 4, "SQ_INSTS_VALU_FMA_F64": 4, "SQ_INSTS_VALU_TRANS_F64": 14,
