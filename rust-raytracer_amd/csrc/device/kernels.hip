@@ -64,9 +64,12 @@ DEV double dot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }  // vec
 DEV double sqlen(D3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }     // vec3.rs:61-63
 DEV D3 cross(D3 a, D3 b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 DEV double comp(D3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+// Measured and dropped in round 3 (both forms exact in the whole suite): (a) the three divisions of unit() / of (p - c) / radius
+// sharing ONE reciprocal refinement of the hardware's division pipeline (the three v_div_scale of the denominator, taken as the
+// compiler's expansion takes them, must return the denominator itself; else plain divisions): 33 -> 29 VALU and two v_rcp_f64 less
+// per triple, 2838 against 2836 Msamples/s; (b) division by a correctly rounded reciprocal with one fma correction behind an exponent
+// guard: +-0 as in round 2.  Only (b) WITHOUT its guard gains (+1.8 %), and that is not exact at the ends of the exponent range.
 // Vec3::unit, vec3.rs:85-90 ; the panic becomes a sticky error flag
-// (measured again in round 3 and dropped again: the three divisions by l through ONE correctly rounded reciprocal -- q = x y, r = fma(-l, q, x),
-// fma(r, y, q), exact by Markstein's theorem, exponent-guarded -- here and for (p - c) / radius: bit-exact in the whole suite, 2836 against 2838 Msamples/s)
 DEV D3 unit(D3 a, int* err) {
     double l = sqrt(sqlen(a));
     if (l == 0.) atomicOr(err, 1);
