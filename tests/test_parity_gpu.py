@@ -768,6 +768,9 @@ def test_wavefront_kernel_64_instances_bit_exact():
     b, st = w.render(cam, width=128, height=128, spp=4, seed=8, kernel=6)
     assert st["kernel_used"] == 6
     _assert_same(b, a, "64 instances, kernel 6 against kernel 2")
+    auto, st0 = w.render(cam, width=128, height=128, spp=4, seed=8)
+    assert st0["kernel_used"] == 6      # 33..64 large instances: kernel 5 does not apply, kernel 6 is the automatic choice
+    _assert_same(auto, a, "64 instances, automatic kernel")
     k1, _ = w.render(cam, width=48, height=48, spp=2, seed=8, kernel=1)
     k6, _ = w.render(cam, width=48, height=48, spp=2, seed=8, kernel=6)
     _assert_same(k6, k1, "64 instances, kernel 6 against the reference-order kernel")
