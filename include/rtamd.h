@@ -307,7 +307,8 @@ int rt_debug_rng_device(uint64_t seed, uint64_t pixel, uint64_t sample, int n, u
 int rt_debug_rng_host(uint64_t seed, uint64_t pixel, uint64_t sample, int n, uint64_t* out_host);
 /* device f64 sqrt / divide / rtamd-ln-1, element-wise: op 0 = sqrt(a), 1 = a/b, 2 = det_ln(a) */
 int rt_debug_math_device(int op, size_t n, const double* a_host, const double* b_host, double* out_host);
-/* closest hit of explicit world-space rays through device traversal `kernel` (1 or 2): rays n*6 (orig,dir);
+/* closest hit of explicit world-space rays through device traversal `kernel` (1, 2, or 3 = kernel 2's LDS node table "NodeW" with
+ * its own box test, which pt_kernel uses when the scene is LDS-resident): rays n*6 (orig,dir);
  * out n*12 = {hit, t, p[3], normal[3], front_face, u, v, leaf index in the reference-order program} */
 int rt_debug_hit_device(const rt_scene* s, int kernel, size_t n, const double* rays_host, double t_min, double t_max, double* out_host);
 

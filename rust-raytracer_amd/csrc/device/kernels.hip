@@ -2378,10 +2378,29 @@ __global__ void math_kernel(int op, size_t n, const double* a, const double* b, 
 __global__ void hit_kernel(FlatView sv, int accel, size_t n, const double* rays, double t_min, double t_max, double* out, int* err) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
     Acc A = make_acc(sv.base, sv.base, sv);
+    uint32_t stack_at = 0;
+    if (accel == 3) {  // the NodeW table of pt_kernel's LDS variants (box32w), expanded here as that kernel expands it; tables stay global
+        for (uint32_t k = threadIdx.x; k < sv.n_nodes2; k += blockDim.x) {
+            const uint4* nd = (const uint4*)(sv.base + sv.off_n2) + (size_t)k * NODE2_F4;
+            const uint4 a = nd[0], b = nd[1], c = nd[2], d4 = nd[3];
+            const uint32_t c0 = wide_ref(d4.x), c1 = wide_ref(d4.y);
+            char* w = smem + wide_ref(k);
+            const uint4 lo0 = make_uint4(a.x, a.y, a.z, a.w), lo1 = make_uint4(b.x, b.y, c0, c1);
+            const uint4 hi0 = make_uint4(b.z, b.w, c.x, c.y), hi1 = make_uint4(c.z, c.w, c0, c1);
+            ((uint4*)w)[0] = lo0; ((uint4*)w)[1] = lo1;
+            ((uint4*)(w + NODEW_FAR))[0] = hi0; ((uint4*)(w + NODEW_FAR))[1] = hi1;
+            ((uint4*)(w + 2 * NODEW_FAR))[0] = lo0; ((uint4*)(w + 2 * NODEW_FAR))[1] = lo1;
+        }
+        __syncthreads();
+        A.n2w_lds = (uint32_t)(uintptr_t)(AS_L char*)smem;
+        stack_at = nodew_bytes(sv.n_nodes2);
+    }
+    if (i >= n) return;
     D3 o = mk(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]), d = mk(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
-    Hit h = (accel == 2) ? traverse2<true, false, false>(A, (uint32_t*)smem + threadIdx.x, (int)blockDim.x, o, d, t_min, t_max)
+    uint32_t* stk = (uint32_t*)(smem + stack_at) + threadIdx.x;
+    Hit h = (accel == 3) ? traverse2<true, false, false, true>(A, stk, (int)blockDim.x, o, d, t_min, t_max)
+          : (accel == 2) ? traverse2<true, false, false>(A, stk, (int)blockDim.x, o, d, t_min, t_max)
                          : traverse<true>(A, o, d, t_min, t_max);
     double* q = out + 12 * i;
     for (int k = 0; k < 12; k++) q[k] = 0.;
@@ -3278,11 +3297,16 @@ void debug_hit_device(const rt_scene& s, int kernel, size_t n, const double* ray
     err.alloc(4);
     HIP_CHECK(hipMemset(err.p, 0, 4));
     HIP_CHECK(hipMemcpy(dr.p, rays, n * 48, hipMemcpyHostToDevice));
-    if (kernel == 2 && !view.accel_ok) throw RtError(RT_ERR_UNSUPPORTED, "no accel for this scene");
-    if (kernel == 2 && !(t_min >= 0.)) throw RtError(RT_ERR_UNSUPPORTED, "kernel 2 needs t_min >= 0 (box32)");
+    if ((kernel == 2 || kernel == 3) && !view.accel_ok) throw RtError(RT_ERR_UNSUPPORTED, "no accel for this scene");
+    if ((kernel == 2 || kernel == 3) && !(t_min >= 0.)) throw RtError(RT_ERR_UNSUPPORTED, "kernel 2 needs t_min >= 0 (box32)");
     if (view.kinds_mask & (1u << NK_MEDIUM_BEGIN))
         throw RtError(RT_ERR_UNSUPPORTED, "closest-hit queries on a scene with a ConstantMedium need the path's random stream");
-    const size_t smem = (kernel == 2) ? view.stack2 * 64 * sizeof(uint32_t) : 0;
+    size_t smem = (kernel == 2 || kernel == 3) ? view.stack2 * 64 * sizeof(uint32_t) : 0;
+    if (kernel == 3) {  // kernel 2's LDS node table (NodeW, box32w) in isolation: the table must fit beside the stacks
+        smem += ((size_t)(view.n_nodes2 + NODEW_CHUNK - 1) / NODEW_CHUNK) * 3 * NODEW_FAR;
+        if (smem > 160 * 1024) throw RtError(RT_ERR_UNSUPPORTED, "the NodeW table of this scene does not fit in LDS");
+        if (smem > 48 * 1024) HIP_CHECK(hipFuncSetAttribute((const void*)hit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    }
     hipLaunchKernelGGL(hit_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), smem, 0, view,
                        kernel, n, (const double*)dr.p, t_min, t_max, (double*)dout.p, (int*)err.p);
     HIP_CHECK(hipGetLastError());

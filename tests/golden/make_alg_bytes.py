@@ -18,7 +18,7 @@ for key in (sys.argv[1:] or list(configs.CONFIGS)):
     w, h = (300, 300) if key == "c4" else (W, H)
     sc = configs.oracle_scene(key)
     t0 = time.time()
-    _, cnt = sc.render(w, h, spp, max_depth=50, seed=1)
+    _, cnt = sc.render(w, h, spp, max_depth=50, seed=1, integrator=configs.INTEGRATOR.get(key, 0))
     dt = time.time() - t0
     n = cnt["n_samples"]
     per = {k: v / n for k, v in cnt.items()}

@@ -129,7 +129,7 @@ def test_cornell_box_bit_exact(kernel):
     assert img.max() > 0
 
 
-@pytest.mark.parametrize("kernel", [1, 2])
+@pytest.mark.parametrize("kernel", [1, 2, 3])
 def test_first_hit_records_match_oracle(kernel):
     """World::hit on explicit rays: t, p, normal, front_face identical to the oracle's HitRecord."""
     import oracle
@@ -144,7 +144,7 @@ def test_first_hit_records_match_oracle(kernel):
         rays[:, :3] = origin
         target = rng.random((n, 3)) * scale if scale > 100 else (rng.random((n, 3)) - 0.5) * scale
         rays[:, 3:] = target - rays[:, :3]
-        out = world.debug_hit(rays, t_min=1e-3, kernel=min(kernel, 2))   # kernel 3 = kernel 2's traversal, other scheduling
+        out = world.debug_hit(rays, t_min=1e-3, kernel=kernel)
         nhit = 0
         for i in range(n):
             h = ref.hit(rays[i, :3], rays[i, 3:], t_min=1e-3)
@@ -199,6 +199,7 @@ def test_kernels_agree_on_random_sphere_soups_with_ties():
     a = w.debug_hit(rays, kernel=1)
     b = w.debug_hit(rays, kernel=2)
     assert np.array_equal(a, b)
+    assert np.array_equal(a, w.debug_hit(rays, kernel=3))
     assert a[:, 0].sum() > n // 2
     cam = rtamd.Camera(((0, 0, -20), (0, 0, 0)), (0, 1, 0), 40, 1.0, 0.0, 20.0)
     i1, _ = w.render(cam, width=48, height=48, spp=4, kernel=1)
@@ -287,7 +288,7 @@ def test_accel_is_conservative_fuzz(scale):
         d[::13] *= 1e6                                                           # huge ones
         rays = np.concatenate([o, d], axis=1)
         a = w.debug_hit(rays, t_min=1e-3, kernel=1)
-        for k in (2,):
+        for k in (2, 3):   # 3: the LDS node table of pt_kernel (NodeW: planes selected by address, no widening factor)
             b = w.debug_hit(rays, t_min=1e-3, kernel=k)
             bad = np.argwhere((a != b).any(axis=1))
             assert len(bad) == 0, "trial %d: %d rays differ, first %s:\n k1 %s\n k%d %s" % (trial, len(bad), rays[bad[0, 0]], a[bad[0, 0]], k, b[bad[0, 0]])
@@ -307,7 +308,7 @@ def test_accel_is_conservative_fuzz(scale):
         far, tgt = np.array(far), np.array(tgt)
         rays = np.concatenate([far, tgt - far], axis=1)
         a = w.debug_hit(rays, t_min=1e-3, kernel=1)
-        for k in (2,):
+        for k in (2, 3):   # 3: the LDS node table of pt_kernel (NodeW: planes selected by address, no widening factor)
             b = w.debug_hit(rays, t_min=1e-3, kernel=k)
             bad = np.argwhere((a != b).any(axis=1))
             assert len(bad) == 0, "trial %d (grazing): %d rays differ, first %s:\n k1 %s\n k%d %s" % (trial, len(bad), rays[bad[0, 0]], a[bad[0, 0]], k, b[bad[0, 0]])

@@ -12,17 +12,18 @@ import bench
 
 scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
 rows = []
-for key in ("scene_10", "scene_500_c2", "scene_500", "cornell", "c4"):
+for key in ("scene_10", "scene_500_c2", "scene_500", "cornell", "cornell_mix", "c4"):
     label, W, H, spp_cfg, _ = configs.CONFIGS[key]
     spp = max(1, int(spp_cfg * scale))
     world, cam = configs.product(key)
-    world.render(cam, width=W, height=H, spp=min(spp, 4), seed=1)  # warm-up (workspace, code load)
-    _, st = world.render(cam, width=W, height=H, spp=spp, seed=1)
+    integ = configs.INTEGRATOR.get(key, 0)
+    world.render(cam, width=W, height=H, spp=min(spp, 4), seed=1, integrator=integ)  # warm-up (workspace, code load)
+    _, st = world.render(cam, width=W, height=H, spp=spp, seed=1, integrator=integ)
     acc = {"kernel_ms": st["kernel_ms"], "launches": st["launches"], "samples": st["samples"]}
     model = os.path.join(ROOT, "profiles", "pt_kernel_model.json") if key == "scene_500" else os.path.join(ROOT, "profiles", "r03", "model_%s.json" % key)
     roof, contract, hbm = bench.roofline_objects(acc, st["kernel_ms"] * 1e-3, model_path=model,
                                                  alg_path=os.path.join(ROOT, "tests", "golden", "alg_bytes_%s.json" % key))
-    row = dict(config=label, key=key, width=W, height=H, spp=spp, kernel=st["kernel_used"], lds=st["scene_in_lds"],
+    row = dict(config=label, key=key, width=W, height=H, spp=spp, integrator=integ, kernel=st["kernel_used"], lds=st["scene_in_lds"],
                msamples_per_s_kernel=st["samples"] / (st["kernel_ms"] * 1e-3) / 1e6, msamples_per_s_wall=st["samples"] / st["seconds"] / 1e6,
                wall_s=st["seconds"], roofline=roof, roofline_contract=contract, roofline_hbm=hbm)
     rows.append(row)

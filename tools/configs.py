@@ -15,9 +15,11 @@ CONFIGS = {
     "scene_10": ("C1 scene_10 400x225x100", 400, 225, 100, 16),
     "scene_500_c2": ("C2 scene_500 1200x800x500", 1200, 800, 500, 2),
     "scene_500": ("headline scene_500 1200x1200x1000", 1200, 1200, 1000, 2),
-    "cornell": ("C3 cornell 800x800x2000", 800, 800, 2000, 4),
+    "cornell": ("C3 cornell 800x800x2000 (BSDF sampling, integrator 0)", 800, 800, 2000, 4),
+    "cornell_mix": ("C3 cornell 800x800x2000 (light / cosine mixture pdf, integrator 1)", 800, 800, 2000, 4),
     "c4": ("C4 cornell + 102,400-triangle torus 1200x1200x1000", 1200, 1200, 1000, 1),
 }
+INTEGRATOR = {"cornell_mix": 1}  # rt_params.integrator of a configuration (default 0)
 CORNELL_CAM = ((278, 278, -800), (278, 278, 278), (0, 1, 0), 50, 1.0, 0.0, 10.0)
 
 
@@ -33,7 +35,7 @@ def product(key):
         return w, c.with_aspect(1.5)
     if key == "scene_500":
         return rtamd.load_scene_file(os.path.join(SCENES, "scene_500.json"))
-    if key == "cornell":
+    if key in ("cornell", "cornell_mix"):
         return rtamd.select_scene(os.path.join(SCENES, "cube.obj"), 1.0, 1)
     if key == "c4":
         P, N, I = shapes.torus(160, 320)
@@ -55,7 +57,7 @@ def oracle_scene(key):
         return oracle.load_scene_file(os.path.join(SCENES, "scene_500.json"), aspect=1.5)
     if key == "scene_500":
         return oracle.load_scene_file(os.path.join(SCENES, "scene_500.json"))
-    if key == "cornell":
+    if key in ("cornell", "cornell_mix"):
         return oracle.cornell_box_scene(os.path.join(SCENES, "cube.obj"), 1.0, 1)
     if key == "c4":
         P, N, I = shapes.torus(160, 320)

@@ -1,4 +1,5 @@
-"""One-off stress of the conservative f32 box test: closest hits of kernel 2 (SAH BVH2, f32 boxes) against kernel 1 (the
+"""One-off stress of the conservative f32 box tests: closest hits of kernel 2 (SAH BVH2, f32 boxes; both its global-memory node form, box32,
+and its LDS form, box32w) against kernel 1 (the
 reference-order walk with exact f64 boxes) on random scenes at several scales, with axis-parallel, tiny and huge direction
 components and origins inside / far outside the scene.  usage: python tools/fuzz_boxes.py [trials] [rays]"""
 import sys, os
@@ -23,8 +24,9 @@ for trial in range(trials):
         a1, b1 = a0 + rng.uniform(0.5, 6.0) * scale, b0 + rng.uniform(0.5, 6.0) * scale
         ctor = [w.XYRectangle, w.XZRectangle, w.YZRectangle][rng.integers(3)]
         items.append(ctor((float(a0), float(b0)), (float(a1), float(b1)), float((rng.random() - 0.5) * 20.0 * scale), m[rng.integers(3)]))
+    small = trial % 2 == 1   # every other trial: meshes small enough for the LDS node table
     for k in range(int(rng.integers(1, 4))):
-        P, N, I = shapes.torus(int(rng.integers(6, 30)), int(rng.integers(8, 40)))
+        P, N, I = shapes.torus(int(rng.integers(4, 9)), int(rng.integers(6, 12))) if small else shapes.torus(int(rng.integers(6, 30)), int(rng.integers(8, 40)))
         mesh = w.Mesh(P, N, I, m[rng.integers(3)], bvh_seed=int(rng.integers(1 << 30)))
         items.append(w.Transform(tuple(rng.uniform(-180, 180, 3)), tuple(rng.uniform(0.2, 3.0, 3) * scale), tuple((rng.random(3) - 0.5) * 16.0 * scale), mesh))
     w.new(items, bvh_seed=int(rng.integers(1 << 30)))
@@ -40,9 +42,13 @@ for trial in range(trials):
     rays = np.concatenate([o, d], axis=1)
     a = w.debug_hit(rays, t_min=1e-3, kernel=1)
     b = w.debug_hit(rays, t_min=1e-3, kernel=2)
-    bad = np.argwhere((a != b).any(axis=1))[:, 0]
+    try:
+        c = w.debug_hit(rays, t_min=1e-3, kernel=3)   # pt_kernel's LDS node table (NodeW, box32w: no widening factor since round 3)
+    except rtamd.RtError:
+        c = b                                          # (the table of this scene does not fit in LDS: pt_kernel would not use it either)
+    bad = np.argwhere((a != b).any(axis=1) | (a != c).any(axis=1))[:, 0]
     total_bad += len(bad)
-    print("trial %d scale %.3g items %d: hit share %.3f, %d of %d rays differ" % (trial, scale, len(items), a[:, 0].mean(), len(bad), n), flush=True)
+    print("trial %d scale %.3g items %d%s: hit share %.3f, %d of %d rays differ" % (trial, scale, len(items), "" if c is not b else " (no NodeW)", a[:, 0].mean(), len(bad), n), flush=True)
     for i in bad[:3]:
         print("   ray", rays[i], "k1", a[i], "k2", b[i])
 print("TOTAL differing rays:", total_bad)
