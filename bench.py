@@ -115,14 +115,27 @@ def launch_ranks(args, argv):
     if n_dev < args.gpus and not rehearse:
         raise SystemExit("bench.py: --gpus %d but only %d HIP device(s) visible; refusing to render on fewer GPUs than asked "
                          "(RTAMD_BENCH_REHEARSE=1 rehearses the N-rank path on one device over gloo)" % (args.gpus, n_dev))
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env["MASTER_ADDR"] = "127.0.0.1"
-    return subprocess.call(rank_command(args.gpus, argv, port), env=env)
+    rc = 1
+    for attempt in range(3):
+        # a free port found by bind / close can be taken by another process before the rendezvous binds it (parallel jobs on one
+        # box): the ranks' stderr is passed through and, when the launch died on "address already in use", another port is tried
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        p = subprocess.Popen(rank_command(args.gpus, argv, port), env=env, stderr=subprocess.PIPE, text=True)
+        tail = []
+        for line in p.stderr:
+            sys.stderr.write(line)
+            tail.append(line)
+            del tail[:-400]
+        rc = p.wait()
+        if rc == 0 or not any("ddress already in use" in ln or "EADDRINUSE" in ln for ln in tail):
+            break
+    return rc
 
 
 def kernel_source_sha16():
