@@ -63,3 +63,41 @@ def cornell_with_mesh(world_or_scene, positions, normals, indices, scale=120.0, 
 
 CORNELL_CAMERA = dict(look_from=(278.0, 278.0, -800.0), look_at=(278.0, 278.0, 278.0), vup=(0.0, 1.0, 0.0), vfov=50.0, aperture=0.0,
                       focus_dist=10.0)
+
+
+def final_scene_reduced(B, n_boxes=20, n_cluster=1000, seed=2):
+    """BASELINE config C5 ("motion-blur + Perlin-noise volumetric final scene", book 2) reduced to what the reference has code for:
+    no motion blur (ray.rs:3-6 has no time: the moving sphere stands still) and no Perlin noise (no noise texture: that sphere gets a
+    checker).  Everything else is the book's scene: a ground of n_boxes^2 boxes of random height, a rectangle light, glass and metal
+    spheres, a blue subsurface ball (a ConstantMedium inside a glass sphere), a thin global fog (a ConstantMedium in a sphere of
+    radius 5000), an image-textured sphere, and n_cluster small spheres in their own BVH under a rotate + translate Transform.
+    Works on both builders (rtamd.World and the oracle's Scene).  Returns the list of top-level hitables."""
+    rng = np.random.default_rng(seed)
+    ground = B.Lambertian(B.ConstantTexture((0.48, 0.83, 0.53)))
+    items = []
+    w = 100.0 * 20.0 / n_boxes
+    boxes = []
+    for i in range(n_boxes):
+        for j in range(n_boxes):
+            x0, z0 = -1000.0 + i * w, -1000.0 + j * w
+            boxes.append(B.Cube((x0, 0.0, z0), (x0 + w, float(rng.uniform(1.0, 101.0)), z0 + w), ground))
+    items.append(B.BVHNode_new(boxes, 11))
+    items.append(B.XZRectangle((123.0, 147.0), (423.0, 412.0), 554.0, B.DiffuseLight(B.ConstantTexture((7.0, 7.0, 7.0)))))
+    items.append(B.Sphere((400.0, 400.0, 200.0), 50.0, B.Lambertian(B.ConstantTexture((0.7, 0.3, 0.1)))))          # the "moving" sphere
+    items.append(B.Sphere((260.0, 150.0, 45.0), 50.0, B.Dielectric(1.5, B.ConstantTexture((1.0, 1.0, 1.0)))))
+    items.append(B.Sphere((0.0, 150.0, 145.0), 50.0, B.Metal(B.ConstantTexture((0.8, 0.8, 0.9)), 1.0)))
+    glass = B.Dielectric(1.5, B.ConstantTexture((1.0, 1.0, 1.0)))
+    items.append(B.Sphere((360.0, 150.0, 145.0), 70.0, glass))
+    items.append(B.ConstantMedium(0.2, B.Sphere((360.0, 150.0, 145.0), 70.0, glass), B.Isotropic(B.ConstantTexture((0.2, 0.4, 0.9)))))
+    items.append(B.ConstantMedium(0.0001, B.Sphere((0.0, 0.0, 0.0), 5000.0, glass), B.Isotropic(B.ConstantTexture((1.0, 1.0, 1.0)))))
+    yy, xx = np.mgrid[0:64, 0:128]
+    earth = np.stack([(40 + 150 * (np.sin(xx / 9.0) * np.cos(yy / 7.0) > 0.2)), 90 + (xx * 3 + yy * 5) % 120, 160 + (yy * 11) % 90], axis=-1).astype(np.uint8)
+    items.append(B.Sphere((400.0, 200.0, 400.0), 100.0, B.Lambertian(B.ImageTexture(earth))))
+    items.append(B.Sphere((220.0, 280.0, 300.0), 80.0, B.Lambertian(B.CheckerTexture(B.ConstantTexture((0.2, 0.2, 0.2)), B.ConstantTexture((0.9, 0.9, 0.9))))))  # (Perlin in the book)
+    white = B.Lambertian(B.ConstantTexture((0.73, 0.73, 0.73)))
+    cluster = [B.Sphere(tuple(float(c) for c in rng.uniform(0.0, 165.0, 3)), 10.0, white) for _ in range(n_cluster)]
+    items.append(B.Transform((0.0, 15.0, 0.0), (1.0, 1.0, 1.0), (-100.0, 270.0, 395.0), B.BVHNode_new(cluster, 12)))
+    return items
+
+
+FINAL_SCENE_CAMERA = ((478.0, 278.0, -600.0), (278.0, 278.0, 0.0), (0.0, 1.0, 0.0), 40.0, 1.0, 0.0, 10.0)

@@ -251,3 +251,29 @@ def test_a_medium_under_a_transform_keeps_the_reference_order_kernel_and_a_share
     med = w2.ConstantMedium(0.3, w2.Sphere((0.0, 1.0, 0.0), 1.0, white), fog)
     w2.set_root(w2.HitableList([w2.XZRectangle((-5.0, -5.0), (5.0, 5.0), 0.0, white), med, med]))
     assert w2.info()["accel_ok"] == 1          # visited twice (as BVHNode::new's one-object leaves do, Q14): two visits, each may draw
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kernel", [0, 1, 2])
+def test_final_scene_reduced_bit_exact(kernel):
+    """BASELINE config C5 reduced to what the reference has code for (rtamd.shapes.final_scene_reduced: no motion blur, no Perlin
+    noise; 400 boxes, two ConstantMedium volumes -- one inside a glass ball, one spanning the scene --, an image texture, a
+    1000-sphere cluster under a Transform): the accel kernel's MEDIA variant (the automatic choice) and the reference-order kernel
+    against the oracle."""
+    import oracle
+    import rtamd
+    from rtamd import shapes
+    w = rtamd.World()
+    w.new(shapes.final_scene_reduced(w), bvh_seed=3)
+    o = oracle.Scene()
+    o.World(shapes.final_scene_reduced(o), 3)
+    o.Camera(*shapes.FINAL_SCENE_CAMERA)
+    f, t, up, vfov, asp, ap, fd = shapes.FINAL_SCENE_CAMERA
+    cam = rtamd.Camera((f, t), up, vfov, asp, ap, fd)
+    info = w.info()
+    assert info["accel_ok"] == 1 and info["n_rects"] == 2401 and info["n_spheres"] == 1008
+    exp, _ = o.render(80, 80, 6, seed=4)
+    img, st = w.render(cam, width=80, height=80, spp=6, seed=4, kernel=kernel)
+    assert st["kernel_used"] == (2 if kernel == 0 else kernel)
+    assert np.array_equal(img, exp), int((img != exp).any(axis=2).sum())
+    assert exp.max() > 0

@@ -12,9 +12,11 @@ import bench
 
 scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
 rows = []
-for key in ("scene_10", "scene_500_c2", "scene_500", "cornell", "cornell_mix", "c4"):
+for key in ("scene_10", "scene_500_c2", "scene_500", "cornell", "cornell_mix", "c4", "c5r"):
     label, W, H, spp_cfg, _ = configs.CONFIGS[key]
     spp = max(1, int(spp_cfg * scale))
+    if key == "c5r":
+        spp = max(1, spp // 8)  # 1600x1600x4000 = 10.2 G samples is the 8-GPU configuration: one GPU measures 500 spp of it
     world, cam = configs.product(key)
     integ = configs.INTEGRATOR.get(key, 0)
     world.render(cam, width=W, height=H, spp=min(spp, 4), seed=1, integrator=integ)  # warm-up (workspace, code load)

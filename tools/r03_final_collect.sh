@@ -3,7 +3,7 @@
 cd "$(dirname "$0")/.."
 cp gpurun_out/r03_pmc_final/pt_kernel_model.json profiles/pt_kernel_model.json
 cp gpurun_out/r03_pmc_final/pmc_summary_headline.csv profiles/r03/pmc_summary_headline.csv
-for c in scene_10 scene_500_c2 cornell cornell_mix c4; do
+for c in scene_10 scene_500_c2 cornell cornell_mix c4 c5r; do
   cp gpurun_out/r03_cfgpmc_$c/model_$c.json profiles/r03/model_$c.json
   cp gpurun_out/r03_cfgpmc_$c/pmc_summary_$c.csv profiles/r03/pmc_summary_$c.csv
 done
