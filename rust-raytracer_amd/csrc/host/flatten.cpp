@@ -472,6 +472,21 @@ void flatten(rt_scene& s) {
                 mn[a] = std::fmin((double)lo[a][0], (double)lo[a][1]);
                 mx[a] = std::fmax((double)hi[a][0], (double)hi[a][1]);
             }
+            // A flat instance (a single triangle, a planar mesh) has an extent of twice the pad along one axis: its grid scale would be
+            // astronomical and the ray's grid coordinates (origin bound x scale) would leave the range box32 is proven for (2^35).  A
+            // thin axis is therefore widened around its centre until  (origin bound) * QGRID_MAX / extent <= 2^33  -- the boxes of
+            // that axis are then only rounded outward onto a coarser grid: still conservative.
+            {
+                double mab = 0.;
+                for (int a = 0; a < 3; a++) mab = std::fmax(mab, std::fmax(std::fabs(mn[a]), std::fabs(mx[a])));
+                const double emin = QGRID_MAX * (inst_oo[i] + mab) / 8589934592.;
+                for (int a = 0; a < 3; a++)
+                    if (mx[a] - mn[a] < emin) {
+                        const double c = 0.5 * (mn[a] + mx[a]);
+                        mn[a] = c - 0.5 * emin;
+                        mx[a] = c + 0.5 * emin;
+                    }
+            }
             // grid: g(x) = (x - mn) * k + shift, shift = P + 1, (mx - mn) * k = QGRID_MAX - 2 P - 2
             double k0 = 0., mabs = 0.;
             for (int a = 0; a < 3; a++) {

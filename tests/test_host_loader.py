@@ -278,3 +278,28 @@ def test_host_graph_entry_points_for_stored_fields_match_the_constructors():
         wa2 = rtamd.World()
         wa2.Transform_from_matrix(np.zeros((4, 4)), wa2.Sphere((0, 0, 0), 1, wa2.Lambertian(wa2.ConstantTexture((1, 1, 1)))))
     assert e.value.code == -4
+
+
+def test_small_bvhs_have_no_empty_children_and_do_not_disable_the_compact_instance_data():
+    """Round-2 advice: a BVH whose items all fit one leaf used to get an inner root with an "empty" second child (lo = +inf,
+    hi = -inf), which the slab test of the kernels always passes and which the 16-bit quantisation of kernel 5's NodeQ cannot
+    represent -- one tiny instance switched the compact data (and with it kernels 5 / 6) off for the whole scene.  Now the root
+    of a BVH with >= 2 items always splits into two real children and a single item gets a zero-size second box."""
+    import rtamd
+    from rtamd import shapes
+    w = rtamd.World()
+    white = w.Lambertian(w.ConstantTexture((0.7, 0.7, 0.7)))
+    P, N, I = shapes.torus(20, 40)                       # 1 600 triangles: a large instance
+    big = w.Transform((0.0, 0.0, 0.0), (50.0, 50.0, 50.0), (278.0, 200.0, 278.0), w.Mesh(P, N, I, white, bvh_seed=1))
+    tri = w.Mesh(np.array([[0.0, 0.0, 0.0], [1.0, 0.0, 0.0], [0.0, 1.0, 0.0]]), np.array([[0.0, 0.0, 1.0]] * 3), np.array([[0, 1, 2]], dtype=np.uint32), white)
+    one = w.Transform((0.0, 10.0, 0.0), (30.0, 30.0, 30.0), (100.0, 100.0, 100.0), tri)      # a ONE-triangle instance
+    P3, N3, I3 = shapes.torus(2, 2)                      # 8 triangles... (2 x 2 x 2): everything in at most two leaves
+    few = w.Transform((0.0, 0.0, 0.0), (20.0, 20.0, 20.0), (400.0, 100.0, 100.0), w.Mesh(P3, N3, I3, white, bvh_seed=2))
+    w.new([w.XZRectangle((0.0, 0.0), (555.0, 555.0), 0.0, white), big, one, few], bvh_seed=1)
+    info = w.info()
+    assert info["accel_ok"] == 1 and info["accel_instances"] == 3
+    assert info["accel_compact"] == 1                    # was 0 with the empty-child wrappers
+    w2 = rtamd.World()                                   # a world of one item: one inner node, two finite boxes
+    white = w2.Lambertian(w2.ConstantTexture((0.7, 0.7, 0.7)))
+    w2.new([w2.Sphere((0.0, 0.0, 0.0), 1.0, white)], bvh_seed=1)
+    assert w2.info()["accel_ok"] == 1 and w2.info()["accel_nodes"] == 1

@@ -777,3 +777,42 @@ def test_wavefront_kernel_64_instances_bit_exact():
     _assert_same(k6, k1, "64 instances, kernel 6 against the reference-order kernel")
     with pytest.raises(rtamd.RtError):
         w.render(cam, width=32, height=32, spp=1, seed=8, kernel=5)   # more than 32 instances
+
+
+def test_flat_and_single_triangle_instances_bit_exact():
+    """instances that are FLAT in object space (one triangle; a planar two-triangle quad) beside a large mesh instance: their grids
+    for the 16-bit node boxes have a thin axis (widened by flatten.cpp), their BVHs are a single leaf under an inner root with a
+    zero-size second box -- kernels 5 and 6 must still apply (accel_compact) and agree with kernels 1 / 2 and the oracle."""
+    import oracle
+    import rtamd
+    from rtamd import shapes
+    P, N, I = shapes.torus(24, 48)
+    tri = (np.array([[0.0, 0.0, 0.0], [1.0, 0.0, 0.0], [0.0, 1.0, 0.0]]), np.array([[0.0, 0.0, 1.0]] * 3), np.array([[0, 1, 2]], dtype=np.uint32))
+    quad = (np.array([[-1.0, 0.0, -1.0], [1.0, 0.0, -1.0], [1.0, 0.0, 1.0], [-1.0, 0.0, 1.0]]), np.array([[0.0, 1.0, 0.0]] * 4), np.array([[0, 1, 2], [0, 2, 3]], dtype=np.uint32))
+
+    def build(B, mesh):
+        white = B.Lambertian(B.ConstantTexture((0.73, 0.73, 0.73)))
+        mirror = B.Metal(B.ConstantTexture((0.9, 0.9, 0.9)), 0.0)
+        items = shapes.cornell_with_mesh(B, P, N, I, scale=90.0, translate=(300.0, 200.0, 300.0))
+        items.append(B.Transform((20.0, 30.0, 0.0), (160.0, 160.0, 160.0), (60.0, 120.0, 150.0), mesh(B, tri, mirror, 5)))
+        items.append(B.Transform((35.0, 0.0, 10.0), (90.0, 90.0, 90.0), (420.0, 330.0, 250.0), mesh(B, quad, white, 6)))
+        return items
+
+    w = rtamd.World()
+    w.new(build(w, lambda B, m, mat, sd: B.Mesh(m[0], m[1], m[2], mat, bvh_seed=sd)), bvh_seed=2)
+    o = oracle.Scene()
+    o.World(build(o, lambda B, m, mat, sd: B.Mesh(m[0], m[1], m[2], mat, sd)), 2)
+    o.Camera((278, 278, -800), (278, 278, 278), (0, 1, 0), 50, 1.0, 0.0, 10.0)
+    cam = _c4_scene()["cam"]
+    info = w.info()
+    assert info["accel_instances"] == 3 and info["accel_compact"] == 1
+    exp, _ = o.render(64, 64, 4, seed=7)
+    for k in (1, 2, 5, 6, 0):
+        img, st = w.render(cam, width=64, height=64, spp=4, seed=7, kernel=k)
+        _assert_same(img, exp, "flat instances, kernel %d" % k)
+        if k == 0:
+            assert st["kernel_used"] == 5
+    a, _ = w.render(cam, width=160, height=160, spp=8, seed=9, kernel=2)
+    for k in (5, 6):
+        b, _ = w.render(cam, width=160, height=160, spp=8, seed=9, kernel=k)
+        _assert_same(b, a, "flat instances at 160 x 160 x 8, kernel %d against kernel 2" % k)
