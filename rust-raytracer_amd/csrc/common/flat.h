@@ -77,6 +77,9 @@ struct TexDev {   // material.rs:48-84
 //   instance (8 B): {xform index, root ref of its object-space BVH}
 // ---------------------------------------------------------------------------
 static const uint32_t NK_INSTANCE = 8;
+// An instance that has no compact copy (anything but f32-vertex triangles): kernels 5 / 6 enter it in the lane, as kernel 2 enters
+// every instance, instead of deferring it; only accel items carry this kind.
+static const uint32_t NK_INSTANCE_INLINE = 12;
 #ifndef RT_NODE2_PAD
 #define RT_NODE2_PAD 2
 #endif
@@ -120,7 +123,8 @@ struct FlatView {  // by-value kernel argument
     uint32_t n_inst2;            // instances (object-space BVHs under a Transform)
     uint32_t max_inst_nodes2;    // Node2 count of the largest instance BVH
     uint32_t inst_depth2;        // depth of the deepest instance BVH (stack entries a suspended object-space walk can hold)
-    uint32_t n_world_items2;     // items2[0 .. n_world_items2) are the world-space BVH's (its leaves are laid out first)
+    uint32_t n_world_items2;     // items2[0 .. n_world_items2) are the world-space BVH's and the INLINE instances' (their leaves are laid out first)
+    uint32_t stack2_inline;      // stack entries a lane needs for the world-space walk including the inline instances
     // kernel 5's compact copies of the object-space data (see "Compact instance data" below); coop_data_ok = 0: not available
     uint32_t coop_data_ok;
     uint32_t off_n2q;            // NodeQ per Node2 index (object-space nodes only; world-space entries are unused)

@@ -634,9 +634,9 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
                     } else if (kind == NK_TRI) {
                         double b1, b2;
                         got = tri_hit(A.tripre2 + 5 * (first + i), o, d, t_min, h.t, t, b1, b2);
-                    } else if (DEFER) {  // NK_INSTANCE, deferred (at most 32 / 64 instances, checked on the host)
+                    } else if (DEFER && kind == NK_INSTANCE) {  // deferred (at most 32 / 64 instances, checked on the host)
                         *pend |= (PEND)1 << pl;
-                    } else {  // NK_INSTANCE: descend into its object-space BVH after the remaining items
+                    } else {  // NK_INSTANCE (or NK_INSTANCE_INLINE: an instance kernels 5 / 6 cannot defer): descend into its object-space BVH after the remaining items
                         enter = pl;
                     }
                 }
@@ -649,7 +649,7 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
                     r.best = ray32_best(t);
                 }
             }
-            if (GENERAL && !DEFER && enter != REF_DONE) {  // Transform::hit, transform.rs:153-156
+            if (GENERAL && enter != REF_DONE) {  // Transform::hit, transform.rs:153-156
                 uint2 in = A.inst2[enter];
                 const double* Minv = A.xforms + 32 * in.x;
                 o = xf_point(Minv, wo);
@@ -2628,14 +2628,15 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
     const bool accel2_usable = view.accel_ok && camera_ok && stack2_bytes <= lds_max;  // per-lane stacks live in LDS
     const bool media = (view.kinds_mask & (1u << NK_MEDIUM_BEGIN)) != 0;               // kernel 1, or kernel 2's MEDIA variant (traverse2_media)
     // kernel 5 = kernel 2's BVH with the cooperative instance service (pt_kernel_coop): for scenes with LARGE mesh instances
-    const uint32_t stack5 = std::max(view.world_depth2, view.inst_depth2) + 2u;  // the two walks of kernel 5 never share a stack
+    // the two walks of kernel 5 never share a stack; the world-space walk includes the instances it enters in the lane (NK_INSTANCE_INLINE)
+    const uint32_t stack5 = std::max(std::max(view.world_depth2, view.inst_depth2) + 2u, view.stack2_inline);
     const size_t stack5_bytes = (size_t)stack5 * PT_BLOCK * sizeof(uint32_t);
     const size_t coop_world = coop_world_bytes(view);  // world-level tables, always in LDS for this kernel
     const size_t coop_lds = (size_t)3 * COOP_RING * sizeof(uint16_t) + 8 * sizeof(uint32_t) + ((sizeof(CoopArgs) + 15) & ~size_t(15)) + coop_world;  // + three rings of pool-slot ids, counters, argument block
     const bool coop_usable = accel2_usable && general && !media && view.coop_data_ok != 0 && view.n_inst2 >= 1 && view.n_inst2 <= (uint32_t)COOP_MAX_INST &&
                              view.inst_depth2 <= (uint32_t)COOP_STACK_MAX && coop_world <= 16384 && stack5_bytes + coop_lds <= lds_max && plan.max_depth < (1 << 24);
     // kernel 6 = the same instance service across the whole GPU and across launches (wavefront.inc)
-    const uint32_t stack6 = std::max<uint32_t>(view.world_depth2 + 2u, (uint32_t)WF_ENTRY_STACK + 1u);
+    const uint32_t stack6 = std::max<uint32_t>(std::max(view.world_depth2 + 2u, view.stack2_inline), (uint32_t)WF_ENTRY_STACK + 1u);
     const uint32_t n_entry6 = std::min<uint32_t>((uint32_t)COOP_ENTRY_NODES, view.n_nodes2);
     const size_t wf_lds_pt = coop_world + (size_t)std::min<uint32_t>(128u, view.world_top2) * sizeof(Node2) + (size_t)n_entry6 * sizeof(NodeQ) +
                              (size_t)stack6 * PT_BLOCK * sizeof(uint32_t) + ((size_t)WF_BOOK_WORDS + CFG_WORDS + 8) * sizeof(uint32_t);
@@ -2653,9 +2654,9 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
     if (kernel == 0)
         kernel = accel2_usable ? ((coop_usable && view.max_inst_nodes2 >= 64u) ? 5 : (wf_usable && !coop_usable && view.max_inst_nodes2 >= 64u) ? 6 : 2) : 1;
     if (kernel == 5 && !coop_usable)
-        throw RtError(RT_ERR_UNSUPPORTED, "kernel 5 (cooperative instance service) needs a usable accel and 1..32 instances that hold only triangles with f32 vertices (OBJ meshes), of BVH depth <= 40");
+        throw RtError(RT_ERR_UNSUPPORTED, "kernel 5 (cooperative instance service) needs a usable accel, 1..32 instances of which at least one holds only triangles with f32 vertices (an OBJ mesh), of BVH depth <= 40");
     if (kernel == 6 && !wf_usable)
-        throw RtError(RT_ERR_UNSUPPORTED, "kernel 6 (wavefront instance service) needs a usable accel and 1..64 instances that hold only triangles with f32 vertices (OBJ meshes)");
+        throw RtError(RT_ERR_UNSUPPORTED, "kernel 6 (wavefront instance service) needs a usable accel and 1..64 instances of which at least one holds only triangles with f32 vertices (an OBJ mesh)");
     if ((kernel == 2 || kernel == 5) && !accel2_usable)
         throw RtError(RT_ERR_UNSUPPORTED, "kernel 2 requested but no usable accel for this scene/camera (unbounded item, depth overflow, stacks "
                                           "larger than LDS, negative t_min, or camera farther than 64x the scene extent); use kernel 0/1");

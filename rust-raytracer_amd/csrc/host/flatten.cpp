@@ -304,7 +304,8 @@ void flatten(rt_scene& s) {
     // ---- accel (kernel 2) ----
     AccelBuild ab;
     ab.ok = b.accel_ok;
-    uint32_t root2 = REF_DONE, max_inst_nodes = 0, inst_depth = 0, n_world_items = 0, world_depth = 0;
+    uint32_t root2 = REF_DONE, max_inst_nodes = 0, inst_depth = 0, n_world_items = 0, world_depth = 0, stack_inline = 0;
+    std::vector<char> compact_cand;  // per instance: only triangles with f32 vertices (kernels 5 / 6 can defer it)
     std::vector<double> inst_oo;  // per instance: bound of |object-space ray origin|
     double origin_limit = 0.;
     // An instance's item in the enclosing space carries the Transform's own bounding box (the box of the 8 transformed corners
@@ -357,9 +358,14 @@ void flatten(rt_scene& s) {
             if (!(origin_limit < 68719476736.)) ab.ok = false;  // 2^36
             root2 = accel_build_bvh(ab, b.actx[0].items, pad_w, 0);
             const int depth_tlas = ab.max_depth;
-            n_world_items = (uint32_t)(ab.items.size() / 2);
             world_depth = (uint32_t)depth_tlas;
             ab.inst.assign(2 * (b.actx.size() - 1), 0u);
+            // Which instances can kernels 5 / 6 defer?  Those that hold nothing but triangles with f32 vertices (flat.h "Compact
+            // instance data").  The others are entered in the lane (item kind NK_INSTANCE_INLINE); their BVHs are built FIRST so that
+            // their leaves sit right behind the world's in the item array: kernels 5 / 6 stage that prefix in LDS.
+            auto is_f32v = [](double x) { return (double)(float)x == x; };
+            compact_cand.assign(b.actx.size() - 1, 1);
+            inst_oo.assign(b.actx.size() - 1, 0.);
             for (size_t i = 1; ab.ok && i < b.actx.size(); i++) {
                 auto& c = b.actx[i];
                 // object-space origin bound: |M^-1 o| <= sum_b |Minv[a][b]| * |o|max + |Minv[a][3]|
@@ -370,13 +376,46 @@ void flatten(rt_scene& s) {
                 for (auto& it : c.items)  // hit points inside the instance also serve as origins of secondary rays (in world space only)
                     for (int a = 0; a < 3; a++) oo = std::fmax(oo, std::fmax(std::fabs(it.box.mn[a]), std::fabs(it.box.mx[a])));
                 if (!(oo < 68719476736.)) { ab.ok = false; break; }
-                inst_oo.push_back(oo);
-                const size_t nodes_before = ab.nodes.size();
-                uint32_t r = accel_build_bvh(ab, c.items, 3. * std::ldexp(oo, -22), depth_tlas + 1);
-                max_inst_nodes = std::max<uint32_t>(max_inst_nodes, (uint32_t)(ab.nodes.size() - nodes_before));
-                inst_depth = (uint32_t)std::max(1, ab.max_depth - depth_tlas + 1);  // bound for every instance built so far
-                ab.inst[2 * (i - 1)] = c.xform;
-                ab.inst[2 * (i - 1) + 1] = r;
+                inst_oo[i - 1] = oo;
+                for (auto& it : c.items) {
+                    if ((it.kp & NK_MASK) != NK_TRI) { compact_cand[i - 1] = 0; break; }
+                    const uint32_t t = it.kp >> NK_BITS;
+                    for (int c3 = 0; c3 < 3 && compact_cand[i - 1]; c3++)
+                        for (int a = 0; a < 3; a++)
+                            if (!is_f32v(b.vpos[3 * (size_t)b.tris[4 * (size_t)t + c3] + a])) compact_cand[i - 1] = 0;
+                    if (!compact_cand[i - 1]) break;
+                }
+                if (!compact_cand[i - 1]) {
+                    const uint32_t want = NK_INSTANCE | ((uint32_t)(i - 1) << NK_BITS);
+                    for (auto& it : b.actx[0].items)
+                        if (it.kp == want) it.kp = NK_INSTANCE_INLINE | ((uint32_t)(i - 1) << NK_BITS);
+                }
+            }
+            // (the world BVH was built above with the items' kinds as they were: its leaf items are patched below, after the build)
+            for (int pass = 0; pass < 2; pass++) {
+                for (size_t i = 1; ab.ok && i < b.actx.size(); i++) {
+                    if ((compact_cand[i - 1] != 0) != (pass == 1)) continue;  // pass 0: inline instances, pass 1: deferrable ones
+                    auto& c = b.actx[i];
+                    const size_t nodes_before = ab.nodes.size();
+                    const int depth_before = ab.max_depth;
+                    ab.max_depth = depth_tlas + 1;
+                    uint32_t r = accel_build_bvh(ab, c.items, 3. * std::ldexp(inst_oo[i - 1], -22), depth_tlas + 1);
+                    if (pass == 1) {
+                        max_inst_nodes = std::max<uint32_t>(max_inst_nodes, (uint32_t)(ab.nodes.size() - nodes_before));
+                        inst_depth = std::max<uint32_t>(inst_depth, (uint32_t)std::max(1, ab.max_depth - depth_tlas + 1));
+                    }
+                    ab.max_depth = std::max(ab.max_depth, depth_before);
+                    ab.inst[2 * (i - 1)] = c.xform;
+                    ab.inst[2 * (i - 1) + 1] = r;
+                }
+                if (pass == 0) {
+                    n_world_items = (uint32_t)(ab.items.size() / 2);
+                    stack_inline = (uint32_t)(ab.max_depth + 2);
+                }
+            }
+            for (size_t j = 0; j < ab.items.size() / 2; j++) {  // the world leaves' instance items, as classified
+                const uint32_t kp = ab.items[2 * j];
+                if ((kp & NK_MASK) == NK_INSTANCE && !compact_cand[kp >> NK_BITS]) ab.items[2 * j] = NK_INSTANCE_INLINE | (kp & ~NK_MASK);
             }
         }
     } else {
@@ -443,6 +482,11 @@ void flatten(rt_scene& s) {
     std::vector<Tri32> tri32;
     std::vector<QGrid> qgrid;
     bool coop_data = ab.ok && !ab.inst.empty();
+    {
+        bool any = false;
+        for (char c : compact_cand) any = any || c != 0;
+        coop_data = coop_data && any;
+    }
     uint32_t world_top = 0;
     if (ab.ok) {
         // world-space nodes after the depth sort: new_of of the first n_world_nodes old indices -- recomputed from the roots
@@ -462,6 +506,7 @@ void flatten(rt_scene& s) {
         qgrid.assign(ab.inst.size() / 2, QGrid{});
         auto is_f32 = [](double x) { return (double)(float)x == x; };
         for (size_t i = 0; coop_data && i < ab.inst.size() / 2; i++) {
+            if (!compact_cand[i]) continue;  // an inline instance: no compact copy
             const uint32_t root = ab.inst[2 * i + 1];
             if ((root >> REF_TAG_SHIFT) != 0u) { coop_data = false; break; }
             const Node2& rn = ab.nodes[root];
@@ -602,6 +647,7 @@ void flatten(rt_scene& s) {
     v.max_inst_nodes2 = max_inst_nodes;
     v.inst_depth2 = inst_depth;
     v.n_world_items2 = n_world_items;
+    v.stack2_inline = stack_inline;
     v.coop_data_ok = coop_data ? 1u : 0u;
     v.world_top2 = world_top;
     v.world_depth2 = world_depth;

@@ -816,3 +816,45 @@ def test_flat_and_single_triangle_instances_bit_exact():
     for k in (5, 6):
         b, _ = w.render(cam, width=160, height=160, spp=8, seed=9, kernel=k)
         _assert_same(b, a, "flat instances at 160 x 160 x 8, kernel %d against kernel 2" % k)
+
+
+def test_mixed_instances_keep_the_instance_service():
+    """a scene with a LARGE triangle-mesh instance AND instances kernels 5 / 6 cannot defer (a Cube -- six rectangles -- and a BVH
+    of spheres under Transforms; a mesh whose vertices are not f32 values): the service still applies to the mesh (round 2: one such
+    instance switched it off for the whole scene), the others are entered in the lane as kernel 2 enters every instance."""
+    import oracle
+    import rtamd
+    from rtamd import shapes
+    P, N, I = shapes.torus(40, 80)
+    Pq, Nq, Iq = shapes.torus(5, 7)
+    Pq = Pq * (1.0 + 2.0 ** -40)            # not representable in f32
+    rng = np.random.default_rng(3)
+    centres = rng.uniform(-1.0, 1.0, size=(40, 3))
+
+    def build(B, mesh):
+        white = B.Lambertian(B.ConstantTexture((0.73, 0.73, 0.73)))
+        glass = B.Dielectric(1.5, B.ConstantTexture((1.0, 1.0, 1.0)))
+        items = shapes.cornell_with_mesh(B, P, N, I, scale=100.0, translate=(300.0, 220.0, 300.0))
+        items.append(B.Transform((0.0, 25.0, 0.0), (1.0, 2.0, 1.0), (90.0, 0.0, 330.0), B.Cube((0.0, 0.0, 0.0), (110.0, 110.0, 110.0), white)))
+        items.append(B.Transform((10.0, 40.0, 0.0), (60.0, 60.0, 60.0), (420.0, 400.0, 200.0), B.BVHNode_new([B.Sphere(tuple(c), 0.18, glass if k % 3 == 0 else white) for k, c in enumerate(centres)], 4)))
+        items.append(B.Transform((0.0, 0.0, 30.0), (45.0, 45.0, 45.0), (120.0, 420.0, 250.0), mesh(B, (Pq, Nq, Iq), white, 9)))
+        return items
+
+    w = rtamd.World()
+    w.new(build(w, lambda B, m, mat, sd: B.Mesh(m[0], m[1], m[2], mat, bvh_seed=sd)), bvh_seed=2)
+    o = oracle.Scene()
+    o.World(build(o, lambda B, m, mat, sd: B.Mesh(m[0], m[1], m[2], mat, sd)), 2)
+    o.Camera((278, 278, -800), (278, 278, 278), (0, 1, 0), 50, 1.0, 0.0, 10.0)
+    cam = _c4_scene()["cam"]
+    info = w.info()
+    assert info["accel_instances"] == 4 and info["accel_compact"] == 1
+    exp, _ = o.render(72, 72, 4, seed=12)
+    for k in (1, 2, 5, 6, 0):
+        img, st = w.render(cam, width=72, height=72, spp=4, seed=12, kernel=k)
+        _assert_same(img, exp, "mixed instances, kernel %d" % k)
+        if k == 0:
+            assert st["kernel_used"] == 5
+    a, _ = w.render(cam, width=200, height=200, spp=8, seed=5, kernel=2)
+    for k in (5, 6):
+        b, _ = w.render(cam, width=200, height=200, spp=8, seed=5, kernel=k)
+        _assert_same(b, a, "mixed instances at 200 x 200 x 8, kernel %d against kernel 2" % k)
