@@ -125,6 +125,7 @@ struct FlatView {  // by-value kernel argument
     uint32_t inst_depth2;        // depth of the deepest instance BVH (stack entries a suspended object-space walk can hold)
     uint32_t n_world_items2;     // items2[0 .. n_world_items2) are the world-space BVH's and the INLINE instances' (their leaves are laid out first)
     uint32_t stack2_inline;      // stack entries a lane needs for the world-space walk including the inline instances
+    uint32_t n_inline2;          // instances kernels 5 / 6 enter in the lane (NK_INSTANCE_INLINE); 0: their MIXED variants are not needed
     // kernel 5's compact copies of the object-space data (see "Compact instance data" below); coop_data_ok = 0: not available
     uint32_t coop_data_ok;
     uint32_t off_n2q;            // NodeQ per Node2 index (object-space nodes only; world-space entries are unused)

@@ -526,7 +526,9 @@ DEV bool box32(float lox, float loy, float loz, float hix, float hiy, float hiz,
 // WIDE: the node table is the LDS-resident NodeW form (A.n2w_lds; implies !TOP).
 // LIMIT: only items whose reference-order index is below order_limit take part (traverse2_media: "the closest surface the
 // reference has seen before it visits this medium").
-template <bool GENERAL, bool DEFER = false, bool TOP = true, bool WIDE = false, class PEND = uint32_t, bool LIMIT = false>
+// ENTER: instance items may be entered in the lane (always, unless DEFER; with DEFER only in the MIXED variants of kernels 5 / 6,
+// for the NK_INSTANCE_INLINE items of scenes that have any: compiling the enter path into their world-space walk costs C4 6 %).
+template <bool GENERAL, bool DEFER = false, bool TOP = true, bool WIDE = false, class PEND = uint32_t, bool LIMIT = false, bool ENTER = !DEFER>
 DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, double t_min, double t_max, PEND* pend = nullptr, uint32_t order_limit = 0xFFFFFFFFu) {
     D3 o = wo, d = wd;
     double a = sqlen(d);
@@ -636,7 +638,7 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
                         got = tri_hit(A.tripre2 + 5 * (first + i), o, d, t_min, h.t, t, b1, b2);
                     } else if (DEFER && kind == NK_INSTANCE) {  // deferred (at most 32 / 64 instances, checked on the host)
                         *pend |= (PEND)1 << pl;
-                    } else {  // NK_INSTANCE (or NK_INSTANCE_INLINE: an instance kernels 5 / 6 cannot defer): descend into its object-space BVH after the remaining items
+                    } else if (ENTER) {  // NK_INSTANCE (or NK_INSTANCE_INLINE: an instance kernels 5 / 6 cannot defer): descend into its object-space BVH after the remaining items
                         enter = pl;
                     }
                 }
@@ -649,7 +651,7 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
                     r.best = ray32_best(t);
                 }
             }
-            if (GENERAL && enter != REF_DONE) {  // Transform::hit, transform.rs:153-156
+            if (GENERAL && ENTER && enter != REF_DONE) {  // Transform::hit, transform.rs:153-156
                 uint2 in = A.inst2[enter];
                 const double* Minv = A.xforms + 32 * in.x;
                 o = xf_point(Minv, wo);
@@ -1918,7 +1920,7 @@ __device__ __attribute__((noinline)) Hit coop_walk_inline(const CoopArgs* args, 
     return h;
 }
 
-template <int INTEG>
+template <int INTEG, bool MIXED = false>
 __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam, RenderK rk, double* __restrict__ ring, double* accum,
                                                            unsigned int* tickets, unsigned int* __restrict__ counter, int* __restrict__ err, uint64_t* coop) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -2086,7 +2088,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
         // ---- world-space walk of the lanes that start a segment, instances deferred ----
         if (__ballot(alive && !ready && pend == 0u) != 0ull) COOP_STAT(2, __ballot(alive && !ready && pend == 0u));
         if (alive && !ready && pend == 0u) {  // (pend != 0: a path between two deferred instances of one segment)
-            h = traverse2<true, true>(A, stk, stk_stride, o, d, rk.t_min, INFINITY, &pend);
+            h = traverse2<true, true, true, false, uint32_t, false, MIXED>(A, stk, stk_stride, o, d, rk.t_min, INFINITY, &pend);
             if (pend == 0u) ready = true;
         }
         COOP_TIME(1);
@@ -2679,7 +2681,8 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
     pt_fn fn = (kernel == 1) ? pick_pt_kernel<1>(lds, general, integ) : pick_pt_kernel<2>(lds, general, integ);
     pt_coop_fn fn_coop = nullptr;
     if (kernel == 5)
-        fn_coop = (integ == 1) ? pt_kernel_coop<1> : (integ == 2) ? pt_kernel_coop<2> : pt_kernel_coop<0>;
+        fn_coop = (view.n_inline2 != 0u) ? ((integ == 1) ? pt_kernel_coop<1, true> : (integ == 2) ? pt_kernel_coop<2, true> : pt_kernel_coop<0, true>)
+                                         : ((integ == 1) ? pt_kernel_coop<1> : (integ == 2) ? pt_kernel_coop<2> : pt_kernel_coop<0>);
     if (media)
         fn = (kernel == 2) ? (lds ? pt_kernel<true, true, 2, 0, true> : pt_kernel<false, true, 2, 0, true>)
                            : (lds ? pt_kernel<true, true, 1, 0, true> : pt_kernel<false, true, 1, 0, true>);
@@ -2833,7 +2836,8 @@ static void render_tiles_wf(const rt_scene& s, const FlatView& view, const Camer
     if (integ == 1 && view.n_lights == 0) throw RtError(RT_ERR_ARG, "integrator 1 (light importance sampling) needs rt_scene_set_lights");
     if (integ == 2 && !plan.sppm_est) throw RtError(RT_ERR_ARG, "integrator 2 (SPPM) is reached through rt_render_sppm");
     typedef void (*pt_wf_fn)(FlatView, CamK, RenderK, double*, double*, unsigned int*, unsigned int*, int*, WfArgs);
-    pt_wf_fn fn = (integ == 1) ? pt_kernel_wf<1> : (integ == 2) ? pt_kernel_wf<2> : pt_kernel_wf<0>;
+    pt_wf_fn fn = (view.n_inline2 != 0u) ? ((integ == 1) ? pt_kernel_wf<1, true> : (integ == 2) ? pt_kernel_wf<2, true> : pt_kernel_wf<0, true>)
+                                         : ((integ == 1) ? pt_kernel_wf<1> : (integ == 2) ? pt_kernel_wf<2> : pt_kernel_wf<0>);
     if (lds_pt > 48 * 1024) HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pt));
     int bpc = 0;
     HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)fn, PT_BLOCK, lds_pt));

@@ -648,6 +648,8 @@ void flatten(rt_scene& s) {
     v.inst_depth2 = inst_depth;
     v.n_world_items2 = n_world_items;
     v.stack2_inline = stack_inline;
+    v.n_inline2 = 0;
+    for (char c : compact_cand) v.n_inline2 += c ? 0u : 1u;
     v.coop_data_ok = coop_data ? 1u : 0u;
     v.world_top2 = world_top;
     v.world_depth2 = world_depth;
