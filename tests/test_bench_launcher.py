@@ -119,7 +119,8 @@ def test_forced_process_group_runs_the_rccl_exchange_at_world_1(how, tmp_path):
     one touches the GPU for it.  The stitched frame must equal the plain render bit for bit (camera.rs:77,108,115-123)."""
     import numpy as np
     out_npy = str(tmp_path / "frame.npy")
-    args = ["--gpus", "1", "--steps", "2", "--warmup", "1", "--width", "96", "--height", "72", "--spp", "8", "--cpu-spp", "0", "--frame-out", out_npy]
+    args = ["--gpus", "1", "--steps", "2", "--warmup", "1", "--width", "96", "--height", "72", "--spp", "8", "--cpu-spp", "2" if how == "flag" else "0",
+            "--frame-out", out_npy]
     env = {}
     if how == "flag":
         args.append("--force-pg")
@@ -140,5 +141,17 @@ def test_forced_process_group_runs_the_rccl_exchange_at_world_1(how, tmp_path):
     pg = out["process_group"]
     assert pg["backend"].startswith("nccl") and pg["world"] == 1 and pg["forced_at_world_1"] is True
     assert out["n_gpus"] == 1 and out["value"] > 0
+    # the bench contract: one JSON line with these keys
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "roofline_contract"):
+        assert k in out, k
+    assert out["steps"] == 2 and out["warmup"] == 1 and out["higher_is_better"] is True and out["vs_baseline"] is None and out["dtype"] == "f64"
+    assert "workload" in out["config"] and "model" not in out["config"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in out["roofline"], k
+    if how == "flag":
+        cb = out["cpu_baseline"]
+        assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb and "cpu_model" in cb and cb["reference_default"]["cores"] <= 8
+    assert len([ln for ln in r.stdout.splitlines() if ln.strip()]) == 1      # ONE line on stdout (RCCL's banner goes to stderr)
     got = np.load(out_npy)
     assert got.shape == (72, 96, 3) and np.array_equal(got, _plain_frame(96, 72, 8))
