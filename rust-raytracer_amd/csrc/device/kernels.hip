@@ -526,10 +526,24 @@ DEV bool box32(float lox, float loy, float loz, float hix, float hiy, float hiz,
 // WIDE: the node table is the LDS-resident NodeW form (A.n2w_lds; implies !TOP).
 // LIMIT: only items whose reference-order index is below order_limit take part (traverse2_media: "the closest surface the
 // reference has seen before it visits this medium").
+// TRACK (traverse2_media): beside the closest hit, the walk keeps for up to two media the smallest t among the items the reference
+// visits BEFORE the medium (program index below lim[j]) -- but only as far as the medium's exit (beyond it the value is of no use):
+// candidates are then taken up to  bound = max(best t, min(T[j], exit[j]))  instead of the best t, and the boxes are culled against
+// that.  The root a sphere test returns does not depend on how far the range reaches (it is the smallest admissible one), so the
+// closest hit is what the plain walk finds, and T[j] is what a walk restricted to those items would find (up to exit[j]).
+struct MediaTrack {
+    uint32_t lim[2];  // program index of the medium's BEGIN node; 0: slot unused
+    double exitt[2];  // the medium's exit t on this ray (rec2.t)
+    double T[2];      // out: min t of the items below lim[j] (+inf: none up to exit[j])
+};
+DEV double track_bound(const MediaTrack& K, double best) {
+    return fmax(best, fmax(K.lim[0] != 0u ? fmin(K.T[0], K.exitt[0]) : 0., K.lim[1] != 0u ? fmin(K.T[1], K.exitt[1]) : 0.));
+}
 // ENTER: instance items may be entered in the lane (always, unless DEFER; with DEFER only in the MIXED variants of kernels 5 / 6,
 // for the NK_INSTANCE_INLINE items of scenes that have any: compiling the enter path into their world-space walk costs C4 6 %).
-template <bool GENERAL, bool DEFER = false, bool TOP = true, bool WIDE = false, class PEND = uint32_t, bool LIMIT = false, bool ENTER = !DEFER>
-DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, double t_min, double t_max, PEND* pend = nullptr, uint32_t order_limit = 0xFFFFFFFFu) {
+template <bool GENERAL, bool DEFER = false, bool TOP = true, bool WIDE = false, class PEND = uint32_t, bool LIMIT = false, bool ENTER = !DEFER, bool TRACK = false>
+DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, double t_min, double t_max, PEND* pend = nullptr, uint32_t order_limit = 0xFFFFFFFFu,
+                  MediaTrack* track = nullptr) {
     D3 o = wo, d = wd;
     double a = sqlen(d);
     Hit h;
@@ -539,6 +553,7 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
     h.kp = 0;
     int cur_xf = -1;
     Ray32 r = make_ray32(o, d, t_min, t_max);
+    float best_all32 = r.best;  // TRACK: the best hit's own (outward-rounded) t, beside r.best = the track bound
     if (WIDE) ray32_wide_addr(r, A.n2w_lds);
     int sp = 0;  // stack offset in words (a multiple of stride): avoids an integer multiply per push/pop
     // WIDE: the stack pointer is the LDS byte address itself (one add per push / pop instead of shift-add + add)
@@ -588,16 +603,28 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
             }
             f32x4 q0, q1, q2;  // (lox0,lox1,loy0,loy1) (loz0,loz1,hix0,hix1) (hiy0,hiy1,hiz0,hiz1) (c0,c1,-,-)
             f32x2 q3;          // (only the two child refs of the fourth quad: an 8-byte read)
+            f32x2 q3m = {0.f, 0.f};  // LIMIT / TRACK: the smallest program index in either child's subtree (Node2.pad, accel.cpp)
             if (TOP && cur < A.n2_top_count) {  // the shallowest levels are cached in LDS when the scene lives in L2/HBM
                 const AS_L f32x4* p = A.n2_top + NODE2_F4 * cur;
                 q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = *(const AS_L f32x2*)(p + 3);
+                if (LIMIT || TRACK) q3m = ((const AS_L f32x2*)(p + 3))[1];
             } else {
                 const f32x4* p = (const f32x4*)A.n2 + NODE2_F4 * cur;
                 q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = *(const f32x2*)(p + 3);
+                if (LIMIT || TRACK) q3m = ((const f32x2*)(p + 3))[1];
             }
             float e0, e1;
             bool h0 = box32(q0.x, q0.z, q1.x, q1.z, q2.x, q2.z, r, e0);
             bool h1 = box32(q0.y, q0.w, q1.y, q1.w, q2.y, q2.w, r, e1);
+            if (LIMIT) {  // a subtree without an item below the limit holds nothing for this walk
+                h0 = h0 && __float_as_uint(q3m.x) < order_limit;
+                h1 = h1 && __float_as_uint(q3m.y) < order_limit;
+            }
+            if (TRACK) {  // ... and in a tracked walk such a subtree is only of interest as far as the best hit (r.best reaches to the track bound)
+                const uint32_t lim = max(track->lim[0], track->lim[1]);
+                h0 = h0 && (__float_as_uint(q3m.x) < lim || !(e0 > best_all32));
+                h1 = h1 && (__float_as_uint(q3m.y) < lim || !(e1 > best_all32));
+            }
             uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
             if (h0 && h1) {
                 bool swap = e1 < e0;
@@ -625,25 +652,39 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
                 uint32_t kind = it.x & NK_MASK, pl = it.x >> NK_BITS;
                 double t = 0.;
                 bool got = false;
+                const double t_far = TRACK ? track_bound(*track, h.t) : h.t;  // how far a candidate may lie
                 if (LIMIT && it.y >= order_limit) {
                     // visited by the reference after the medium in question (an instance's subtree is contiguous in the program and
                     // media are world-level, so an instance lies wholly before or wholly after it: its item's order decides)
                 } else if (kind == NK_SPHERE) {
-                    got = sphere_hit(A.spheres + 2 * pl, o, d, a, t_min, h.t, t);
+                    got = sphere_hit(A.spheres + 2 * pl, o, d, a, t_min, t_far, t);
                 } else if (GENERAL) {
                     if (kind == NK_RECT_YZ || kind == NK_RECT_XZ || kind == NK_RECT_XY) {
-                        got = rect_hit(A.rects + 3 * pl, (int)kind - (int)NK_RECT_YZ, o, d, t_min, h.t, t);
+                        got = rect_hit(A.rects + 3 * pl, (int)kind - (int)NK_RECT_YZ, o, d, t_min, t_far, t);
                     } else if (kind == NK_TRI) {
                         double b1, b2;
-                        got = tri_hit(A.tripre2 + 5 * (first + i), o, d, t_min, h.t, t, b1, b2);
+                        got = tri_hit(A.tripre2 + 5 * (first + i), o, d, t_min, t_far, t, b1, b2);
                     } else if (DEFER && kind == NK_INSTANCE) {  // deferred (at most 32 / 64 instances, checked on the host)
                         *pend |= (PEND)1 << pl;
                     } else if (ENTER) {  // NK_INSTANCE (or NK_INSTANCE_INLINE: an instance kernels 5 / 6 cannot defer): descend into its object-space BVH after the remaining items
                         enter = pl;
                     }
                 }
-                // accepted candidates satisfy t <= h.t; an exact tie goes to the later one in reference order
-                if (got && (t < h.t || (int)it.y > h.node || !(t == t))) {
+                if (TRACK) {
+                    if (got) {
+                        if (it.y < track->lim[0] && t < track->T[0]) track->T[0] = t;
+                        if (it.y < track->lim[1] && t < track->T[1]) track->T[1] = t;
+                        if (t < h.t || (t == h.t && (int)it.y > h.node) || !(t == t)) {  // (a candidate may lie beyond the best hit here)
+                            h.t = t;
+                            h.node = (int)it.y;
+                            h.xf = cur_xf;
+                            h.kp = it.x;
+                            best_all32 = ray32_best(t);
+                        }
+                        r.best = ray32_best(track_bound(*track, h.t));
+                    }
+                } else if (got && (t < h.t || (int)it.y > h.node || !(t == t))) {
+                    // accepted candidates satisfy t <= h.t; an exact tie goes to the later one in reference order
                     h.t = t;
                     h.node = (int)it.y;
                     h.xf = cur_xf;
@@ -658,7 +699,7 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
                 d = xf_dir(Minv, wd);
                 a = sqlen(d);
                 cur_xf = (int)in.x;
-                r = make_ray32(o, d, t_min, h.t);
+                r = make_ray32(o, d, t_min, TRACK ? track_bound(*track, h.t) : h.t);
                 if (WIDE) {
                     ray32_wide_addr(r, A.n2w_lds);
                     *(AS_L uint32_t*)(uintptr_t)spw = REF_RESTORE;
@@ -675,7 +716,7 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
             d = wd;
             a = sqlen(d);
             cur_xf = -1;
-            r = make_ray32(o, d, t_min, h.t);
+            r = make_ray32(o, d, t_min, TRACK ? track_bound(*track, h.t) : h.t);
             if (WIDE) ray32_wide_addr(r, A.n2w_lds);
         }
         if (WIDE) {
@@ -700,8 +741,9 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
 // what the reference has visited BEFORE the medium.  The accel visits things in another order, so the media are handled apart, in
 // the reference's order (A.media is in program order):
 //   S  = closest surface of all (one accel walk, the box tests merely cull);
-//   for each medium M:  S_M = closest surface among those the reference visits before M -- S itself when S comes before M in the
-//       program, otherwise a second accel walk restricted to items with a smaller index (LIMIT);
+//   for each medium M:  S_M = closest surface among those the reference visits before M -- for the first two media the ray crosses
+//       the accel walk itself keeps it (TRACK: min t over items with a smaller program index, as far as the medium's exit); for
+//       further ones S itself when S comes before M in the program, otherwise another accel walk restricted to those items (LIMIT);
 //       t_max = min(S_M.t, t of the latest medium hit accepted so far);   rec1 / rec2 = the two boundary queries, walked over the
 //       medium's own two copies of the boundary's subtree in the reference-order program (exact f64, any sign of t);
 //       then medium.rs:28-50 literally: clip, at most one draw, accept t = rec1.t + hit_distance / |d| (it is <= t_max).
@@ -712,28 +754,68 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
 // either way), up to rays that graze a reference box within f64 rounding (the measure-zero caveat of kernel 2).
 template <bool GENERAL, bool TOP, bool WIDE>
 DEV Hit traverse2_media(const Acc& A, uint32_t n_media, uint32_t* stk, const int stride, D3 o, D3 d, double t_min, Rng& rng) {
-    const Hit S = traverse2<GENERAL, false, TOP, WIDE>(A, stk, stride, o, d, t_min, INFINITY);
-    Hit best = S;          // running result
-    double t_med = INFINITY;  // t of the latest accepted medium hit
-    const double ray_length = sqrt(sqlen(d));
+    // 1. the boundary queries of the media (no random number is drawn here); the first two media the ray crosses are TRACKED by the
+    //    accel walk (MediaTrack), so that one walk yields the closest surface S and, for each of the two, the closest surface the
+    //    reference visits before it.  (A second, order-restricted walk per medium -- the first version -- cost more than the
+    //    rest of the segment: 451 instead of 935 Msamples/s without it on the reduced book-2 final scene, where every ray is inside a fog.)
+    MediaTrack K;
+    K.lim[0] = K.lim[1] = 0u;
+    K.exitt[0] = K.exitt[1] = 0.;
+    K.T[0] = K.T[1] = INFINITY;
+    uint32_t tk0 = 0xFFFFFFFFu, tk1 = 0xFFFFFFFFu, k_rest = n_media;  // the tracked media; from k_rest on: not examined yet
+    double ta0 = 0., tb0 = 0., ta1 = 0., tb1 = 0.;
     for (uint32_t k = 0; k < n_media; k++) {
         const MediumDev M = A.media[k];
-        // boundary queries first: most rays miss most media, and a miss needs nothing else (medium.rs:26-27)
         const Hit r1h = traverse<true, false>(A, o, d, -INFINITY, INFINITY, nullptr, M.n_begin + 1u, M.n_mid);
         if (r1h.node < 0) continue;
         const Hit r2h = traverse<true, false>(A, o, d, r1h.t + 0.0001, INFINITY, nullptr, M.n_mid + 1u, M.n_end);
         if (r2h.node < 0) continue;
-        double t_max = t_med;
-        if (S.node >= 0) {
-            if ((uint32_t)S.node < M.n_begin) {
-                t_max = fmin(t_max, S.t);
-            } else if (S.t < r2h.t) {  // (S comes after M; a surface before M is no closer than S: if even S lies beyond the exit nothing clips)
-                const Hit SM = traverse2<GENERAL, false, TOP, WIDE, uint32_t, true>(A, stk, stride, o, d, t_min, INFINITY, nullptr, M.n_begin);
-                if (SM.node >= 0) t_max = fmin(t_max, SM.t);
-            }
+        if (tk0 == 0xFFFFFFFFu) {
+            tk0 = k; ta0 = r1h.t; tb0 = r2h.t;
+            K.lim[0] = M.n_begin; K.exitt[0] = r2h.t;
+        } else {
+            tk1 = k; ta1 = r1h.t; tb1 = r2h.t;
+            K.lim[1] = M.n_begin; K.exitt[1] = r2h.t;
+            k_rest = k + 1u;
+            break;
         }
-        double r1 = fmax(r1h.t, t_min);
-        const double r2 = fmin(r2h.t, t_max);
+    }
+    // 2. the accel walk
+    const Hit S = (tk0 != 0xFFFFFFFFu) ? traverse2<GENERAL, false, TOP, WIDE, uint32_t, false, true, true>(A, stk, stride, o, d, t_min, INFINITY, nullptr, 0xFFFFFFFFu, &K)
+                                       : traverse2<GENERAL, false, TOP, WIDE>(A, stk, stride, o, d, t_min, INFINITY);
+    // 3. the media in the reference's order
+    Hit best = S;
+    double t_med = INFINITY;  // t of the latest accepted medium hit
+    const double ray_length = sqrt(sqlen(d));
+    for (uint32_t k = 0; k < n_media; k++) {
+        double t_a, t_b, t_max = t_med;
+        MediumDev M;
+        if (k == tk0 || k == tk1) {
+            M = A.media[k];
+            t_a = (k == tk0) ? ta0 : ta1;
+            t_b = (k == tk0) ? tb0 : tb1;
+            t_max = fmin(t_max, (k == tk0) ? K.T[0] : K.T[1]);
+        } else if (k >= k_rest) {  // a third, fourth ... crossed medium: its own queries, and a restricted walk where needed
+            M = A.media[k];
+            const Hit r1h = traverse<true, false>(A, o, d, -INFINITY, INFINITY, nullptr, M.n_begin + 1u, M.n_mid);
+            if (r1h.node < 0) continue;
+            const Hit r2h = traverse<true, false>(A, o, d, r1h.t + 0.0001, INFINITY, nullptr, M.n_mid + 1u, M.n_end);
+            if (r2h.node < 0) continue;
+            t_a = r1h.t;
+            t_b = r2h.t;
+            if (S.node >= 0) {
+                if ((uint32_t)S.node < M.n_begin) {
+                    t_max = fmin(t_max, S.t);
+                } else if (S.t < t_b) {  // (S comes after M; a surface before M is no closer than S: if even S lies beyond the exit nothing clips)
+                    const Hit SM = traverse2<GENERAL, false, TOP, WIDE, uint32_t, true>(A, stk, stride, o, d, t_min, INFINITY, nullptr, M.n_begin);
+                    if (SM.node >= 0) t_max = fmin(t_max, SM.t);
+                }
+            }
+        } else {
+            continue;  // examined in step 1: not crossed
+        }
+        double r1 = fmax(t_a, t_min);
+        const double r2 = fmin(t_b, t_max);
         if (r1 >= r2) continue;
         r1 = fmax(r1, 0.);
         const double distance_inside_boundary = (r2 - r1) * ray_length;

@@ -174,7 +174,31 @@ uint32_t build(Ctx& c, int begin, int end, int depth, bool force_split = false) 
 
 }  // namespace
 
+// Node2.pad[k] = the smallest reference-order index among the items of child k's subtree: lets a walk that only cares about items
+// below some index (the media logic of kernel 2: "what the reference has visited before this medium") skip whole subtrees.
+static uint32_t fill_min_order(AccelBuild& out, uint32_t ref) {
+    if ((ref >> REF_TAG_SHIFT) == 1u) {
+        const uint32_t first = ref & REF_LEAF_FIRST_MASK, cnt = ((ref >> REF_LEAF_COUNT_SHIFT) & 7u) + 1u;
+        uint32_t m = 0xFFFFFFFFu;
+        for (uint32_t i = 0; i < cnt; i++) m = std::min(m, out.items[2 * (size_t)(first + i) + 1]);
+        return m;
+    }
+    if ((ref >> REF_TAG_SHIFT) != 0u) return 0xFFFFFFFFu;
+    Node2& nd = out.nodes[ref];
+    const uint32_t c0 = nd.child[0], c1 = nd.child[1];
+    const uint32_t m0 = fill_min_order(out, c0), m1 = fill_min_order(out, c1);
+    out.nodes[ref].pad[0] = m0;
+    out.nodes[ref].pad[1] = m1;
+    return std::min(m0, m1);
+}
+
+static uint32_t accel_build_bvh_impl(AccelBuild& out, std::vector<AccelItem>& items, double pad, int depth0);
 uint32_t accel_build_bvh(AccelBuild& out, std::vector<AccelItem>& items, double pad, int depth0) {
+    const uint32_t root = accel_build_bvh_impl(out, items, pad, depth0);
+    if (out.ok && root != REF_DONE) fill_min_order(out, root);
+    return root;
+}
+static uint32_t accel_build_bvh_impl(AccelBuild& out, std::vector<AccelItem>& items, double pad, int depth0) {
     if (items.empty() || !std::isfinite(pad)) {
         out.ok = false;
         return REF_DONE;
