@@ -60,10 +60,16 @@ def test_launcher_source_never_execs_or_touches_the_gpu_before_spawning():
     assert "torch" not in body.replace("torch.distributed.run", "") and "rtamd." not in body
 
 
-def test_roofline_objects_are_physical():
+def test_roofline_objects_are_physical(tmp_path, monkeypatch):
     sys.path.insert(0, ROOT)
     import bench
     model = json.load(open(bench.MODEL))
+    # (the arithmetic is what is tested here: a copy of the model stamped with this tree's source hash; that the COMMITTED model
+    # belongs to the committed sources is test_committed_pmc_model_belongs_to_the_committed_kernel_sources)
+    model["kernel_source_sha16"] = bench.kernel_source_sha16()
+    mp = tmp_path / "model.json"
+    mp.write_text(json.dumps(model))
+    monkeypatch.setattr(bench, "MODEL", str(mp))
     # a launch at exactly the modelled rate: samples/s = SIMDs * clock / (insts/sample * cycles/inst) * valu_busy
     sps = bench.N_SIMDS * bench.MAX_CLOCK_GHZ * 1e9 / (model["valu_insts_per_sample"] * model["valu_issue_cycles_per_inst"]) * 0.9
     acc = {"kernel_ms": 100.0, "launches": 2, "samples": int(sps * 0.1)}
