@@ -202,6 +202,10 @@ struct RenderK {
     int tiles_x, rank, world;
     int tiles_owned;  // jobs are dealt sample-major: job j = (tile j % tiles_owned, sample blocks [j / tiles_owned * job_units, + job_units))
     int job_units;    // consecutive units of one tile a wave takes at a time (one ticket hand-off per job); n_units counts JOBS
+    // The schedule of one launch (kernels 1, 2, 5; see make_schedule): every tile's samples [s_begin, s_end) are cut into the same sequence
+    // of units, in up to SCHED_LEVELS levels of decreasing unit / job size.  Level l: rounds (jobs per tile) from lvl[l][0], units from
+    // lvl[l][1], samples from lvl[l][2], lvl[l][3] samples per unit, lvl[l][4] units per job; lvl[n_levels] = {rounds, units, s_end, 0, 0}.
+    int lvl[5][5];
     const double* sppm_est;  // INTEG 2: per pixel {caustic estimate[3], global estimate[3]}, index y*width + x
     int n_top;               // kernel 2 with the scene in L2/HBM: number of (depth-sorted) Node2 cached in LDS
     int n_topq;              // kernel 5: number of NodeQ cached in LDS for the serving waves
@@ -1097,7 +1101,16 @@ DEV bool mixture_step(const Acc& A, const Rec& rec, Rng& rng, D3 att, D3& beta, 
 #ifndef REGEN_MIN
 #define REGEN_MIN 8
 #endif
-static const int UNIT_SPP = 8;                              // sample indices per work unit, at most
+#ifndef FOLD_RETRY
+#define FOLD_RETRY 4   // main-loop iterations between two looks at a complete head unit whose ticket has not come
+#endif
+#ifndef FOLD_PERIOD
+#define FOLD_PERIOD 4  // the head of the ring is looked at every FOLD_PERIOD-th iteration (every iteration: -1 % on the whole frame)
+#endif
+#ifndef UNIT_SPP_N
+#define UNIT_SPP_N 8
+#endif
+static const int UNIT_SPP = UNIT_SPP_N;                     // sample indices per work unit, at most
 #ifndef RING_UNITS
 #define RING_UNITS 6                                         // unit buffers per wave (two jobs of 2 units and some slack)
 #endif
@@ -1114,6 +1127,10 @@ DEV void st_agent(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_R
 // ticket is looked at once per job (its first unit), the accumulator is loaded once and stored once per run of the job's
 // units, and the ticket moves after the job's last unit -- the ~3 memory round trips of a fold are paid per job, not per unit.
 // rmeta per ring slot: {tile (local), first sample block of the unit within the launch, samples | first << 8 | last << 9, paths running}
+#ifdef RT_TAIL_STATS  // tools-only build: when every wave of pt_kernel entered, reached the main loop and left (s_memrealtime)
+__device__ unsigned long long g_tail_end[8192], g_tail_beg[8192], g_tail_entry[8192];
+__device__ unsigned int g_tail_xcc[8192];
+#endif
 #ifdef RT_FOLD_STATS  // tools-only build: {calls, cycles in fold_units, units folded, returns on a ticket mismatch, sleeps}
 __device__ unsigned long long g_fold_stats[8];
 #endif
@@ -1201,17 +1218,29 @@ __device__ __attribute__((noinline)) int fold_units(const uint32_t* rmeta, const
 // fetch the next job.  Everything it needs lives in LDS (per-wave state `wst`, launch constants `cfg`), so that the hot loop
 // carries only {pool, next, s0, tx, ty, cur_slot, finished} for all of this; out of line for the same reason (it runs about once
 // per 512 paths).
-//   wst: {r_head, r_cnt, job_tile, job_blk0, job_n, job_k, more_jobs, -}      cfg: see CFG_* below
+//   wst: {r_head, r_cnt, job_tile, job_blk0, job_n, job_k, more_jobs, job's level}      cfg: see CFG_* below
 enum { CFG_N_JOBS, CFG_TILES_OWNED, CFG_JOB_UNITS, CFG_SUBS_PER_TILE, CFG_WORLD, CFG_RANK, CFG_TILES_X, CFG_S_BEGIN, CFG_S_END, CFG_SUB_SPP,
-       CFG_WIDTH, CFG_HEIGHT, CFG_RING_UNITS /* unit buffers per wave: RING_UNITS, kernel 6: WF_RING_UNITS */, CFG_WORDS = 16 };
+       CFG_WIDTH, CFG_HEIGHT, CFG_RING_UNITS /* unit buffers per wave: RING_UNITS, kernel 6: WF_RING_UNITS */, CFG_LVL = 16 /* RenderK::lvl, 25 words */,
+       CFG_WORDS = 48 };
+static const int SCHED_LEVELS = 4;
 struct UnitInfo {
     int pool;      // paths of the unit that was started (0: none was)
     int s0, tx, ty, cur_slot;
     int finished;  // no job left, every unit folded: the wave may exit once its lanes are dead
 };
+// next_unit()'s result comes back in vector registers; it is the same in every lane, and reading it through readfirstlane tells the
+// compiler so (the unit's six words then live in scalar registers across pt_kernel's main loop: -3 ms on the 507 ms headline frame.  NOT in pt_kernel_coop: C4 888 -> 835 Msamples/s with it)
+__device__ __forceinline__ UnitInfo uniform_unit(const UnitInfo& v) {
+    UnitInfo u;
+    u.pool = __builtin_amdgcn_readfirstlane(v.pool); u.s0 = __builtin_amdgcn_readfirstlane(v.s0);
+    u.tx = __builtin_amdgcn_readfirstlane(v.tx); u.ty = __builtin_amdgcn_readfirstlane(v.ty);
+    u.cur_slot = __builtin_amdgcn_readfirstlane(v.cur_slot); u.finished = __builtin_amdgcn_readfirstlane(v.finished);
+    return u;
+}
 __device__ __attribute__((noinline)) UnitInfo next_unit(uint32_t* wst, uint32_t* rmeta, const int* cfg, const double* wring, double* accum,
-                                                        unsigned int* tickets, unsigned int* counter, bool all_dead, int lane) {
+                                                        unsigned int* tickets, unsigned int* counter, bool all_dead, int lane, bool take = true) {
     int r_head = (int)wst[0], r_cnt = (int)wst[1], job_tile = (int)wst[2], job_blk0 = (int)wst[3], job_n = (int)wst[4], job_k = (int)wst[5];
+    int job_lvl = (int)wst[7];
     bool more_jobs = wst[6] != 0u;
     const int ring_units = cfg[CFG_RING_UNITS];
     UnitInfo u;
@@ -1227,8 +1256,9 @@ __device__ __attribute__((noinline)) UnitInfo next_unit(uint32_t* wst, uint32_t*
         r_head += folded;
         if (r_head >= ring_units) r_head -= ring_units;
         r_cnt -= folded;
+        if (!take) u.cur_slot = folded;
     }
-    if (r_cnt < ring_units && (job_k < job_n || more_jobs)) {
+    if (take && r_cnt < ring_units && (job_k < job_n || more_jobs)) {
         if (job_k >= job_n) {  // next job: job_units consecutive sample blocks of one tile
             unsigned int job = 0;
             if (lane == 0) job = atomicAdd(counter, 1u);
@@ -1236,9 +1266,13 @@ __device__ __attribute__((noinline)) UnitInfo next_unit(uint32_t* wst, uint32_t*
             if (job >= (unsigned)cfg[CFG_N_JOBS]) {
                 more_jobs = false;  // every wave gets here: the counter only grows
             } else {
-                job_tile = (int)(job % (unsigned)cfg[CFG_TILES_OWNED]);  // sample-major: all tiles' job k before any tile's job k+1
-                job_blk0 = (int)(job / (unsigned)cfg[CFG_TILES_OWNED]) * cfg[CFG_JOB_UNITS];
-                job_n = min(cfg[CFG_JOB_UNITS], cfg[CFG_SUBS_PER_TILE] - job_blk0);
+                job_tile = (int)(job % (unsigned)cfg[CFG_TILES_OWNED]);  // sample-major: all tiles' round k before any tile's round k+1
+                const int round = (int)(job / (unsigned)cfg[CFG_TILES_OWNED]);
+                job_lvl = 0;
+                while (round >= cfg[CFG_LVL + 5 * (job_lvl + 1)]) job_lvl++;  // (the entry behind the last level holds the number of rounds)
+                const int* L = cfg + CFG_LVL + 5 * job_lvl;
+                job_blk0 = L[1] + (round - L[0]) * L[4];
+                job_n = min(L[4], L[5 + 1] - job_blk0);
                 job_k = 0;
             }
         }
@@ -1247,8 +1281,9 @@ __device__ __attribute__((noinline)) UnitInfo next_unit(uint32_t* wst, uint32_t*
             u.tx = tile % cfg[CFG_TILES_X];
             u.ty = tile / cfg[CFG_TILES_X];
             const int sub_i = job_blk0 + job_k;
-            u.s0 = cfg[CFG_S_BEGIN] + sub_i * cfg[CFG_SUB_SPP];
-            const int s1 = min(u.s0 + cfg[CFG_SUB_SPP], cfg[CFG_S_END]);
+            const int* L = cfg + CFG_LVL + 5 * job_lvl;
+            u.s0 = L[2] + (sub_i - L[1]) * L[3];
+            const int s1 = min(u.s0 + L[3], L[5 + 2]);
             u.pool = (s1 - u.s0) * TILE_PIX;
             u.cur_slot = r_head + r_cnt;
             if (u.cur_slot >= ring_units) u.cur_slot -= ring_units;
@@ -1268,7 +1303,7 @@ __device__ __attribute__((noinline)) UnitInfo next_unit(uint32_t* wst, uint32_t*
     u.finished = (u.pool == 0 && !more_jobs && job_k >= job_n && r_cnt == 0) ? 1 : 0;
     if (lane == 0) {
         wst[0] = (uint32_t)r_head; wst[1] = (uint32_t)r_cnt; wst[2] = (uint32_t)job_tile; wst[3] = (uint32_t)job_blk0;
-        wst[4] = (uint32_t)job_n; wst[5] = (uint32_t)job_k; wst[6] = more_jobs ? 1u : 0u;
+        wst[4] = (uint32_t)job_n; wst[5] = (uint32_t)job_k; wst[6] = more_jobs ? 1u : 0u; wst[7] = (uint32_t)job_lvl;
     }
     return u;
 }
@@ -1277,6 +1312,9 @@ template <bool LDS, bool GENERAL, int ACCEL, int INTEG, bool MEDIA = false>
 __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, RenderK rk, double* __restrict__ ring, double* accum,
                                                       unsigned int* tickets, unsigned int* __restrict__ counter, int* __restrict__ err) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef RT_TAIL_STATS
+    const unsigned long long tail_entry = __builtin_amdgcn_s_memrealtime();
+#endif
     // LDS map: [staged scene tables (LDS variants) | top-of-BVH Node2 cache (scene in L2/HBM)] [kernel 2: per-lane
     // traversal stacks, stack2 x blockDim 32-bit words] [per wave: RING_UNITS x {unit, samples, paths still running}]
     const uint32_t st_begin = (ACCEL == 2) ? sv.stage2_begin : 0u;
@@ -1350,6 +1388,8 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
         cfg[CFG_S_BEGIN] = rk.s_begin; cfg[CFG_S_END] = rk.s_end; cfg[CFG_SUB_SPP] = rk.sub_spp; cfg[CFG_WIDTH] = rk.width;
         cfg[CFG_HEIGHT] = rk.height;
         cfg[CFG_RING_UNITS] = RING_UNITS;
+#pragma unroll
+        for (int i = 0; i < 25; i++) cfg[CFG_LVL + i] = rk.lvl[i / 5][i % 5];
     }
     __syncthreads();
     double* wring = ring + ((size_t)blockIdx.x * (PT_BLOCK / 64) + (size_t)wave) * RING_UNITS * UNIT_DOUBLES;
@@ -1368,6 +1408,10 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
     uint32_t out_slot = 0;  // this path's sample in the wave's ring: (ring slot * UNIT_SPP + sample within the unit) * 64 + pixel
     Rng rng;
     rng.s = 0;
+#ifdef RT_TAIL_STATS
+    const unsigned long long tail_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    int fold_wait = 0;  // iterations until the head of the ring is looked at again (wave-uniform)
     {
         for (;;) {
             // ---- regeneration: dead lanes pull the next (pixel, sample) of the pool ----
@@ -1376,17 +1420,36 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
             // (measured: 1 -> 2142, 4 -> 2174, 8 -> 2228, 12 -> 2210, 16 -> 2189, 24 -> 2094 Msamples/s)
             if ((int)__popcll(dead) < REGEN_MIN && dead != ~0ull) dead = 0ull;
             // ---- pool exhausted: fold what is complete, start the next unit (next_unit, out of line) ----
-            if (dead != 0ull && next >= pool && !finished) {
-                const UnitInfo u = next_unit(wst, rmeta, cfg, wring, accum, tickets, counter, dead == ~0ull, lane);
-                if (u.pool > 0) {
-                    pool = u.pool;
-                    next = 0;
-                    s0 = u.s0;
-                    tx = u.tx;
-                    ty = u.ty;
-                    cur_slot = u.cur_slot;
+            // A complete unit at the head of the ring is folded at once, through the same call (take = false: fold only; one call
+            // site -- a second one in this loop costs 0.6 % of the whole frame in spills).  next_unit() used to fold only when the
+            // wave needed a new unit, about once per millisecond; when a rank owns fewer tiles than the GPU has waves (a frame split
+            // over 8 GPUs: 2 812 tiles for 4 096 waves) consecutive sample blocks of one tile are traced at the same time by
+            // different waves and their folds form a chain -- every hop waited for the holder's next unit boundary, the rings
+            // filled with complete units whose turn had not come and the waves slept on tickets (one rank's eighth of the headline
+            // frame: 75.3 ms instead of 63.4; 81 M sleeps against 0.7 M for the whole frame on one GPU).
+            const bool need_unit = dead != 0ull && next >= pool && !finished;
+            bool head_ready = false;
+            if (FOLD_PERIOD > 0 && !need_unit && --fold_wait < 0) {
+                fold_wait = FOLD_PERIOD - 1;
+                head_ready = __builtin_amdgcn_readfirstlane(wst[1]) != 0u &&
+                             __builtin_amdgcn_readfirstlane(__hip_atomic_load(&rmeta[4 * __builtin_amdgcn_readfirstlane(wst[0]) + 3], __ATOMIC_RELAXED,
+                                                                              __HIP_MEMORY_SCOPE_WORKGROUP)) == 0u;
+            }
+            if (need_unit || head_ready) {
+                const UnitInfo u = uniform_unit(next_unit(wst, rmeta, cfg, wring, accum, tickets, counter, need_unit && dead == ~0ull, lane, need_unit));
+                if (need_unit) {
+                    if (u.pool > 0) {
+                        pool = u.pool;
+                        next = 0;
+                        s0 = u.s0;
+                        tx = u.tx;
+                        ty = u.ty;
+                        cur_slot = u.cur_slot;
+                    }
+                    finished = u.finished != 0;
+                } else if (u.cur_slot == 0) {  // (fold only: the number of units folded comes back in cur_slot)
+                    fold_wait = FOLD_RETRY;  // its ticket has not come: not every iteration
                 }
-                finished = u.finished != 0;
             }
             if (dead != 0ull && next < pool) {
                 int k = next + __popcll(dead & lanemask_lt);
@@ -1460,6 +1523,14 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
             }
         }
     }
+#ifdef RT_TAIL_STATS
+    if (lane == 0) {
+        g_tail_end[blockIdx.x * (PT_BLOCK / 64) + wave] = __builtin_amdgcn_s_memrealtime();
+        g_tail_beg[blockIdx.x * (PT_BLOCK / 64) + wave] = tail_t0;
+        g_tail_entry[blockIdx.x * (PT_BLOCK / 64) + wave] = tail_entry;
+        g_tail_xcc[blockIdx.x * (PT_BLOCK / 64) + wave] = 0u;
+    }
+#endif
 }
 
 // ------------------------------------------------------- pt_kernel_coop (kernel 5) ---
@@ -2077,6 +2148,8 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
         cfg[CFG_S_BEGIN] = rk.s_begin; cfg[CFG_S_END] = rk.s_end; cfg[CFG_SUB_SPP] = rk.sub_spp; cfg[CFG_WIDTH] = rk.width;
         cfg[CFG_HEIGHT] = rk.height;
         cfg[CFG_RING_UNITS] = RING_UNITS;
+#pragma unroll
+        for (int i = 0; i < 25; i++) cfg[CFG_LVL + i] = rk.lvl[i / 5][i % 5];
         cargs->base = sv.base;
         cargs->pool = coop + (size_t)blockIdx.x * COOP_POOL * COOP_REC;
         cargs->err = err;
@@ -2675,6 +2748,44 @@ size_t release_workspaces() {  // frees every idle workspace (all devices); retu
     return freed;
 }
 
+// The schedule of one launch (RenderK::lvl): returns the number of rounds (jobs per tile).  Jobs are dealt sample-major, so the sizes at
+// the end of the sequence are the sizes of the jobs still running when the queue runs dry, and what a wave has left to do then is idle
+// time for every wave that finished before it.  Measured with the uniform schedule (jobs of 2 units x 8 spp; tools-only build
+// -DRT_TAIL_STATS): mean idle wave-time at the end of the launch 2.4 ms of 507.9 (whole headline frame), 3.7 ms of 70.9 (one rank's
+// eighth of it).  Small units everywhere are no answer (8 -> 4 -> 2 -> 1 spp per unit: 509.6, 518.1, 545.9, 628.1 ms for the frame), so
+// only the END of the sequence is tapered: `r` rounds each of single units of sub_spp, sub_spp / 2 and sub_spp / 4 samples, where a
+// round of every level lasts long enough to cover the stragglers of the level before it -- r grows as the rank's share of tiles shrinks
+// (r = ceil(TAPER_R x waves / tiles)), capped at a quarter of the launch's samples.
+#ifndef TAPER_R
+#define TAPER_R 6
+#endif
+static int make_schedule(RenderK& rk, int n_waves) {
+    const int n = rk.s_end - rk.s_begin, sub = rk.sub_spp;
+    // the taper's levels: single units of sub_spp (only when the main part deals jobs of several units), sub_spp / 2, sub_spp / 4
+    int size[SCHED_LEVELS - 1], n_taper = 0, taper_unit = 0;
+    if (rk.job_units > 1) size[n_taper++] = sub;
+    if (sub / 2 >= 1) size[n_taper++] = sub / 2;
+    if (sub / 4 >= 1) size[n_taper++] = sub / 4;
+    for (int k = 0; k < n_taper; k++) taper_unit += size[k];
+    int r = 0;
+    if (TAPER_R > 0 && n_taper > 0)
+        r = (int)std::min<int64_t>(((int64_t)TAPER_R * n_waves + rk.tiles_owned - 1) / std::max(1, rk.tiles_owned), n / 4 / taper_unit);
+    const int main_spp = n - r * taper_unit;
+    int round0 = 0, unit0 = 0, s0 = rk.s_begin, l = 0;
+    auto level = [&](int spp, int sz, int ju) {  // `spp` samples in units of `sz`, `ju` units per job
+        if (spp <= 0) return;
+        const int units = (spp + sz - 1) / sz;
+        rk.lvl[l][0] = round0; rk.lvl[l][1] = unit0; rk.lvl[l][2] = s0; rk.lvl[l][3] = sz; rk.lvl[l][4] = ju;
+        round0 += (units + ju - 1) / ju; unit0 += units; s0 += spp;
+        l++;
+    };
+    level(main_spp, sub, rk.job_units);
+    for (int k = 0; k < n_taper; k++) level(r * size[k], size[k], 1);
+    for (int k = l; k <= SCHED_LEVELS; k++) { rk.lvl[k][0] = round0; rk.lvl[k][1] = unit0; rk.lvl[k][2] = rk.s_end; rk.lvl[k][3] = 0; rk.lvl[k][4] = 0; }
+    rk.subs_per_tile = unit0;
+    return round0;
+}
+
 typedef void (*pt_fn)(FlatView, CamK, RenderK, double*, double*, unsigned int*, unsigned int*, int*);
 typedef void (*pt_coop_fn)(FlatView, CamK, RenderK, double*, double*, unsigned int*, unsigned int*, int*, uint64_t*);
 
@@ -2809,7 +2920,7 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
     int launches = 0;
     for (int s0 = 0; s0 < plan.spp; s0 += plan.spp_chunk) {
         const int s1 = std::min(s0 + plan.spp_chunk, plan.spp);
-        RenderK rk;
+        RenderK rk = {};
         rk.width = plan.width; rk.height = plan.height; rk.max_depth = plan.max_depth;
         rk.t_min = plan.t_min; rk.seed = plan.seed;
         rk.s_begin = s0; rk.s_end = s1;
@@ -2819,12 +2930,12 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
         // (measured: headline 592 ms with 2, 606 with 1 and a 4-slot ring, 593 with 4; 9 M-sample frame 7.0 ms with 1 or 2, 9.3 with 4)
         const bool many_units = plan.tiles_owned * (int64_t)rk.subs_per_tile >= (int64_t)64 * grid * (PT_BLOCK / 64);
         rk.job_units = std::max(1, std::min(many_units ? JOB_UNITS : 1, rk.subs_per_tile));
-        const int jobs_per_tile = (rk.subs_per_tile + rk.job_units - 1) / rk.job_units;
-        int64_t units = plan.tiles_owned * jobs_per_tile;
+        rk.tiles_owned = (int)std::max<int64_t>(1, plan.tiles_owned);
+        const int jobs_per_tile = make_schedule(rk, grid * (PT_BLOCK / 64));
+        int64_t units = plan.tiles_owned * (int64_t)jobs_per_tile;
         if (units > 0x7FFFFFFF) throw RtError(RT_ERR_UNSUPPORTED, "too many work units per launch");
         rk.n_units = (int)units;
         rk.tiles_x = plan.tiles_x; rk.rank = plan.rank; rk.world = plan.world;
-        rk.tiles_owned = (int)std::max<int64_t>(1, plan.tiles_owned);
         rk.sppm_est = plan.sppm_est;
         rk.n_top = n_top;
         rk.n_topq = n_topq;
@@ -2889,6 +3000,41 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
         const char* tn[8] = {"fold + regenerate", "world-space walk", "park", "adopt", "shade", "serve (batch)", "tail: serve rest / idle", "(of park + adopt: the two ring pops)"};
         for (int i = 0; i < 8; i++) fprintf(stderr, "[coop time] %-26s %5.1f %%\n", tn[i], tot ? 100. * (double)tm[i] / (double)tot : 0.);
         HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_coop_time), z, sizeof(tm)));
+    }
+#endif
+#ifdef RT_TAIL_STATS
+    if (kernel != 5 && st) {
+        // s_memrealtime: the 100 MHz counter every CU sees alike (s_memtime has constant offsets of milliseconds between CUs)
+        const int wpb = PT_BLOCK / 64, nw = grid * wpb;
+        std::vector<unsigned long long> te(8192), tb(8192);
+        HIP_CHECK(hipMemcpyFromSymbol(te.data(), HIP_SYMBOL(g_tail_end), sizeof(unsigned long long) * 8192));
+        HIP_CHECK(hipMemcpyFromSymbol(tb.data(), HIP_SYMBOL(g_tail_beg), sizeof(unsigned long long) * 8192));
+        std::vector<unsigned long long> tn(8192);
+        std::vector<unsigned int> xc(8192);
+        HIP_CHECK(hipMemcpyFromSymbol(xc.data(), HIP_SYMBOL(g_tail_xcc), sizeof(unsigned int) * 8192));
+        HIP_CHECK(hipMemcpyFromSymbol(tn.data(), HIP_SYMBOL(g_tail_entry), sizeof(unsigned long long) * 8192));
+        unsigned long long x0[8];
+        for (int x = 0; x < 8; x++) x0[x] = ~0ull;
+        for (int i = 0; i < nw; i++) x0[xc[i]] = std::min(x0[xc[i]], tn[i]);
+        {
+            std::vector<double> n(nw), sg(nw);
+            for (int i = 0; i < nw; i++) { n[i] = (double)(tn[i] - x0[xc[i]]); sg[i] = (double)(tb[i] - tn[i]); }
+            std::sort(n.begin(), n.end());
+            std::sort(sg.begin(), sg.end());
+            fprintf(stderr, "[tail stats] (ticks) kernel entry after the XCD's first wave: 50%% %.0f  99%% %.0f  last %.0f; entry -> main loop (staging): 50%% %.0f  last %.0f\n", n[nw / 2],
+                    n[nw * 99 / 100], n[nw - 1], sg[nw / 2], sg[nw - 1]);
+        }
+        std::vector<double> b(nw), e(nw);
+        for (int i = 0; i < nw; i++) { b[i] = (double)(tb[i] - x0[xc[i]]); e[i] = (double)(te[i] - x0[xc[i]]); }
+        std::sort(b.begin(), b.end());
+        std::sort(e.begin(), e.end());
+        const double k = st->kernel_ms / e[nw - 1];  // ticks -> ms through the event time
+        double idle = 0;
+        for (int i = 0; i < nw; i++) idle += e[nw - 1] - e[i];
+        fprintf(stderr, "[tail stats] kernel %.2f ms; wave starts: 50%% %.3f  99%% %.3f  last %.3f ms; wave ends: first %.2f  10%% %.2f  50%% %.2f  90%% %.2f  99%% %.2f  last %.2f ms; "
+                        "mean idle wave-time at the end %.2f ms\n",
+                st->kernel_ms, k * b[nw / 2], k * b[nw * 99 / 100], k * b[nw - 1], k * e[0], k * e[nw / 10], k * e[nw / 2], k * e[nw * 9 / 10], k * e[nw * 99 / 100],
+                k * e[nw - 1], k * idle / nw);
     }
 #endif
 #ifdef RT_FOLD_STATS
@@ -2960,7 +3106,7 @@ static void render_tiles_wf(const rt_scene& s, const FlatView& view, const Camer
     double kms = 0.;
     for (int s0 = 0; s0 < plan.spp; s0 += plan.spp_chunk) {
         const int s1 = std::min(s0 + plan.spp_chunk, plan.spp);
-        RenderK rk;
+        RenderK rk = {};
         rk.width = plan.width; rk.height = plan.height; rk.max_depth = plan.max_depth;
         rk.t_min = plan.t_min; rk.seed = plan.seed;
         rk.s_begin = s0; rk.s_end = s1;

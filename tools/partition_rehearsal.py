@@ -13,6 +13,7 @@ for world in (1, 2, 4, 8):
         w.render(c, width=1200, height=1200, spp=1000, seed=1, rank=r, world=world)  # sizes the cached workspace
         _, st = w.render(c, width=1200, height=1200, spp=1000, seed=1, rank=r, world=world)
         worst = max(worst, st["seconds"])
-        print("world %d rank %d: %.3f s, %.0f Msamples/s on this rank, launches %d chunk %d" % (world, r, st["seconds"], st["samples"] / st["seconds"] / 1e6, st["launches"], st["spp_chunk"]))
+        print("world %d rank %d: %.3f s wall (host buffers), kernel %.2f ms = %.0f Msamples/s on this rank, launches %d chunk %d" % (
+            world, r, st["seconds"], st["kernel_ms"], st["samples"] / st["kernel_ms"] / 1e3, st["launches"], st["spp_chunk"]))
     t1 = t1 or worst
     print("   -> projected speed-up at %d GPUs (render only): %.2fx" % (world, t1 / worst))
