@@ -576,7 +576,7 @@ def test_degenerate_image_sizes_match_the_oracle(w, h):
 
 
 def test_render_workspace_is_small_and_can_be_released():
-    """samples live in per-wave unit rings (6 x 12 KB per resident wave) and are folded into the accumulator inside the
+    """samples live in per-wave unit rings (8 x 12 KB per resident wave) and are folded into the accumulator inside the
     kernel: the device workspace does not grow with spp, stays well below 1 GiB for a 1200 x 1200 frame, and
     rt_release_workspaces gives it back."""
     import rtamd
@@ -585,7 +585,7 @@ def test_render_workspace_is_small_and_can_be_released():
     _, a = world.render(cam, width=1200, height=1200, spp=2, seed=1)
     _, b = world.render(cam, width=1200, height=1200, spp=24, seed=1)
     assert a["workspace_bytes"] == b["workspace_bytes"] and a["launches"] == b["launches"] == 1
-    assert b["workspace_bytes"] < 400 * 1024 * 1024 and b["reduce_ms"] == 0.0
+    assert b["workspace_bytes"] < 512 * 1024 * 1024 and b["reduce_ms"] == 0.0
     freed = rtamd.release_workspaces()
     assert freed >= b["workspace_bytes"]
     again, _ = world.render(cam, width=64, height=64, spp=2, seed=1)
@@ -613,6 +613,30 @@ def test_one_tile_many_units_fold_in_order():
     img, st = world.render(cam, width=8, height=8, spp=1000, seed=4)
     exp, _ = ref.render(8, 8, 1000, seed=4)
     _assert_same(img, exp, "one tile, 125 units")
+
+
+def test_tapered_end_of_launch_schedule_folds_in_sample_order(tuning):
+    """every launch ends in rounds of smaller jobs (make_schedule, kernels.hip: single units of sub_spp, sub_spp / 2, sub_spp / 4 samples, at
+    most a quarter of the launch) so that the waves run dry together.  The taper changes which wave traces which samples, never the order
+    of a pixel's sum: 250 spp (not a multiple of any unit size) against the oracle, then unit sizes, launch chunks and a 3-rank partition
+    against that image, on kernel 2 and on kernel 1."""
+    world, cam, ref = _pair("scene_10.json", aspect=40 / 24)
+    w, h, spp = 40, 24, 250
+    full, st = world.render(cam, width=w, height=h, spp=spp, seed=12)
+    assert st["launches"] == 1 and st["kernel_used"] == 2
+    exp, _ = ref.render(w, h, spp, seed=12)
+    _assert_same(full, exp, "tapered schedule, 250 spp")
+    for sub, chunk, kernel in ((8, 97, 2), (5, 0, 2), (3, 113, 2), (2, 0, 1), (8, 0, 1)):
+        tuning(sub_spp=sub)
+        other, st2 = world.render(cam, width=w, height=h, spp=spp, seed=12, spp_chunk=chunk, kernel=kernel)
+        assert st2["launches"] == (1 if chunk == 0 else -(-spp // chunk))
+        assert np.array_equal(other, full), (sub, chunk, kernel)
+    tuning()
+    acc = np.zeros_like(full)
+    for r in range(3):
+        part, _ = world.render(cam, width=w, height=h, spp=spp, seed=12, rank=r, world=3)
+        acc += part
+    assert np.array_equal(acc, full)
 
 
 def test_negative_t_min_goes_through_the_reference_order_kernel():

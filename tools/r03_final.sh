@@ -13,4 +13,5 @@ for c in scene_10 scene_500_c2 cornell cornell_mix c4 c5r; do cp gpurun_out/r03_
 echo "== config bench"; timeout -k 10 900 python3 tools/config_bench.py > $OUT/config_bench.log 2>&1 || { tail -5 $OUT/config_bench.log; exit 1; }
 cp gpurun_out/config_bench.json $OUT/config_bench_1gpu.json
 echo "== bench records"; tools/r03_profile.sh > $OUT/profile.log 2>&1 || { tail -5 $OUT/profile.log; exit 1; }
+echo "== share scaling"; tools/r03_share.sh > $OUT/share.log 2>&1 || { tail -5 $OUT/share.log; exit 1; }
 tail -c 300 gpurun_out/r03_prof/bench_default.json

@@ -9,3 +9,4 @@ for c in scene_10 scene_500_c2 cornell cornell_mix c4 c5r; do
 done
 cp gpurun_out/r03_final/config_bench_1gpu.json profiles/r03/config_bench_1gpu.json
 cp gpurun_out/r03_prof/bench_default.json gpurun_out/r03_prof/bench_under_rocprof.json gpurun_out/r03_prof/kernel_stats_bench_default.csv gpurun_out/r03_prof/bench_forced_rccl_world1.json profiles/r03/
+cp gpurun_out/r03_share/share_scaling.txt gpurun_out/r03_share/tail_stats.txt gpurun_out/r03_share/step_wall.txt profiles/r03/
