@@ -311,6 +311,12 @@ int rt_debug_math_device(int op, size_t n, const double* a_host, const double* b
  * its own box test, which pt_kernel uses when the scene is LDS-resident): rays n*6 (orig,dir);
  * out n*12 = {hit, t, p[3], normal[3], front_face, u, v, leaf index in the reference-order program} */
 int rt_debug_hit_device(const rt_scene* s, int kernel, size_t n, const double* rays_host, double t_min, double t_max, double* out_host);
+/* the per-tile job sequence of one launch over samples [s_begin, s_end) for a rank that owns `tiles_owned` tiles on a GPU with `n_waves`
+ * resident waves (host logic only, no device needed): out[25] = 5 rows {first round, first unit, first sample, samples per unit, units per
+ * job}, one per level of decreasing unit / job size, the row behind the last level = {rounds, units, s_end, 0, 0}.  Every tile's samples
+ * are cut the same way; jobs are dealt round by round, so the small jobs of the last levels are what runs when the queue runs dry.
+ * Returns the number of rounds (jobs per tile) or a negative rt_status. */
+int rt_debug_schedule(int64_t tiles_owned, int n_waves, int s_begin, int s_end, int sub_spp, int job_units, int* out25);
 
 #ifdef __cplusplus
 }

@@ -10,6 +10,7 @@
 #include <new>
 
 #include "common/rng.h"
+#include "common/schedule.h"
 #include "device/device.h"
 #include "host/scene.h"
 #include "rtamd.h"
@@ -746,6 +747,17 @@ int rt_debug_hit_device(const rt_scene* s, int kernel, size_t n, const double* r
         debug_hit_device(*s, kernel, n, rays_host, t_min, t_max, out_host);
         return (int)RT_OK;
     });
+}
+int rt_debug_schedule(int64_t tiles_owned, int n_waves, int s_begin, int s_end, int sub_spp, int job_units, int* out25) {
+    int rounds = 0;
+    const int rc = guard([&] {
+        REQUIRE(tiles_owned > 0 && n_waves > 0 && s_begin >= 0 && s_end > s_begin && sub_spp >= 1 && sub_spp <= 8 && job_units >= 1 && out25, "bad argument");
+        Schedule sch;
+        rounds = make_schedule(sch, (int)std::min<int64_t>(tiles_owned, 0x7fffffff), n_waves, s_begin, s_end, sub_spp, job_units);
+        for (int i = 0; i < 25; i++) out25[i] = sch.lvl[i / 5][i % 5];
+        return (int)RT_OK;
+    });
+    return rc < 0 ? rc : rounds;
 }
 
 }  // extern "C"

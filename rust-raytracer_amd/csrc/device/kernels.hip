@@ -32,6 +32,7 @@
 #include "../common/flat.h"
 #include "../common/detlog.h"
 #include "../common/rng.h"
+#include "../common/schedule.h"
 #include "device.h"
 
 namespace rtamd {
@@ -202,7 +203,7 @@ struct RenderK {
     int tiles_x, rank, world;
     int tiles_owned;  // jobs are dealt sample-major: job j = (tile j % tiles_owned, sample blocks [j / tiles_owned * job_units, + job_units))
     int job_units;    // consecutive units of one tile a wave takes at a time (one ticket hand-off per job); n_units counts JOBS
-    // The schedule of one launch (kernels 1, 2, 5; see make_schedule): every tile's samples [s_begin, s_end) are cut into the same sequence
+    // The schedule of one launch (kernels 1, 2, 5; see make_schedule, host/schedule.cpp): every tile's samples [s_begin, s_end) are cut into the same sequence
     // of units, in up to SCHED_LEVELS levels of decreasing unit / job size.  Level l: rounds (jobs per tile) from lvl[l][0], units from
     // lvl[l][1], samples from lvl[l][2], lvl[l][3] samples per unit, lvl[l][4] units per job; lvl[n_levels] = {rounds, units, s_end, 0, 0}.
     int lvl[5][5];
@@ -1115,6 +1116,9 @@ static const int UNIT_SPP = UNIT_SPP_N;                     // sample indices pe
 #define RING_UNITS 8                                         // unit buffers per wave (6 -> 8: a rank's eighth of the headline frame 68.7 -> 67.2 ms, the whole frame 507.6 -> 503.0)
 #endif
 static const int UNIT_DOUBLES = UNIT_SPP * TILE_PIX * 3;    // 12 KB per unit
+#ifndef SINGLE_UNITS_BELOW_WAVES
+#define SINGLE_UNITS_BELOW_WAVES 1                           // jobs of single units when the rank owns fewer tiles than the GPU has waves (render_tiles)
+#endif
 #ifndef JOB_UNITS
 #define JOB_UNITS 2                                          // consecutive units of one tile per job (one accumulator hand-off per job)
 #endif
@@ -1222,7 +1226,7 @@ __device__ __attribute__((noinline)) int fold_units(const uint32_t* rmeta, const
 enum { CFG_N_JOBS, CFG_TILES_OWNED, CFG_JOB_UNITS, CFG_SUBS_PER_TILE, CFG_WORLD, CFG_RANK, CFG_TILES_X, CFG_S_BEGIN, CFG_S_END, CFG_SUB_SPP,
        CFG_WIDTH, CFG_HEIGHT, CFG_RING_UNITS /* unit buffers per wave: RING_UNITS, kernel 6: WF_RING_UNITS */, CFG_LVL = 16 /* RenderK::lvl, 25 words */,
        CFG_WORDS = 48 };
-static const int SCHED_LEVELS = 4;
+static_assert(SCHED_LEVELS == 4, "RenderK::lvl holds SCHED_LEVELS + 1 rows");
 struct UnitInfo {
     int pool;      // paths of the unit that was started (0: none was)
     int s0, tx, ty, cur_slot;
@@ -2748,44 +2752,6 @@ size_t release_workspaces() {  // frees every idle workspace (all devices); retu
     return freed;
 }
 
-// The schedule of one launch (RenderK::lvl): returns the number of rounds (jobs per tile).  Jobs are dealt sample-major, so the sizes at
-// the end of the sequence are the sizes of the jobs still running when the queue runs dry, and what a wave has left to do then is idle
-// time for every wave that finished before it.  Measured with the uniform schedule (jobs of 2 units x 8 spp; tools-only build
-// -DRT_TAIL_STATS): mean idle wave-time at the end of the launch 2.4 ms of 507.9 (whole headline frame), 3.7 ms of 70.9 (one rank's
-// eighth of it).  Small units everywhere are no answer (8 -> 4 -> 2 -> 1 spp per unit: 509.6, 518.1, 545.9, 628.1 ms for the frame), so
-// only the END of the sequence is tapered: `r` rounds each of single units of sub_spp, sub_spp / 2 and sub_spp / 4 samples, where a
-// round of every level lasts long enough to cover the stragglers of the level before it -- r grows as the rank's share of tiles shrinks
-// (r = ceil(TAPER_R x waves / tiles)), capped at a quarter of the launch's samples.
-#ifndef TAPER_R
-#define TAPER_R 6
-#endif
-static int make_schedule(RenderK& rk, int n_waves) {
-    const int n = rk.s_end - rk.s_begin, sub = rk.sub_spp;
-    // the taper's levels: single units of sub_spp (only when the main part deals jobs of several units), sub_spp / 2, sub_spp / 4
-    int size[SCHED_LEVELS - 1], n_taper = 0, taper_unit = 0;
-    if (rk.job_units > 1) size[n_taper++] = sub;
-    if (sub / 2 >= 1) size[n_taper++] = sub / 2;
-    if (sub / 4 >= 1) size[n_taper++] = sub / 4;
-    for (int k = 0; k < n_taper; k++) taper_unit += size[k];
-    int r = 0;
-    if (TAPER_R > 0 && n_taper > 0)
-        r = (int)std::min<int64_t>(((int64_t)TAPER_R * n_waves + rk.tiles_owned - 1) / std::max(1, rk.tiles_owned), n / 4 / taper_unit);
-    const int main_spp = n - r * taper_unit;
-    int round0 = 0, unit0 = 0, s0 = rk.s_begin, l = 0;
-    auto level = [&](int spp, int sz, int ju) {  // `spp` samples in units of `sz`, `ju` units per job
-        if (spp <= 0) return;
-        const int units = (spp + sz - 1) / sz;
-        rk.lvl[l][0] = round0; rk.lvl[l][1] = unit0; rk.lvl[l][2] = s0; rk.lvl[l][3] = sz; rk.lvl[l][4] = ju;
-        round0 += (units + ju - 1) / ju; unit0 += units; s0 += spp;
-        l++;
-    };
-    level(main_spp, sub, rk.job_units);
-    for (int k = 0; k < n_taper; k++) level(r * size[k], size[k], 1);
-    for (int k = l; k <= SCHED_LEVELS; k++) { rk.lvl[k][0] = round0; rk.lvl[k][1] = unit0; rk.lvl[k][2] = rk.s_end; rk.lvl[k][3] = 0; rk.lvl[k][4] = 0; }
-    rk.subs_per_tile = unit0;
-    return round0;
-}
-
 typedef void (*pt_fn)(FlatView, CamK, RenderK, double*, double*, unsigned int*, unsigned int*, int*);
 typedef void (*pt_coop_fn)(FlatView, CamK, RenderK, double*, double*, unsigned int*, unsigned int*, int*, uint64_t*);
 
@@ -2929,9 +2895,16 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
         // jobs of JOB_UNITS units halve the cross-wave hand-offs; small launches keep single units for load balance
         // (measured: headline 592 ms with 2, 606 with 1 and a 4-slot ring, 593 with 4; 9 M-sample frame 7.0 ms with 1 or 2, 9.3 with 4)
         const bool many_units = plan.tiles_owned * (int64_t)rk.subs_per_tile >= (int64_t)64 * grid * (PT_BLOCK / 64);
-        rk.job_units = std::max(1, std::min(many_units ? JOB_UNITS : 1, rk.subs_per_tile));
+        // (a rank that owns fewer tiles than the GPU has waves traces consecutive jobs of one tile at the same time: single units hand the
+        // tile's ticket on sooner -- 1/8 of the headline frame 68.2 -> 66.6 ms, while the whole frame loses 1.2 % with single units)
+        const bool tiles_cover_waves = !SINGLE_UNITS_BELOW_WAVES || plan.tiles_owned >= (int64_t)grid * (PT_BLOCK / 64);
+        rk.job_units = std::max(1, std::min(many_units && tiles_cover_waves ? JOB_UNITS : 1, rk.subs_per_tile));
         rk.tiles_owned = (int)std::max<int64_t>(1, plan.tiles_owned);
-        const int jobs_per_tile = make_schedule(rk, grid * (PT_BLOCK / 64));
+        Schedule sch;
+        const int jobs_per_tile = make_schedule(sch, rk.tiles_owned, grid * (PT_BLOCK / 64), rk.s_begin, rk.s_end, rk.sub_spp, rk.job_units);  // host/schedule.cpp
+        static_assert(sizeof(rk.lvl) == sizeof(sch.lvl), "RenderK::lvl is Schedule::lvl");
+        std::memcpy(rk.lvl, sch.lvl, sizeof(rk.lvl));
+        rk.subs_per_tile = sch.units_per_tile;
         int64_t units = plan.tiles_owned * (int64_t)jobs_per_tile;
         if (units > 0x7FFFFFFF) throw RtError(RT_ERR_UNSUPPORTED, "too many work units per launch");
         rk.n_units = (int)units;

@@ -154,6 +154,7 @@ _SIGS = [
     ("rt_debug_rng_host", C.c_int, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_uint64)]),
     ("rt_debug_math_device", C.c_int, [C.c_int, C.c_size_t, _dp, _dp, _dp]),
     ("rt_debug_hit_device", C.c_int, [C.c_void_p, C.c_int, C.c_size_t, _dp, C.c_double, C.c_double, _dp]),
+    ("rt_debug_schedule", C.c_int, [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
 ]
 ABI_SYMBOLS = [s[0] for s in _SIGS]
 
@@ -516,6 +517,16 @@ def set_tuning(**fields):
 def release_workspaces():
     """rt_release_workspaces: free the idle per-device render workspaces; returns the bytes released."""
     return int(lib().rt_release_workspaces())
+
+
+def debug_schedule(tiles_owned, n_waves, s_begin, s_end, sub_spp=8, job_units=2):
+    """rt_debug_schedule: (rounds, levels) with levels = [(first round, first unit, first sample, samples per unit, units per job), ...] and the
+    closing row (rounds, units, s_end, 0, 0) last.  Host logic only."""
+    out = (C.c_int * 25)()
+    rounds = _chk(lib().rt_debug_schedule(int(tiles_owned), int(n_waves), int(s_begin), int(s_end), int(sub_spp), int(job_units), out))
+    rows = [tuple(out[5 * i:5 * i + 5]) for i in range(5)]
+    n = next(i for i, r in enumerate(rows) if r[3] == 0)
+    return rounds, rows[:n + 1]
 
 
 def tiles_owned(params):

@@ -8,4 +8,6 @@ mkdir -p variants
   -Rpass-analysis=kernel-resource-usage -c csrc/device/kernels.hip -o variants/kernels_$name.o 2>&1 \
   | grep -E "Function Name|VGPRs:|ScratchSize" | grep -A2 "pt_kernelILb1ELb0ELi2ELi0" | grep -E "VGPRs|Scratch" | sed 's/.*remark: //' | cut -c1-50 | tr '\n' ' '
 echo " <- $name"
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o variants/librtamd_$name.so csrc/abi.o csrc/host/*.o variants/kernels_$name.o
+# the schedule (host/schedule.cpp) takes the same -D switches (-DTAPER_R=...)
+g++ -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -I../include -Icsrc $(for f in "$@"; do case $f in -D*) echo $f;; esac; done) -c csrc/host/schedule.cpp -o variants/schedule_$name.o
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o variants/librtamd_$name.so csrc/abi.o $(ls csrc/host/*.o | grep -v schedule.o) variants/schedule_$name.o variants/kernels_$name.o

@@ -44,7 +44,7 @@ def kernel_source_sha16():
     import hashlib
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rust-raytracer_amd", "csrc")
     h = hashlib.sha256()
-    for rel in ("device/kernels.hip", "device/wavefront.inc", "device/sppm.inc", "device/device.h", "common/flat.h", "common/rng.h", "common/detlog.h"):
+    for rel in ("device/kernels.hip", "device/wavefront.inc", "device/sppm.inc", "device/device.h", "common/flat.h", "common/rng.h", "common/detlog.h", "common/schedule.h", "host/schedule.cpp"):
         with open(os.path.join(root, rel), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]

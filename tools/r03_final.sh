@@ -14,4 +14,6 @@ echo "== config bench"; timeout -k 10 900 python3 tools/config_bench.py > $OUT/c
 cp gpurun_out/config_bench.json $OUT/config_bench_1gpu.json
 echo "== bench records"; tools/r03_profile.sh > $OUT/profile.log 2>&1 || { tail -5 $OUT/profile.log; exit 1; }
 echo "== share scaling"; tools/r03_share.sh > $OUT/share.log 2>&1 || { tail -5 $OUT/share.log; exit 1; }
+echo "== schedule soak"; timeout -k 10 600 python3 tools/schedule_soak.py 60 > $OUT/schedule_soak.log 2>$OUT/schedule_soak.err || { tail -5 $OUT/schedule_soak.log $OUT/schedule_soak.err; exit 1; }
+tail -2 $OUT/schedule_soak.log
 tail -c 300 gpurun_out/r03_prof/bench_default.json
