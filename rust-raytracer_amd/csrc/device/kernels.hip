@@ -1105,6 +1105,9 @@ DEV bool mixture_step(const Acc& A, const Rec& rec, Rng& rng, D3 att, D3& beta, 
 #ifndef FOLD_RETRY
 #define FOLD_RETRY 4   // main-loop iterations between two looks at a complete head unit whose ticket has not come
 #endif
+#ifndef COOP_EARLY_FOLD
+#define COOP_EARLY_FOLD 1
+#endif
 #ifndef FOLD_PERIOD
 #define FOLD_PERIOD 4  // the head of the ring is looked at every FOLD_PERIOD-th iteration (every iteration: -1 % on the whole frame)
 #endif
@@ -2077,7 +2080,7 @@ __device__ __attribute__((noinline)) Hit coop_walk_inline(const CoopArgs* args, 
     return h;
 }
 
-template <int INTEG, bool MIXED = false>
+template <int INTEG, bool MIXED = false, bool EARLY = false>
 __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam, RenderK rk, double* __restrict__ ring, double* accum,
                                                            unsigned int* tickets, unsigned int* __restrict__ counter, int* __restrict__ err, uint64_t* coop) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -2184,6 +2187,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
     uint32_t out_slot = 0;  // owner wave << 12 | (ring slot * UNIT_SPP + sample within the unit) * 64 + pixel
     uint32_t pend = 0u;
     int dec_slot = -1;      // a finished path whose unit counter still has to be decremented (owner wave << 12 | slot index)
+    int fold_wait = 0;      // iterations until the head of the ring is looked at again (wave-uniform)
     Rng rng;
     rng.s = 0;
     Hit h;
@@ -2205,17 +2209,34 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
         // ---- free lanes generate new paths right before the walk ----
         uint64_t dead = __ballot(!alive);
         if ((int)__popcll(dead) < REGEN_MIN && dead != ~0ull) dead = 0ull;
-        if (dead != 0ull && next >= pool && !finished) {
-            const UnitInfo u = next_unit(wst, rmeta, cfg, wring, accum, tickets, counter, false, lane);
-            if (u.pool > 0) {
-                pool = u.pool;
-                next = 0;
-                s0 = u.s0;
-                tx = u.tx;
-                ty = u.ty;
-                cur_slot = u.cur_slot;
+        {
+            // EARLY: as in pt_kernel, a complete unit at the head of the ring is folded at once through the same call (take = false).  A variant of
+            // its own because the check costs this kernel 3 % on a whole frame (C4: 409 -> 423 ms at 256 spp) and pays only for a rank's share
+            // (1/8 of the frame: 64 -> 56..63 ms, 1/16: 31.1 -> 29.0); render_tiles picks it when the rank owns fewer tiles than 2 x waves
+            const bool need_unit = dead != 0ull && next >= pool && !finished;
+            bool head_ready = false;
+            if (EARLY && !need_unit && --fold_wait < 0) {
+                fold_wait = FOLD_PERIOD - 1;
+                head_ready = __builtin_amdgcn_readfirstlane(wst[1]) != 0u &&
+                             __builtin_amdgcn_readfirstlane(__hip_atomic_load(&rmeta[4 * __builtin_amdgcn_readfirstlane(wst[0]) + 3], __ATOMIC_RELAXED,
+                                                                              __HIP_MEMORY_SCOPE_WORKGROUP)) == 0u;
             }
-            finished = u.finished != 0;
+            if (need_unit || head_ready) {
+                const UnitInfo u = next_unit(wst, rmeta, cfg, wring, accum, tickets, counter, false, lane, need_unit);
+                if (need_unit) {
+                    if (u.pool > 0) {
+                        pool = u.pool;
+                        next = 0;
+                        s0 = u.s0;
+                        tx = u.tx;
+                        ty = u.ty;
+                        cur_slot = u.cur_slot;
+                    }
+                    finished = u.finished != 0;
+                } else if (__builtin_amdgcn_readfirstlane(u.cur_slot) == 0) {
+                    fold_wait = FOLD_RETRY;
+                }
+            }
         }
         if (dead != 0ull && next < pool) {
             int k = next + __popcll(dead & lanemask_lt);
@@ -2839,9 +2860,13 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
                                           "reference-order walk; light sampling and SPPM have no volume events)");
     pt_fn fn = (kernel == 1) ? pick_pt_kernel<1>(lds, general, integ) : pick_pt_kernel<2>(lds, general, integ);
     pt_coop_fn fn_coop = nullptr;
-    if (kernel == 5)
+    pt_coop_fn fn_coop_early = nullptr;  // the variant that folds from the main loop: for a rank that owns few tiles (see pt_kernel_coop)
+    if (kernel == 5) {
+        fn_coop_early = (view.n_inline2 != 0u) ? ((integ == 1) ? pt_kernel_coop<1, true, true> : (integ == 2) ? pt_kernel_coop<2, true, true> : pt_kernel_coop<0, true, true>)
+                                               : ((integ == 1) ? pt_kernel_coop<1, false, true> : (integ == 2) ? pt_kernel_coop<2, false, true> : pt_kernel_coop<0, false, true>);
         fn_coop = (view.n_inline2 != 0u) ? ((integ == 1) ? pt_kernel_coop<1, true> : (integ == 2) ? pt_kernel_coop<2, true> : pt_kernel_coop<0, true>)
                                          : ((integ == 1) ? pt_kernel_coop<1> : (integ == 2) ? pt_kernel_coop<2> : pt_kernel_coop<0>);
+    }
     if (media)
         fn = (kernel == 2) ? (lds ? pt_kernel<true, true, 2, 0, true> : pt_kernel<false, true, 2, 0, true>)
                            : (lds ? pt_kernel<true, true, 1, 0, true> : pt_kernel<false, true, 1, 0, true>);
@@ -2861,6 +2886,7 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
         if (tun.n_top >= 0) n_topq = std::min(n_topq, tun.n_top);
     }
     const size_t smem = (lds ? hot_bytes : (size_t)n_top * sizeof(Node2) + (size_t)n_topq * sizeof(NodeQ)) + stack_bytes;
+    if (kernel == 5 && COOP_EARLY_FOLD && plan.tiles_owned < (int64_t)2 * di.cus * (PT_BLOCK / 64)) fn_coop = fn_coop_early;  // (one workgroup per CU)
     const void* fptr = (kernel == 5) ? (const void*)fn_coop : (const void*)fn;
     if (smem > 48 * 1024) HIP_CHECK(hipFuncSetAttribute(fptr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     int blocks_per_cu = 0;

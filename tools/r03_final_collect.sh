@@ -11,3 +11,4 @@ cp gpurun_out/r03_final/config_bench_1gpu.json profiles/r03/config_bench_1gpu.js
 cp gpurun_out/r03_prof/bench_default.json gpurun_out/r03_prof/bench_under_rocprof.json gpurun_out/r03_prof/kernel_stats_bench_default.csv gpurun_out/r03_prof/bench_forced_rccl_world1.json profiles/r03/
 cp gpurun_out/r03_share/share_scaling.txt gpurun_out/r03_share/tail_stats.txt gpurun_out/r03_share/step_wall.txt profiles/r03/
 cp gpurun_out/r03_final/schedule_soak.log profiles/r03/schedule_soak.log
+cp gpurun_out/r03_final/c4_share.txt profiles/r03/c4_share.txt
