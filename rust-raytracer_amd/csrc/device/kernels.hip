@@ -207,6 +207,7 @@ struct RenderK {
     // of units, in up to SCHED_LEVELS levels of decreasing unit / job size.  Level l: rounds (jobs per tile) from lvl[l][0], units from
     // lvl[l][1], samples from lvl[l][2], lvl[l][3] samples per unit, lvl[l][4] units per job; lvl[n_levels] = {rounds, units, s_end, 0, 0}.
     int lvl[5][5];
+    int pool_mode;  // the wave's unit buffers are a pool folded out of order (next_unit_pool) instead of a FIFO: launches of single-unit jobs
     const double* sppm_est;  // INTEG 2: per pixel {caustic estimate[3], global estimate[3]}, index y*width + x
     int n_top;               // kernel 2 with the scene in L2/HBM: number of (depth-sorted) Node2 cached in LDS
     int n_topq;              // kernel 5: number of NodeQ cached in LDS for the serving waves
@@ -1108,6 +1109,12 @@ DEV bool mixture_step(const Acc& A, const Rec& rec, Rng& rng, D3 att, D3& beta, 
 #ifndef COOP_EARLY_FOLD
 #define COOP_EARLY_FOLD 1
 #endif
+#ifndef POOL_MODE
+#define POOL_MODE 1    // launches of single-unit jobs fold their unit buffers out of order (next_unit_pool)
+#endif
+#ifndef FOLD_BATCH
+#define FOLD_BATCH 1   // sample indices whose loads are in flight together in fold_units (2: 507.1, 4: 512.4 ms against 502.3 for the headline frame)
+#endif
 #ifndef FOLD_PERIOD
 #define FOLD_PERIOD 4  // the head of the ring is looked at every FOLD_PERIOD-th iteration (every iteration: -1 % on the whole frame)
 #endif
@@ -1119,6 +1126,7 @@ static const int UNIT_SPP = UNIT_SPP_N;                     // sample indices pe
 #define RING_UNITS 8                                         // unit buffers per wave (6 -> 8: a rank's eighth of the headline frame 68.7 -> 67.2 ms, the whole frame 507.6 -> 503.0)
 #endif
 static const int UNIT_DOUBLES = UNIT_SPP * TILE_PIX * 3;    // 12 KB per unit
+static_assert(RING_UNITS * 4 <= 64, "a wave clears its ring bookkeeping with one store per lane");
 #ifndef SINGLE_UNITS_BELOW_WAVES
 #define SINGLE_UNITS_BELOW_WAVES 1                           // jobs of single units when the rank owns fewer tiles than the GPU has waves (render_tiles)
 #endif
@@ -1127,6 +1135,9 @@ static const int UNIT_DOUBLES = UNIT_SPP * TILE_PIX * 3;    // 12 KB per unit
 #endif
 DEV uint64_t ld_agent(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 DEV void st_agent(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// the same through pointers the compiler knows to be global memory (a generic pointer makes these FLAT accesses that also wait on lgkmcnt)
+DEV uint64_t ld_agent_g(const AS_G uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEV void st_agent_g(AS_G uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // Fold the wave's completed units, oldest first, into the accumulator (see "Where the samples go" above).  Returns how many
 // units were folded.  `idle`: the wave has nothing else to do, so it waits for the tile's previous job instead of returning.
@@ -1147,18 +1158,21 @@ __device__ __attribute__((noinline)) int fold_units(const uint32_t* rmeta, const
     const unsigned long long t_in = __builtin_amdgcn_s_memtime();
     unsigned long long n_mis = 0, n_sleep = 0;
 #endif
+    // address spaces spelled out: rmeta is the wave's bookkeeping in LDS, everything else global memory
+    const AS_L uint32_t* rm = (const AS_L uint32_t*)rmeta;
+    AS_G unsigned int* tk_g = (AS_G unsigned int*)tickets;
     int folded = 0;
     bool have = false;
     uint32_t cur_tile = 0;
     double ax = 0., ay = 0., az = 0.;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's sample stores are in L2
     while (r_cnt > 0) {
-        const uint32_t* m = rmeta + 4 * r_head;
+        const AS_L uint32_t* m = rm + 4 * r_head;
         if (__hip_atomic_load(&m[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) break;  // paths still running
         const uint32_t tile = m[0], blk = m[1], ns = m[2] & 0xffu;
         const bool first = (m[2] & 0x100u) != 0u, last = (m[2] & 0x200u) != 0u;
         if (first) {
-            const uint32_t tk = __hip_atomic_load(&tickets[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t tk = __hip_atomic_load(&tk_g[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (tk != blk) {  // the tile's previous job is not folded yet (rare): trace on unless nothing else is left to do
 #ifdef RT_FOLD_STATS
                 if (!idle) n_mis++;
@@ -1169,22 +1183,41 @@ __device__ __attribute__((noinline)) int fold_units(const uint32_t* rmeta, const
                 continue;
             }
         }
-        uint64_t* acc = (uint64_t*)accum + ((size_t)tile * TILE_PIX + (size_t)lane) * 3;
+        AS_G uint64_t* acc = (AS_G uint64_t*)accum + ((size_t)tile * TILE_PIX + (size_t)lane) * 3;
         if (!have) {
             ax = 0.; ay = 0.; az = 0.;
             if (!(blk == 0u && first_launch)) {
-                ax = __longlong_as_double(ld_agent(acc));
-                ay = __longlong_as_double(ld_agent(acc + 1));
-                az = __longlong_as_double(ld_agent(acc + 2));
+                ax = __longlong_as_double(ld_agent_g(acc));
+                ay = __longlong_as_double(ld_agent_g(acc + 1));
+                az = __longlong_as_double(ld_agent_g(acc + 2));
             }
             have = true;
             cur_tile = tile;
         }
-        const uint64_t* p = (const uint64_t*)wring + ((size_t)r_head * UNIT_SPP * TILE_PIX + (size_t)lane) * 3;
-        for (uint32_t si = 0; si < ns; si++) {  // pixel_color += sample, in sample order (camera.rs:96-101)
-            ax = ax + __longlong_as_double(ld_agent(p));
-            ay = ay + __longlong_as_double(ld_agent(p + 1));
-            az = az + __longlong_as_double(ld_agent(p + 2));
+        // pixel_color += sample, in sample order (camera.rs:96-101).  One memory round trip per sample index: loading several indices
+        // together (FOLD_BATCH) shortens the fold but its registers come out of pt_kernel's budget -- the kernel's scratch grows from 288 to
+        // 336 B per lane with 4 and the whole frame loses 2 %; the waiting wave costs little, three others run on its SIMD.
+        const AS_G uint64_t* p = (const AS_G uint64_t*)wring + ((size_t)r_head * UNIT_SPP * TILE_PIX + (size_t)lane) * 3;
+        uint32_t si = 0;
+#if FOLD_BATCH > 1
+        for (; si + FOLD_BATCH <= ns; si += FOLD_BATCH) {
+            uint64_t v[3 * FOLD_BATCH];
+#pragma unroll
+            for (int k = 0; k < 3 * FOLD_BATCH; k++) v[k] = ld_agent_g(p + (size_t)(k / 3) * (TILE_PIX * 3) + (k % 3));
+#pragma unroll
+            for (int j = 0; j < FOLD_BATCH; j++) {
+                ax = ax + __longlong_as_double(v[3 * j]);
+                ay = ay + __longlong_as_double(v[3 * j + 1]);
+                az = az + __longlong_as_double(v[3 * j + 2]);
+            }
+            p += FOLD_BATCH * TILE_PIX * 3;
+        }
+#endif
+        for (; si < ns; si++) {
+            const uint64_t v0 = ld_agent_g(p), v1 = ld_agent_g(p + 1), v2 = ld_agent_g(p + 2);
+            ax = ax + __longlong_as_double(v0);
+            ay = ay + __longlong_as_double(v1);
+            az = az + __longlong_as_double(v2);
             p += TILE_PIX * 3;
         }
         r_head = (r_head + 1 == ring_units) ? 0 : r_head + 1;
@@ -1193,17 +1226,17 @@ __device__ __attribute__((noinline)) int fold_units(const uint32_t* rmeta, const
         // the next unit continues this job iff it exists, is complete and is not the first of another job
         bool more = false;
         if (!last && r_cnt > 0) {
-            const uint32_t* n = rmeta + 4 * r_head;
+            const AS_L uint32_t* n = rm + 4 * r_head;
             more = __hip_atomic_load(&n[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u;
         }
         if (!more) {
-            st_agent(acc, __double_as_longlong(ax));
-            st_agent(acc + 1, __double_as_longlong(ay));
-            st_agent(acc + 2, __double_as_longlong(az));
+            st_agent_g(acc, __double_as_longlong(ax));
+            st_agent_g(acc + 1, __double_as_longlong(ay));
+            st_agent_g(acc + 2, __double_as_longlong(az));
             have = false;
             if (last) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // accumulator stores done before the ticket moves
-                if (lane == 0) __hip_atomic_store(&tickets[cur_tile], blk + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0) __hip_atomic_store(&tk_g[cur_tile], blk + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else {
                 break;  // the job's next unit still runs: come back later (it needs no ticket)
             }
@@ -1244,8 +1277,134 @@ __device__ __forceinline__ UnitInfo uniform_unit(const UnitInfo& v) {
     u.cur_slot = __builtin_amdgcn_readfirstlane(v.cur_slot); u.finished = __builtin_amdgcn_readfirstlane(v.finished);
     return u;
 }
-__device__ __attribute__((noinline)) UnitInfo next_unit(uint32_t* wst, uint32_t* rmeta, const int* cfg, const double* wring, double* accum,
+// next_unit() for launches of single-unit jobs (RenderK::pool_mode, the POOL variants of the kernels; a rank that owns fewer tiles than
+// the GPU has waves): the wave's unit
+// buffers are a POOL.  With the FIFO a complete unit at the head whose tile's ticket has not come keeps every unit behind it from being
+// folded, whatever the state of THEIR tiles, and with two or three waves per tile such heads are the rule (1/16 of the headline frame:
+// 1.9 M ticket mismatches for 0.2 M units).  Here every complete unit whose turn it is gets folded, whichever slot it is in, and a new
+// unit takes any free slot (kernel 6's next_unit_wf works the same way).  rmeta per slot: {tile (local), unit index, samples | 0x100 (slot
+// in use), paths still running}; wst: [0] the slot of the oldest unit (the main loop looks at it for the early fold), [1] slots in use,
+// [6] jobs left.  take = false: fold only; the number of units folded comes back in cur_slot.
+__device__ __attribute__((noinline)) UnitInfo next_unit_pool(uint32_t* wst_, uint32_t* rmeta_, const int* cfg_, const double* wring, double* accum,
+                                                             unsigned int* tickets, unsigned int* counter, bool all_dead, int lane, bool take = true) {
+    AS_L uint32_t* wst = (AS_L uint32_t*)wst_;
+    AS_L uint32_t* rmeta = (AS_L uint32_t*)rmeta_;
+    const AS_L int* cfg = (const AS_L int*)cfg_;
+    int n_used = (int)wst[1];
+    bool more_jobs = wst[6] != 0u;
+    const bool first_launch = cfg[CFG_S_BEGIN] == 0;
+    const int ring_units = cfg[CFG_RING_UNITS];  // <= 64: one slot per lane
+    AS_G unsigned int* tk_g = (AS_G unsigned int*)tickets;
+    int folded = 0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's sample stores are in L2
+    for (int round = 0; n_used > 0; round++) {
+        bool can = false;
+        if (lane < ring_units) {
+            const AS_L uint32_t* m = rmeta + 4 * lane;
+            if ((m[2] & 0x100u) != 0u && __hip_atomic_load(&m[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u)
+                can = __hip_atomic_load(&tk_g[m[0]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == m[1];
+        }
+        uint64_t mask = __ballot(can);
+        if (mask == 0ull) {
+            // nothing can be folded now.  A wave that can neither start a unit nor trace anything waits for a ticket
+            const bool idle = take && all_dead && folded == 0 && (n_used == ring_units || !more_jobs);
+            if (!idle) break;
+            __builtin_amdgcn_s_sleep(4);
+            continue;
+        }
+        while (mask != 0ull) {
+            const int sl = __ffsll((long long)mask) - 1;
+            mask &= mask - 1ull;
+            const AS_L uint32_t* m = rmeta + 4 * sl;
+            const uint32_t tile = m[0], blk = m[1], ns = m[2] & 0xffu;
+            AS_G uint64_t* acc = (AS_G uint64_t*)accum + ((size_t)tile * TILE_PIX + (size_t)lane) * 3;
+            double ax = 0., ay = 0., az = 0.;
+            if (!(blk == 0u && first_launch)) {
+                ax = __longlong_as_double(ld_agent_g(acc));
+                ay = __longlong_as_double(ld_agent_g(acc + 1));
+                az = __longlong_as_double(ld_agent_g(acc + 2));
+            }
+            const AS_G uint64_t* p = (const AS_G uint64_t*)wring + ((size_t)sl * UNIT_SPP * TILE_PIX + (size_t)lane) * 3;
+            for (uint32_t si = 0; si < ns; si++) {  // pixel_color += sample, in sample order (camera.rs:96-101)
+                ax = ax + __longlong_as_double(ld_agent_g(p));
+                ay = ay + __longlong_as_double(ld_agent_g(p + 1));
+                az = az + __longlong_as_double(ld_agent_g(p + 2));
+                p += TILE_PIX * 3;
+            }
+            st_agent_g(acc, __double_as_longlong(ax));
+            st_agent_g(acc + 1, __double_as_longlong(ay));
+            st_agent_g(acc + 2, __double_as_longlong(az));
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // accumulator stores done before the ticket moves
+            if (lane == 0) {
+                __hip_atomic_store(&tk_g[tile], blk + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                rmeta[4 * sl + 2] = 0u;  // slot free
+            }
+            n_used--;
+            folded++;
+        }
+        if (round >= 2) break;  // (a fold can make the tile's next unit, also in this pool, foldable: look again, a few times)
+    }
+    UnitInfo u;
+    u.pool = 0; u.s0 = 0; u.tx = 0; u.ty = 0; u.cur_slot = take ? 0 : folded; u.finished = 0;
+    if (take && n_used < ring_units && more_jobs) {
+        unsigned int job = 0;
+        if (lane == 0) job = atomicAdd(counter, 1u);
+        job = __builtin_amdgcn_readfirstlane(job);
+        if (job >= (unsigned)cfg[CFG_N_JOBS]) {
+            more_jobs = false;
+        } else {
+            const int job_tile = (int)(job % (unsigned)cfg[CFG_TILES_OWNED]);  // sample-major: all tiles' round k before any tile's round k+1
+            const int round = (int)(job / (unsigned)cfg[CFG_TILES_OWNED]);
+            int lv = 0;
+            while (round >= cfg[CFG_LVL + 5 * (lv + 1)]) lv++;
+            const AS_L int* L = cfg + CFG_LVL + 5 * lv;
+            const int sub_i = L[1] + (round - L[0]);  // (single-unit jobs: a round is a unit)
+            const uint64_t fm = __ballot(lane < ring_units && (rmeta[4 * lane + 2] & 0x100u) == 0u);
+            const int slot = __ffsll((long long)fm) - 1;
+            const int tile = job_tile * cfg[CFG_WORLD] + cfg[CFG_RANK];
+            u.tx = tile % cfg[CFG_TILES_X];
+            u.ty = tile / cfg[CFG_TILES_X];
+            u.s0 = L[2] + (sub_i - L[1]) * L[3];
+            const int s1 = min(u.s0 + L[3], L[5 + 2]);
+            u.pool = (s1 - u.s0) * TILE_PIX;
+            u.cur_slot = slot;
+            n_used++;
+            if (lane == 0) {
+                AS_L uint32_t* m = rmeta + 4 * slot;
+                m[0] = (uint32_t)job_tile;
+                m[1] = (uint32_t)sub_i;
+                m[2] = (uint32_t)(s1 - u.s0) | 0x100u;
+                const int w_in = min(TILE_W, cfg[CFG_WIDTH] - u.tx * TILE_W), h_in = min(TILE_H, cfg[CFG_HEIGHT] - u.ty * TILE_H);
+                __hip_atomic_store(&m[3], (uint32_t)((s1 - u.s0) * w_in * h_in), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    }
+    u.finished = (take && u.pool == 0 && !more_jobs && n_used == 0) ? 1 : 0;
+    // the oldest unit in the pool (smallest unit index: rounds are dealt in order) is the one the main loop watches
+    int oldest = 0;
+    uint32_t oldest_blk = 0xffffffffu;
+    for (int k = 0; k < ring_units; k++) {
+        const bool is_new = take && u.pool > 0 && k == u.cur_slot;  // (lane 0's write of the new unit's rmeta may not be visible yet)
+        if (!is_new && (rmeta[4 * k + 2] & 0x100u) != 0u && rmeta[4 * k + 1] < oldest_blk) {
+            oldest_blk = rmeta[4 * k + 1];
+            oldest = k;
+        }
+    }
+    if (oldest_blk == 0xffffffffu && take && u.pool > 0) oldest = u.cur_slot;
+    if (lane == 0) {
+        wst[0] = (uint32_t)oldest;
+        wst[1] = (uint32_t)n_used;
+        wst[6] = more_jobs ? 1u : 0u;
+    }
+    return u;
+}
+
+__device__ __attribute__((noinline)) UnitInfo next_unit(uint32_t* wst_, uint32_t* rmeta_, const int* cfg_, const double* wring, double* accum,
                                                         unsigned int* tickets, unsigned int* counter, bool all_dead, int lane, bool take = true) {
+    // the bookkeeping lives in LDS: typed pointers keep these DS accesses instead of FLAT ones
+    AS_L uint32_t* wst = (AS_L uint32_t*)wst_;
+    AS_L uint32_t* rmeta = (AS_L uint32_t*)rmeta_;
+    const AS_L int* cfg = (const AS_L int*)cfg_;
     int r_head = (int)wst[0], r_cnt = (int)wst[1], job_tile = (int)wst[2], job_blk0 = (int)wst[3], job_n = (int)wst[4], job_k = (int)wst[5];
     int job_lvl = (int)wst[7];
     bool more_jobs = wst[6] != 0u;
@@ -1258,7 +1417,7 @@ __device__ __attribute__((noinline)) UnitInfo next_unit(uint32_t* wst, uint32_t*
         const int folded = 1;
         (void)idle;
 #else
-        const int folded = fold_units(rmeta, wring, accum, tickets, cfg[CFG_S_BEGIN] == 0, r_head, r_cnt, idle, lane, ring_units);
+        const int folded = fold_units(rmeta_, wring, accum, tickets, cfg[CFG_S_BEGIN] == 0, r_head, r_cnt, idle, lane, ring_units);
 #endif
         r_head += folded;
         if (r_head >= ring_units) r_head -= ring_units;
@@ -1277,7 +1436,7 @@ __device__ __attribute__((noinline)) UnitInfo next_unit(uint32_t* wst, uint32_t*
                 const int round = (int)(job / (unsigned)cfg[CFG_TILES_OWNED]);
                 job_lvl = 0;
                 while (round >= cfg[CFG_LVL + 5 * (job_lvl + 1)]) job_lvl++;  // (the entry behind the last level holds the number of rounds)
-                const int* L = cfg + CFG_LVL + 5 * job_lvl;
+                const AS_L int* L = cfg + CFG_LVL + 5 * job_lvl;
                 job_blk0 = L[1] + (round - L[0]) * L[4];
                 job_n = min(L[4], L[5 + 1] - job_blk0);
                 job_k = 0;
@@ -1288,7 +1447,7 @@ __device__ __attribute__((noinline)) UnitInfo next_unit(uint32_t* wst, uint32_t*
             u.tx = tile % cfg[CFG_TILES_X];
             u.ty = tile / cfg[CFG_TILES_X];
             const int sub_i = job_blk0 + job_k;
-            const int* L = cfg + CFG_LVL + 5 * job_lvl;
+            const AS_L int* L = cfg + CFG_LVL + 5 * job_lvl;
             u.s0 = L[2] + (sub_i - L[1]) * L[3];
             const int s1 = min(u.s0 + L[3], L[5 + 2]);
             u.pool = (s1 - u.s0) * TILE_PIX;
@@ -1296,7 +1455,7 @@ __device__ __attribute__((noinline)) UnitInfo next_unit(uint32_t* wst, uint32_t*
             if (u.cur_slot >= ring_units) u.cur_slot -= ring_units;
             r_cnt++;
             if (lane == 0) {
-                uint32_t* m = rmeta + 4 * u.cur_slot;
+                AS_L uint32_t* m = rmeta + 4 * u.cur_slot;
                 m[0] = (uint32_t)job_tile;
                 m[1] = (uint32_t)sub_i;
                 m[2] = (uint32_t)(s1 - u.s0) | (job_k == 0 ? 0x100u : 0u) | (job_k + 1 == job_n ? 0x200u : 0u);
@@ -1315,7 +1474,7 @@ __device__ __attribute__((noinline)) UnitInfo next_unit(uint32_t* wst, uint32_t*
     return u;
 }
 
-template <bool LDS, bool GENERAL, int ACCEL, int INTEG, bool MEDIA = false>
+template <bool LDS, bool GENERAL, int ACCEL, int INTEG, bool MEDIA = false, bool POOL = false>
 __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, RenderK rk, double* __restrict__ ring, double* accum,
                                                       unsigned int* tickets, unsigned int* __restrict__ counter, int* __restrict__ err) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1389,6 +1548,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
     uint32_t* wst = book + (size_t)(PT_BLOCK / 64) * RING_UNITS * 4 + (size_t)wave * 8;
     int* cfg = (int*)(book + (size_t)(PT_BLOCK / 64) * (RING_UNITS * 4 + 8));
     if (lane < 8) wst[lane] = (lane == 6) ? 1u : 0u;  // nothing in flight, no job yet, jobs left
+    if (POOL && lane < RING_UNITS * 4) rmeta[lane] = 0u;  // no slot in use (next_unit_pool reads the flags of slots it never wrote)
     if (threadIdx.x == 0) {
         cfg[CFG_N_JOBS] = rk.n_units; cfg[CFG_TILES_OWNED] = rk.tiles_owned; cfg[CFG_JOB_UNITS] = rk.job_units;
         cfg[CFG_SUBS_PER_TILE] = rk.subs_per_tile; cfg[CFG_WORLD] = rk.world; cfg[CFG_RANK] = rk.rank; cfg[CFG_TILES_X] = rk.tiles_x;
@@ -1443,7 +1603,10 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
                                                                               __HIP_MEMORY_SCOPE_WORKGROUP)) == 0u;
             }
             if (need_unit || head_ready) {
-                const UnitInfo u = uniform_unit(next_unit(wst, rmeta, cfg, wring, accum, tickets, counter, need_unit && dead == ~0ull, lane, need_unit));
+                // (POOL: a variant of its own -- the function called here decides which registers the loop may keep across the call, and the
+                // whole-frame kernel lost 1.4 % when it could reach both)
+                const UnitInfo u = uniform_unit(POOL ? next_unit_pool(wst, rmeta, cfg, wring, accum, tickets, counter, need_unit && dead == ~0ull, lane, need_unit)
+                                                     : next_unit(wst, rmeta, cfg, wring, accum, tickets, counter, need_unit && dead == ~0ull, lane, need_unit));
                 if (need_unit) {
                     if (u.pool > 0) {
                         pool = u.pool;
@@ -2149,6 +2312,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
     }
     if (threadIdx.x < 8) cnt[threadIdx.x] = (threadIdx.x == 5) ? (uint32_t)rk.coop_pool : 0u;  // FQ tail = number of slots
     if (lane < 8) wst[lane] = (lane == 6) ? 1u : 0u;
+    if (EARLY && lane < RING_UNITS * 4) rmeta[lane] = 0u;  // no slot in use (next_unit_pool)
     if (threadIdx.x == 0) {
         cfg[CFG_N_JOBS] = rk.n_units; cfg[CFG_TILES_OWNED] = rk.tiles_owned; cfg[CFG_JOB_UNITS] = rk.job_units;
         cfg[CFG_SUBS_PER_TILE] = rk.subs_per_tile; cfg[CFG_WORLD] = rk.world; cfg[CFG_RANK] = rk.rank; cfg[CFG_TILES_X] = rk.tiles_x;
@@ -2222,7 +2386,8 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
                                                                               __HIP_MEMORY_SCOPE_WORKGROUP)) == 0u;
             }
             if (need_unit || head_ready) {
-                const UnitInfo u = next_unit(wst, rmeta, cfg, wring, accum, tickets, counter, false, lane, need_unit);
+                const UnitInfo u = (EARLY && rk.pool_mode != 0) ? next_unit_pool(wst, rmeta, cfg, wring, accum, tickets, counter, false, lane, need_unit)
+                                                                : next_unit(wst, rmeta, cfg, wring, accum, tickets, counter, false, lane, need_unit);
                 if (need_unit) {
                     if (u.pool > 0) {
                         pool = u.pool;
@@ -2471,7 +2636,8 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
         if (__ballot(alive) == 0ull && next >= pool && ring_len(C.aq) == 0u && __ballot(dec_slot >= 0) == 0ull) {
             bool got_unit = false;
             if (!finished) {  // units still running somewhere (parked, or adopted by other waves)
-                const UnitInfo u = next_unit(wst, rmeta, cfg, wring, accum, tickets, counter, false, lane);
+                const UnitInfo u = (EARLY && rk.pool_mode != 0) ? next_unit_pool(wst, rmeta, cfg, wring, accum, tickets, counter, false, lane)
+                                                                : next_unit(wst, rmeta, cfg, wring, accum, tickets, counter, false, lane);
                 if (u.pool > 0) {
                     pool = u.pool;
                     next = 0;
@@ -2783,6 +2949,13 @@ static pt_fn pick_pt_kernel(bool lds, bool general, int integ) {
     return lds ? (general ? pt_kernel<true, true, ACCEL, 0> : pt_kernel<true, false, ACCEL, 0>)
                : (general ? pt_kernel<false, true, ACCEL, 0> : pt_kernel<false, false, ACCEL, 0>);
 }
+// the POOL variants (out-of-order fold for a rank that owns fewer tiles than the GPU has waves) exist for kernel 2
+static pt_fn pick_pt_kernel_pool(bool lds, bool general, int integ) {
+    if (integ == 1) return lds ? pt_kernel<true, true, 2, 1, false, true> : pt_kernel<false, true, 2, 1, false, true>;
+    if (integ == 2) return lds ? pt_kernel<true, true, 2, 2, false, true> : pt_kernel<false, true, 2, 2, false, true>;
+    return lds ? (general ? pt_kernel<true, true, 2, 0, false, true> : pt_kernel<true, false, 2, 0, false, true>)
+               : (general ? pt_kernel<false, true, 2, 0, false, true> : pt_kernel<false, false, 2, 0, false, true>);
+}
 
 static void render_tiles_wf(const rt_scene& s, const FlatView& view, const CameraDev& cam, const RenderPlan& plan, const Tuning& tun, double* d_tiles,
                             hipStream_t stream, rt_stats* st, int dev, const DevInfo& di, uint32_t stack6, uint32_t n_entry6, size_t lds_pt, uint32_t stack6w,
@@ -2893,6 +3066,13 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
     HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, fptr, PT_BLOCK, smem));
     if (blocks_per_cu < 1) blocks_per_cu = 1;
     const int grid = di.cus * blocks_per_cu;
+    // a rank that owns fewer tiles than the launch has waves: single-unit jobs (below) folded out of order (next_unit_pool)
+    const bool pool = POOL_MODE && SINGLE_UNITS_BELOW_WAVES && plan.tiles_owned < (int64_t)grid * (PT_BLOCK / 64) &&
+                      ((kernel == 2 && !media) || (kernel == 5 && fn_coop == fn_coop_early));
+    if (pool && kernel == 2) {
+        fn = pick_pt_kernel_pool(lds, general, integ);  // (same resources as the variant the occupancy was asked for)
+        if (smem > 48 * 1024) HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    }
 
     const int64_t n_pix = plan.tiles_owned * TILE_PIX;
     // workspace: RING_UNITS unit buffers (12 KB) per resident wave -- independent of the image -- plus accumulator and tickets
@@ -2926,6 +3106,7 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
         const bool tiles_cover_waves = !SINGLE_UNITS_BELOW_WAVES || plan.tiles_owned >= (int64_t)grid * (PT_BLOCK / 64);
         rk.job_units = std::max(1, std::min(many_units && tiles_cover_waves ? JOB_UNITS : 1, rk.subs_per_tile));
         rk.tiles_owned = (int)std::max<int64_t>(1, plan.tiles_owned);
+        rk.pool_mode = pool ? 1 : 0;  // (job_units is 1: the rank's tiles do not cover the waves)
         Schedule sch;
         const int jobs_per_tile = make_schedule(sch, rk.tiles_owned, grid * (PT_BLOCK / 64), rk.s_begin, rk.s_end, rk.sub_spp, rk.job_units);  // host/schedule.cpp
         static_assert(sizeof(rk.lvl) == sizeof(sch.lvl), "RenderK::lvl is Schedule::lvl");
