@@ -482,8 +482,9 @@ static RenderPlan make_plan(const rt_params* p) {
     pl.sub_spp = std::max(std::min(chunk, 4), std::min(sub, 8));
     const int tun_sub_spp = tuning().sub_spp;
     if (tun_sub_spp > 0) pl.sub_spp = std::max(1, std::min(std::min(chunk, 8), tun_sub_spp));  // rt_tuning (A/B runs)
-    {   // at most 2^31 work units per launch
-        const int64_t max_chunk = ((int64_t(1) << 31) - 1) / std::max<int64_t>(1, pl.tiles_owned) * pl.sub_spp;
+    {   // at most 2^31 jobs per launch; 2^30 uniform units leave room for the tapered end of the schedule (host/schedule.cpp: up to
+        // 1.2x as many units as a uniform cut, single-unit jobs)
+        const int64_t max_chunk = (int64_t(1) << 30) / std::max<int64_t>(1, pl.tiles_owned) * pl.sub_spp;
         if (max_chunk < 1) throw RtError(RT_ERR_UNSUPPORTED, "image too large for one rank");
         if (chunk > max_chunk) chunk = (int)max_chunk;
     }
