@@ -6,7 +6,7 @@ set -o pipefail
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 OUT=gpurun_out/r03_final; rm -rf $OUT; mkdir -p $OUT
-echo "== headline PMC"; tools/r03_headline_pmc.sh final > $OUT/headline_pmc.log 2>&1 || { tail -5 $OUT/headline_pmc.log; exit 1; }
+echo "== headline PMC (the bench workload itself: 1000 spp)"; SPP=1000 tools/r03_headline_pmc.sh final > $OUT/headline_pmc.log 2>&1 || { tail -5 $OUT/headline_pmc.log; exit 1; }
 cp gpurun_out/r03_pmc_final/pt_kernel_model.json profiles/pt_kernel_model.json
 echo "== config PMC"; tools/r03_config_pmc.sh > $OUT/config_pmc.log 2>&1 || { tail -5 $OUT/config_pmc.log; exit 1; }
 for c in scene_10 scene_500_c2 cornell cornell_mix c4 c5r; do cp gpurun_out/r03_cfgpmc_$c/model_$c.json profiles/r03/model_$c.json; done
