@@ -4,7 +4,7 @@
 set -o pipefail
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-declare -A SPP=( [scene_10]=100 [scene_500_c2]=96 [cornell]=96 [cornell_mix]=96 [c4]=64 [c5r]=32 )
+declare -A SPP=( [scene_10]=100 [scene_500_c2]=500 [cornell]=2000 [cornell_mix]=2000 [c4]=1000 [c5r]=500 )  # the spp tools/config_bench.py times them with
 declare -A PIX=( [scene_10]=$((400*225)) [scene_500_c2]=$((1200*800)) [cornell]=$((800*800)) [cornell_mix]=$((800*800)) [c4]=$((1200*1200)) [c5r]=$((1600*1600)) )
 for CFG in ${@:-scene_10 scene_500_c2 cornell cornell_mix c4 c5r}; do
   OUT=gpurun_out/r03_cfgpmc_$CFG; rm -rf $OUT; mkdir -p $OUT
