@@ -83,7 +83,7 @@ typedef struct rt_params {
     int32_t spp;         /* sample_per_pixel (camera.rs:73) default 256 */
     int32_t max_depth;   /* photon_mapper.rs:334 default 50 */
     double t_min;        /* photon_mapper.rs:335 default 0.001 */
-    uint64_t seed;       /* rtamd-rng-2 stream seed (replaces thread_rng) */
+    uint64_t seed;       /* rtamd-rng-3 stream seed (replaces thread_rng) */
     int32_t rank;        /* image-tile partition: this call renders tiles t with t % world == rank */
     int32_t world;       /* 1 = whole image */
     int32_t spp_chunk;   /* samples per pixel per kernel launch; 0 = all in one launch */
@@ -195,7 +195,7 @@ int rt_object_triangle(rt_scene* s, int mesh, uint32_t a, uint32_t b, uint32_t c
 /* impl Hitable for Vec<Arc<dyn Hitable>> (objects/hit.rs:56-93) */
 int rt_object_list(rt_scene* s, int n, const int* objects);
 /* BVHNode::construct(left,right) (bvh.rs:47-58) and BVHNode::new(src_objects) (bvh.rs:60-83; split axes from
- * the seeded rtamd-rng-2 "bvh" stream instead of thread_rng) */
+ * the seeded rtamd-rng-3 "bvh" stream instead of thread_rng) */
 int rt_object_bvh_node(rt_scene* s, int left, int right);
 int rt_object_bvh_build(rt_scene* s, int n, const int* objects, uint64_t bvh_seed);
 /* Hitable::bounding_box (objects/hit.rs:53): out = min[3], max[3]; RT_ERR_NO_BBOX for None */
@@ -301,10 +301,14 @@ int rt_tonemap_u8(const double* rgb, size_t n_channels, uint8_t* out);
 int rt_write_png(const char* path, int width, int height, const uint8_t* rgb);
 
 /* ---- diagnostics used by the parity tests ------------------------------- */
-/* rtamd-rng-2: first n u64 draws of stream (seed, pixel, sample) computed ON THE DEVICE */
+/* rtamd-rng-3 (csrc/common/rng.h): first n u64 draws of stream (seed, pixel, sample) computed ON THE DEVICE */
 int rt_debug_rng_device(uint64_t seed, uint64_t pixel, uint64_t sample, int n, uint64_t* out_host);
 /* host-side restatement of the same stream (used by BVHNode::new's axis draws) */
 int rt_debug_rng_host(uint64_t seed, uint64_t pixel, uint64_t sample, int n, uint64_t* out_host);
+/* the float conversions of the spec (rand 0.8.4's): out_gen[i] = the i-th gen::<f64>() of a fresh stream (seed, pixel, sample),
+ * out_range[i] = the i-th gen_range(lo..hi) of another fresh stream of the same key; on_device != 0 computes them in a kernel */
+int rt_debug_rng_floats(uint64_t seed, uint64_t pixel, uint64_t sample, int n, double lo, double hi, int on_device, double* out_gen,
+                        double* out_range);
 /* device f64 sqrt / divide / rtamd-ln-1, element-wise: op 0 = sqrt(a), 1 = a/b, 2 = det_ln(a) */
 int rt_debug_math_device(int op, size_t n, const double* a_host, const double* b_host, double* out_host);
 /* closest hit of explicit world-space rays through device traversal `kernel` (1, 2, or 3 = kernel 2's LDS node table "NodeW" with

@@ -80,6 +80,7 @@ def lib():
     L.orc_tonemap_u8.argtypes = [c_double_p, C.c_size_t, c_u8_p]
     L.orc_rng_stream.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, c_u64_p]
     L.orc_rng_f64.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, c_double_p]
+    L.orc_rng_range.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_double, C.c_double, c_double_p]
     L.orc_sample_helper.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, c_double_p, c_double_p]
     L.orc_vec3_op.argtypes = [C.c_int, c_double_p, c_double_p, C.c_double, c_double_p]
     L.orc_schlick.restype = C.c_double
@@ -309,6 +310,12 @@ def rng_u64(seed, pixel, sample, n):
 def rng_f64(seed, pixel, sample, n):
     out = (C.c_double * n)()
     lib().orc_rng_f64(seed, pixel, sample, n, out)
+    return [float(x) for x in out]
+
+
+def rng_range(seed, pixel, sample, n, lo, hi):
+    out = (C.c_double * n)()
+    lib().orc_rng_range(seed, pixel, sample, n, lo, hi, out)
     return [float(x) for x in out]
 
 

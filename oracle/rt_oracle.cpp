@@ -23,7 +23,7 @@
 //
 // DELIBERATE DIVERGENCES FROM THE REFERENCE (all documented in DESIGN.md)
 //   D1. RNG: rand::thread_rng() -> counter-based stream keyed by (seed, pixel,
-//       sample) (spec rtamd-rng-2: SplitMix64-hashed key, xoroshiro64** draws);
+//       sample) (spec rtamd-rng-3: SplitMix64-hashed key, xoroshiro64** draws);
 //       draws inside a sample are sequential in the reference's call order.
 //   D2. sample_ray: on a Diffuse interaction the path CONTINUES
 //       (throughput *= attenuation; ray = scattered), i.e. the two lines the
@@ -97,20 +97,24 @@ static inline bool v_near_zero(Vec3 a) {  // :92-95
 static inline double v_max(Vec3 a) { return std::fmax(std::fmax(a.x, a.y), a.z); }  // :57-59
 
 // ----------------------------------------------------------------------------
-// RNG (divergence D1).  Spec "rtamd-rng-2" -- restated independently in the
+// RNG (divergence D1).  Spec "rtamd-rng-3" -- restated independently in the
 // product (rust-raytracer_amd/csrc/common/rng.h); pinned against each other by
 // tests/golden/rng_kat.json.
 //   stream key (SplitMix64 finaliser; Steele, Lea, Flood 2014; public-domain reference by Vigna):
 //                state = mix(mix(seed + G*(pixel+1)) + H*(sample+1)), G if that is 0; (s0, s1) = its (low, high) halves
-//   generator:   xoroshiro64** (Blackman & Vigna 2018; public-domain reference), 32 bits per draw
-//   gen::<f64>() = u32 * 2^-32                     in [0,1)
-//   gen_range(lo..hi) = lo + (hi - lo) * gen::<f64>()
-//   gen_range(0..3)   = (u32 * 3) >> 32
-//   u64 draws (debug / KAT entry points only) = two u32 draws, the first in the high half
+//   generator:   xoroshiro64** (Blackman & Vigna 2018; public-domain reference), 32 bits per step
+//   next_u64     = two steps, the first in the high half
+//   The float conversions are those of the reference's `rand 0.8.4` (Cargo.lock:836-837; the crate is not under /root/reference,
+//   restated from its published algorithm):
+//   gen::<f64>() = (next_u64 >> 11) as f64 * 2^-53                  `Standard`, 53 bits, [0,1)       (distributions/float.rs)
+//   gen_range(lo..hi) = `UniformFloat::sample_single`: v = from_bits(exponent 0 | next_u64 >> 12) - 1.0  (52 bits);
+//                  res = v * (hi - lo) + lo; return it if res < hi, otherwise (rounding reached the open end) draw again with
+//                  `scale` one ulp smaller.  At the reference's call sites (lo = -1 or 0) the retry cannot happen.
+//   gen_range(0..3)   = (u32 * 3) >> 32            (BVHNode::new's axis only, D3; rand's widening-multiply-with-rejection is not restated)
 // ----------------------------------------------------------------------------
 struct Rng {
     uint32_t s0, s1;
-    uint64_t draws = 0;  // numbers drawn so far (orc_hit_rng reports it)
+    uint64_t draws = 0;  // random NUMBERS drawn so far (a gen::<f64>() / gen_range is one; orc_hit_rng reports it)
     static inline uint64_t mix(uint64_t z) {
         z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
         z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
@@ -126,7 +130,6 @@ struct Rng {
         s1 = (uint32_t)(s >> 32);
     }
     inline uint32_t next_u32() {
-        draws++;
         const uint32_t r = rotl(s0 * 0x9E3779BBu, 5) * 5u;
         s1 ^= s0;
         s0 = rotl(s0, 26) ^ s1 ^ (s1 << 9);
@@ -137,9 +140,27 @@ struct Rng {
         const uint64_t hi = next_u32();
         return (hi << 32) | (uint64_t)next_u32();
     }
-    inline double gen_f64() { return (double)next_u32() * (1.0 / 4294967296.0); }
-    inline double gen_range(double lo, double hi) { return lo + (hi - lo) * gen_f64(); }
-    inline uint32_t gen_below3() { return (uint32_t)(((uint64_t)next_u32() * 3ULL) >> 32); }  // gen_range(0..3)
+    inline double gen_f64() {
+        draws++;
+        return (double)(next_u64() >> 11) * (1.0 / 9007199254740992.0);
+    }
+    inline double gen_range(double lo, double hi) {
+        draws++;
+        double scale = hi - lo;
+        for (;;) {
+            const uint64_t bits = (uint64_t(1023) << 52) | (next_u64() >> 12);  // into_float_with_exponent(0): [1, 2)
+            double value1_2;
+            std::memcpy(&value1_2, &bits, sizeof(value1_2));
+            const double value0_1 = value1_2 - 1.0;
+            const double res = value0_1 * scale + lo;
+            if (res < hi) return res;
+            scale = std::nextafter(scale, 0.0);  // decrease_masked
+        }
+    }
+    inline uint32_t gen_below3() {  // gen_range(0..3)
+        draws++;
+        return (uint32_t)(((uint64_t)next_u32() * 3ULL) >> 32);
+    }
 };
 
 // vec3.rs:111-129 -- Marsaglia; returns a point ON the unit sphere (quirk Q3).
@@ -1487,7 +1508,7 @@ int orc_bvh_new(void* s, int n, const int* ids, uint64_t seed) {
         v.push_back(obj(sc, ids[i]));
     }
     try {
-        Rng rng(seed, 0xB7E151628AED2A6AULL, 0);  // BVH-build stream (spec rtamd-rng-2, "bvh" key)
+        Rng rng(seed, 0xB7E151628AED2A6AULL, 0);  // BVH-build stream (spec rtamd-rng-3, "bvh" key)
         return bvh_new(sc, v, rng)->id;
     } catch (const std::exception& e) {
         sc.err = e.what();
@@ -1774,6 +1795,10 @@ void orc_rng_stream(uint64_t seed, uint64_t pixel, uint64_t sample, int n, uint6
 void orc_rng_f64(uint64_t seed, uint64_t pixel, uint64_t sample, int n, double* out) {
     Rng r(seed, pixel, sample);
     for (int i = 0; i < n; i++) out[i] = r.gen_f64();
+}
+void orc_rng_range(uint64_t seed, uint64_t pixel, uint64_t sample, int n, double lo, double hi, double* out) {
+    Rng r(seed, pixel, sample);
+    for (int i = 0; i < n; i++) out[i] = r.gen_range(lo, hi);
 }
 // Sampling helpers KAT: which = 0 in_unit_sphere, 1 unit_vector, 2 in_unit_disk, 3 in_hemisphere(n)
 int orc_sample_helper(int which, uint64_t seed, uint64_t pixel, uint64_t sample, const double* n3, double* out3) {

@@ -733,6 +733,23 @@ int rt_debug_rng_host(uint64_t seed, uint64_t pixel, uint64_t sample, int n, uin
         return (int)RT_OK;
     });
 }
+int rt_debug_rng_floats(uint64_t seed, uint64_t pixel, uint64_t sample, int n, double lo, double hi, int on_device, double* out_gen,
+                        double* out_range) {
+    return guard([&] {
+        REQUIRE(n > 0 && out_gen && out_range && lo < hi && std::isfinite(hi - lo), "bad argument");
+        if (on_device) {
+            if (device_count() < 1) throw RtError(RT_ERR_NO_DEVICE, "no HIP device");
+            debug_rng_floats_device(seed, pixel, sample, n, lo, hi, out_gen, out_range);
+            return (int)RT_OK;
+        }
+        Rng r;
+        r.seed_stream(seed, pixel, sample);
+        for (int i = 0; i < n; i++) out_gen[i] = r.gen_f64();
+        r.seed_stream(seed, pixel, sample);
+        for (int i = 0; i < n; i++) out_range[i] = r.gen_range(lo, hi);
+        return (int)RT_OK;
+    });
+}
 int rt_debug_math_device(int op, size_t n, const double* a_host, const double* b_host, double* out_host) {
     return guard([&] {
         REQUIRE(n > 0 && a_host && out_host && (op == 0 || op == 2 || (op == 1 && b_host)), "bad argument");

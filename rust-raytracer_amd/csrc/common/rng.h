@@ -1,4 +1,4 @@
-// rtamd-rng-2: the counter-based integer RNG that replaces rand::thread_rng()
+// rtamd-rng-3: the counter-based integer RNG that replaces rand::thread_rng()
 // (vec3.rs:98,103,112,154; material.rs:37,172; camera.rs:90; bvh.rs:61-62).
 //
 // Spec (shared by host and device code of the product; restated independently
@@ -13,10 +13,15 @@
 //   next_u32 (xoroshiro64**, Blackman & Vigna 2018):
 //            r  = rotl(s0 * 0x9E3779BB, 5) * 5
 //            s1 ^= s0 ; s0 = rotl(s0, 26) ^ s1 ^ (s1 << 9) ; s1 = rotl(s1, 13) ; return r
-//   next_u64 = next_u32 << 32 | next_u32                     (first draw in the high half; debug / KAT entry points only)
-//   gen::<f64>()       = next_u32 * 2^-32                    in [0,1)
-//   gen_range(lo..hi)  = lo + (hi - lo) * gen::<f64>()
-//   gen_range(0..3)    = (next_u32 * 3) >> 32
+//   next_u64 = next_u32 << 32 | next_u32                     (first draw in the high half)
+//   gen::<f64>()       = (next_u64 >> 11) * 2^-53            in [0,1), 53 bits: rand 0.8.4 `Standard` for f64
+//   gen_range(lo..hi)  = v * (hi - lo) + lo,  v = f64::from_bits(0x3FF0.. | next_u64 >> 12) - 1.0   (52 bits, multiply then add):
+//                        rand 0.8.4 `UniformFloat::sample_single` (also `Uniform::sample` of WeightedIndex's f64 weights).  Its retry
+//                        (`res >= hi`: rounding reached the open end) cannot happen at the reference's call sites -- lo is -1 or 0
+//                        (vec3.rs:118-119,156; light.rs:150,222): (1 - 2^-52) * 2 - 1 = 1 - 2^-51 exactly, and v * hi < hi for lo = 0 --
+//                        so it is not restated.
+//   gen_range(0..3)    = (next_u32 * 3) >> 32                (host only: BVHNode::new's axis, D3)
+// (rtamd-rng-2, rounds 2-3, drew gen::<f64>() as next_u32 * 2^-32: 2^21 times coarser than the reference's uniforms.)
 // pixel = y * width + x of the FULL frame, sample = index in 0..spp: the value of
 // a sample never depends on how the image is tiled, chunked or spread over GPUs.
 // (rtamd-rng-1, round 1, drew every number through the SplitMix64 finaliser: two 64-bit multiplies = eight quarter-rate
@@ -58,8 +63,17 @@ struct Rng {
         const uint64_t hi = next_u32();
         return (hi << 32) | (uint64_t)next_u32();
     }
-    RT_HD double gen_f64() { return (double)next_u32() * (1.0 / 4294967296.0); }
-    RT_HD double gen_range(double lo, double hi) { return lo + (hi - lo) * gen_f64(); }
+    RT_HD double gen_f64() {  // both halves convert exactly; the sum has 53 bits
+        const uint32_t hi = next_u32(), lo = next_u32();
+        return (double)hi * (1.0 / 4294967296.0) + (double)(lo >> 11) * (1.0 / 9007199254740992.0);
+    }
+    RT_HD double gen_range(double lo, double hi) {
+        const uint32_t h = next_u32(), l = next_u32();
+        const uint64_t bits = 0x3FF0000000000000ULL | ((uint64_t)(h >> 12) << 32) | (uint64_t)((h << 20) | (l >> 12));
+        double v12;
+        __builtin_memcpy(&v12, &bits, sizeof(v12));
+        return (v12 - 1.0) * (hi - lo) + lo;
+    }
     RT_HD uint32_t gen_below3() { return (uint32_t)(((uint64_t)next_u32() * 3ULL) >> 32); }
 };
 

@@ -31,6 +31,7 @@ void render_sppm(const rt_scene& s, const CameraDev& cam, RenderPlan plan, const
                  void* stream, rt_stats* st, uint64_t* totals2);
 void assemble_frame(const RenderPlan& plan, const double* d_gathered, int64_t tiles_per_rank_stride, double* d_frame, void* stream);
 void debug_rng_device(uint64_t seed, uint64_t pixel, uint64_t sample, int n, uint64_t* out_host);
+void debug_rng_floats_device(uint64_t seed, uint64_t pixel, uint64_t sample, int n, double lo, double hi, double* out_gen, double* out_range);
 void debug_math_device(int op, size_t n, const double* a, const double* b, double* out);
 void debug_hit_device(const rt_scene& s, int kernel, size_t n, const double* rays, double t_min, double t_max, double* out);
 int device_count();

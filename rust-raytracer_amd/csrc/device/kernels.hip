@@ -2718,6 +2718,14 @@ __global__ void rng_kernel(uint64_t seed, uint64_t pixel, uint64_t sample, int n
     r.seed_stream(seed, pixel, sample);
     for (int i = 0; i < n; i++) out[i] = r.next_u64();
 }
+__global__ void rng_floats_kernel(uint64_t seed, uint64_t pixel, uint64_t sample, int n, double lo, double hi, double* out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    Rng r;
+    r.seed_stream(seed, pixel, sample);
+    for (int i = 0; i < n; i++) out[i] = r.gen_f64();
+    r.seed_stream(seed, pixel, sample);
+    for (int i = 0; i < n; i++) out[n + i] = r.gen_range(lo, hi);
+}
 __global__ void math_kernel(int op, size_t n, const double* a, const double* b, double* out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -3685,6 +3693,14 @@ void debug_rng_device(uint64_t seed, uint64_t pixel, uint64_t sample, int n, uin
     hipLaunchKernelGGL(rng_kernel, dim3(1), dim3(64), 0, 0, seed, pixel, sample, n, (uint64_t*)b.p);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemcpy(out_host, b.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+}
+void debug_rng_floats_device(uint64_t seed, uint64_t pixel, uint64_t sample, int n, double lo, double hi, double* out_gen, double* out_range) {
+    DevBuf b;
+    b.alloc((size_t)n * 16);
+    hipLaunchKernelGGL(rng_floats_kernel, dim3(1), dim3(64), 0, 0, seed, pixel, sample, n, lo, hi, (double*)b.p);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpy(out_gen, b.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(out_range, (const char*)b.p + (size_t)n * 8, (size_t)n * 8, hipMemcpyDeviceToHost));
 }
 void debug_math_device(int op, size_t n, const double* a, const double* bb, double* out) {
     DevBuf da, db, dc;

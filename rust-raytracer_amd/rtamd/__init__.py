@@ -152,6 +152,7 @@ _SIGS = [
     ("rt_write_png", C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_uint8)]),
     ("rt_debug_rng_device", C.c_int, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_uint64)]),
     ("rt_debug_rng_host", C.c_int, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_uint64)]),
+    ("rt_debug_rng_floats", C.c_int, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_double, C.c_double, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("rt_debug_math_device", C.c_int, [C.c_int, C.c_size_t, _dp, _dp, _dp]),
     ("rt_debug_hit_device", C.c_int, [C.c_void_p, C.c_int, C.c_size_t, _dp, C.c_double, C.c_double, _dp]),
     ("rt_debug_schedule", C.c_int, [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
@@ -559,6 +560,13 @@ def debug_rng(seed, pixel, sample, n, device=True):
     fn = lib().rt_debug_rng_device if device else lib().rt_debug_rng_host
     _chk(fn(int(seed), int(pixel), int(sample), n, out))
     return [int(x) for x in out]
+
+
+def debug_rng_floats(seed, pixel, sample, n, lo=-1.0, hi=1.0, device=True):
+    """(first n gen::<f64>(), first n gen_range(lo..hi)) of stream (seed, pixel, sample), computed by the device or the host code"""
+    g, r = (C.c_double * n)(), (C.c_double * n)()
+    _chk(lib().rt_debug_rng_floats(int(seed), int(pixel), int(sample), n, float(lo), float(hi), 1 if device else 0, g, r))
+    return [float(x) for x in g], [float(x) for x in r]
 
 
 def debug_math(op, a, b=None):

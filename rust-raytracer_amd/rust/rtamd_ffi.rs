@@ -242,6 +242,7 @@ extern "C" {
     // diagnostics used by the parity tests
     pub fn rt_debug_rng_device(seed: u64, pixel: u64, sample: u64, n: c_int, out_host: *mut u64) -> c_int;
     pub fn rt_debug_rng_host(seed: u64, pixel: u64, sample: u64, n: c_int, out_host: *mut u64) -> c_int;
+    pub fn rt_debug_rng_floats(seed: u64, pixel: u64, sample: u64, n: c_int, lo: f64, hi: f64, on_device: c_int, out_gen: *mut f64, out_range: *mut f64) -> c_int;
     pub fn rt_debug_math_device(op: c_int, n: usize, a_host: *const c_double, b_host: *const c_double, out_host: *mut c_double) -> c_int;
     pub fn rt_debug_hit_device(s: *const rt_scene, kernel: c_int, n: usize, rays_host: *const c_double, t_min: c_double, t_max: c_double, out_host: *mut c_double) -> c_int;
     pub fn rt_debug_schedule(tiles_owned: i64, n_waves: c_int, s_begin: c_int, s_end: c_int, sub_spp: c_int, job_units: c_int, out25: *mut c_int) -> c_int;

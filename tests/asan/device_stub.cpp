@@ -8,6 +8,7 @@ void render_tiles(const rt_scene&, const CameraDev&, const RenderPlan&, double*,
 void render_sppm(const rt_scene&, const CameraDev&, RenderPlan, const rt_sppm_config&, double*, double*, void*, rt_stats*, uint64_t*) { none(); }
 void assemble_frame(const RenderPlan&, const double*, int64_t, double*, void*) { none(); }
 void debug_rng_device(uint64_t, uint64_t, uint64_t, int, uint64_t*) { none(); }
+void debug_rng_floats_device(uint64_t, uint64_t, uint64_t, int, double, double, double*, double*) { none(); }
 void debug_math_device(int, size_t, const double*, const double*, double*) { none(); }
 void debug_hit_device(const rt_scene&, int, size_t, const double*, double, double, double*) { none(); }
 int device_count() { return 0; }

@@ -116,7 +116,8 @@ def test_host_rng_matches_oracle_spec():
 
 
 def test_rng_golden_vector():
-    """tests/golden/rng_kat.json pins spec rtamd-rng-2 for both restatements."""
+    """tests/golden/rng_kat.json (from a pure-Python restatement) pins spec rtamd-rng-3 -- the integer stream and rand 0.8.4's two float
+    conversions -- for both C++ restatements."""
     import json
     import oracle
     import rtamd
@@ -126,7 +127,31 @@ def test_rng_golden_vector():
         exp = [int(x, 16) for x in case["u64_hex"]]
         assert oracle.rng_u64(*key, len(exp)) == exp
         assert rtamd.debug_rng(*key, len(exp), device=False) == exp
-        assert oracle.rng_f64(*key, 2) == case["f64_first2"]
+        assert oracle.rng_f64(*key, 4) == case["f64_first4"]
+        assert oracle.rng_range(*key, 4, -1.0, 1.0) == case["range_m1_1_first4"]
+        assert oracle.rng_range(*key, 4, 0.0, 7.0) == case["range_0_7_first4"]
+        g, r = rtamd.debug_rng_floats(*key, 4, -1.0, 1.0, device=False)
+        assert g == case["f64_first4"] and r == case["range_m1_1_first4"]
+        assert rtamd.debug_rng_floats(*key, 4, 0.0, 7.0, device=False)[1] == case["range_0_7_first4"]
+
+
+def test_float_draws_have_the_resolution_of_rand_0_8_4():
+    """gen::<f64>() = k * 2^-53 (53 bits, Standard), gen_range = 52 mantissa bits scaled: both below the open end, also for the
+    all-ones draw (the retry of UniformFloat::sample_single cannot happen for lo in {-1, 0}); product host code == oracle on many streams."""
+    import oracle
+    import rtamd
+    low_bits = 0
+    for key in [(3, p, s) for p in range(40) for s in range(5)]:
+        g, r = rtamd.debug_rng_floats(*key, 8, -1.0, 1.0, device=False)
+        assert g == oracle.rng_f64(*key, 8) and r == oracle.rng_range(*key, 8, -1.0, 1.0)
+        for x in g:
+            k = x * 2.0 ** 53
+            assert 0.0 <= x < 1.0 and k == int(k)
+            low_bits |= int(k) & 0x1FFFFF                      # the 21 bits a 32-bit draw does not have
+        assert all(-1.0 <= x < 1.0 for x in r)
+    assert low_bits == 0x1FFFFF
+    top = (2 ** 52 - 1) * 2.0 ** -52                           # the largest value of from_bits(0x3FF0.. | u64 >> 12) - 1
+    assert top * 2.0 + -1.0 < 1.0 and top * 1.0 + 0.0 < 1.0 and top * 7.25 + 0.0 < 7.25
 
 
 def test_tonemap_host_matches_oracle():

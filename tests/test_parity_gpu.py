@@ -41,6 +41,10 @@ def test_rng_device_matches_oracle_and_host():
         host = rtamd.debug_rng(*key, 64, device=False)
         ref = oracle.rng_u64(*key, 64)
         assert dev == ref == host
+        for lo, hi in [(-1.0, 1.0), (0.0, 1.0), (0.0, 7.25)]:   # the float conversions of the spec, computed by the device code
+            g, r = rtamd.debug_rng_floats(*key, 64, lo, hi, device=True)
+            assert g == oracle.rng_f64(*key, 64) and r == oracle.rng_range(*key, 64, lo, hi)
+            assert (g, r) == rtamd.debug_rng_floats(*key, 64, lo, hi, device=False)
 
 
 def test_device_sqrt_and_divide_are_correctly_rounded():

@@ -1,5 +1,5 @@
-"""Statistics of the shipped RNG (rtamd-rng-2, csrc/common/rng.h): gen::<f64>() = next_u32 * 2^-32 of a
-xoroshiro64** stream keyed by (seed, pixel, sample).  The path tracer uses ADJACENT keys (neighbouring pixels, consecutive
+"""Statistics of the shipped RNG (rtamd-rng-3, csrc/common/rng.h): gen::<f64>() = (next_u64 >> 11) * 2^-53 (rand 0.8.4's
+conversion) of a xoroshiro64** stream keyed by (seed, pixel, sample); a next_u64 is two 32-bit steps.  The path tracer uses ADJACENT keys (neighbouring pixels, consecutive
 sample indices), so uniformity and independence are checked across adjacent keys as well as along a stream, on the product's
 host implementation (rt_debug_rng_host through the C ABI) and on the oracle's independent restatement; the device
 implementation is pinned to both bit for bit elsewhere (tests/test_parity_gpu.py::test_rng_device_matches_oracle_and_host).
@@ -15,7 +15,7 @@ def _first_draws(draw_fn, seed, pixels, samples):
     out = np.empty((len(pixels), len(samples)))
     for i, p in enumerate(pixels):
         for j, s in enumerate(samples):
-            out[i, j] = (int(draw_fn(seed, p, s, 1)[0]) >> 32) * 2.0 ** -32     # gen_f64 = the first next_u32 = high half of next_u64
+            out[i, j] = (int(draw_fn(seed, p, s, 1)[0]) >> 11) * 2.0 ** -53     # gen_f64 of the first next_u64
     return out
 
 
@@ -38,8 +38,8 @@ def test_first_draws_of_adjacent_keys_are_uniform_and_uncorrelated(which):
     r_pix = (x[:-1] * x[1:]).sum() / (x * x).sum()              # neighbouring pixels, same sample index
     r_smp = (x[:, :-1] * x[:, 1:]).sum() / (x * x).sum()        # consecutive samples of one pixel
     assert abs(r_pix) < 4.0 / np.sqrt(n) and abs(r_smp) < 4.0 / np.sqrt(n), (r_pix, r_smp)
-    bits = (f.ravel() * 2.0 ** 32).astype(np.uint64)
-    for b in range(32):                                         # every one of the 32 bits is balanced
+    bits = (f.ravel() * 2.0 ** 53).astype(np.uint64)
+    for b in range(53):                                         # every one of the 53 bits is balanced
         ones = int(((bits >> np.uint64(b)) & np.uint64(1)).sum())
         assert abs(ones - n / 2) < 4.5 * np.sqrt(n) / 2, (b, ones)
 
@@ -57,7 +57,13 @@ def test_draws_along_one_stream_are_uniform_and_uncorrelated(which):
     for lag in (1, 2, 3):
         r = (x[:-lag] * x[lag:]).sum() / (x * x).sum()
         assert abs(r) < 4.0 / np.sqrt(n), (lag, r)
-    assert f.min() >= 0.0 and f.max() < 1.0                     # [0, 1): 1.0 is never produced (the largest value is 1 - 2^-32)
+    assert f.min() >= 0.0 and f.max() < 1.0                     # [0, 1): 1.0 is never produced
+    g = (u >> np.uint64(11)).astype(np.float64) * 2.0 ** -53    # the same stream as 53-bit draws (two steps each)
+    x = g - 0.5
+    for lag in (1, 2, 3):
+        r = (x[:-lag] * x[lag:]).sum() / (x * x).sum()
+        assert abs(r) < 4.0 / np.sqrt(g.size), (lag, r)
+    assert g.min() >= 0.0 and g.max() < 1.0
 
 
 def _unxorshift(z, k):
@@ -77,8 +83,17 @@ def _unmix(z):
 
 
 def _key_with_first_draw_zero():
-    """(seed, pixel, sample) = (seed, 0, 0) whose stream starts in the state (s0, s1) = (0, 1): next_u32 = rotl(s0 * K, 5) * 5 = 0."""
-    s = 1 << 32
+    """(seed, pixel, sample) = (seed, 0, 0) whose first next_u64 has its upper 53 bits clear, i.e. gen::<f64>() == 0.0 exactly.
+    xoroshiro64**'s output is rotl(s0 * K, 5) * 5 with K and 5 odd: a state whose s0 is 0 outputs 0 (the high half); the next state's
+    s0 is s1 ^ (s1 << 9) -- an invertible map of s1 -- so s1 is chosen such that the second output is 1 (< 2^11)."""
+    K, M32 = 0x9E3779BB, (1 << 32) - 1
+    rotr = lambda x, k: ((x >> k) | (x << (32 - k))) & M32
+    s0_next = (rotr(pow(5, -1, 1 << 32) * 1 & M32, 5) * pow(K, -1, 1 << 32)) & M32   # rotl(s0' * K, 5) * 5 == 1
+    s1 = 0
+    for b in range(32):                                          # solve s1 ^ (s1 << 9) == s0_next bit by bit from the low end
+        s1 |= (((s0_next >> b) & 1) ^ ((s1 >> (b - 9)) & 1 if b >= 9 else 0)) << b
+    assert (s1 ^ (s1 << 9)) & M32 == s0_next and s1 != 0
+    s = s1 << 32
     h = (_unmix(s) - 0xD1B54A32D192ED03 * 1) & M64
     return (_unmix(h) - 0x9E3779B97F4A7C15 * 1) & M64, 0, 0
 
@@ -89,14 +104,14 @@ def test_a_zero_draw_exists_and_every_implementation_returns_it():
     key = _key_with_first_draw_zero()
     a = rtamd.debug_rng(*key, 3, device=False)
     b = oracle.rng_u64(*key, 3)
-    assert list(a) == list(b) and (int(a[0]) >> 32) == 0        # gen_f64() == 0.0 exactly
-    assert oracle.rng_f64(*key, 1)[0] == 0.0
-    assert (int(a[0]) & 0xFFFFFFFF) != 0                         # ... and the stream goes on normally
+    assert list(a) == list(b) and int(a[0]) == 1                 # 53 upper bits clear: gen_f64() == 0.0 exactly
+    assert oracle.rng_f64(*key, 1)[0] == 0.0 and rtamd.debug_rng_floats(*key, 1, device=False)[0][0] == 0.0
+    assert int(a[1]) >> 11 != 0                                  # ... and the stream goes on normally
 
 
 def test_constant_medium_with_a_zero_draw_does_not_scatter():
     """gen::<f64>() == 0 -> ln(0) = -inf -> hit_distance = -1/density * -inf = +inf > any chord: the ray passes, whatever the
-    density (medium.rs:37-40); one draw is consumed.  With 32-bit draws this happens once per 2^32 medium crossings."""
+    density (medium.rs:37-40); one draw is consumed.  With 53-bit draws (the reference's) this happens once per 2^53 medium crossings."""
     import oracle
     o = oracle.Scene()
     iso = o.Isotropic(o.ConstantTexture((0.9, 0.8, 0.7)))
