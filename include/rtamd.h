@@ -133,12 +133,15 @@ typedef struct rt_tuning {
     int32_t max_leaf;              /* 1..4: accel builder, items per leaf; 0 auto (read at rt_scene_commit)             */
     int32_t sppm_photon_capacity;  /* > 0: initial photon-buffer capacity (forces the grow-and-retry path); 0 auto      */
     int32_t sppm_knn_candidates;   /* >= 0: k-nearest candidates kept in LDS (0 forces the out-of-LDS selection); -1 auto */
+    int32_t multi_force_rccl;      /* 1: rt_render_multi sends EVERY rank's rows through the RCCL communicator, also those that already sit on
+                                      the root device (a rank then sends to itself): exercises the exchange on a one-GPU box; 0 auto      */
     double sah_box_cost;           /* > 0: accel builder, SAH cost of a box-pair test relative to 2.0 per primitive; 0 auto */
 } rt_tuning;
 void rt_tuning_default(rt_tuning* t);
 int rt_tuning_set(const rt_tuning* t);
 /* The render entry points keep a workspace per device for the life of the process (unit rings of the resident waves, ~0.3 GB,
- * accumulator, tickets: no hipMalloc on the hot path).  This frees the idle ones; returns the bytes released. */
+ * accumulator, tickets: no hipMalloc on the hot path), rt_render_multi also its RCCL communicators.  This frees the idle ones;
+ * returns the bytes released. */
 int64_t rt_release_workspaces(void);
 
 /* ---- scene graph builders (one per reference constructor) ---------------- */
@@ -294,6 +297,33 @@ int64_t rt_tiles_owned(const rt_params* p);   /* tiles t in [0,total) with t % w
  * each padded to rt_tiles_owned of rank 0) into a row-major frame; both pointers DEVICE memory. */
 int rt_assemble_frame_device(const rt_params* p, const double* d_gathered, int64_t tiles_per_rank_stride, double* d_frame,
                              void* hip_stream);
+
+/* ---- the frame across the GPUs of one node ------------------------------------ */
+/* Camera::capture_image as the reference structures it (camera.rs:74-126: the worker pool, the jobs, the channel and the stitch are
+ * all INSIDE the call; main.rs:52-54 makes one call): one process, one host thread per logical rank.  The committed scene is
+ * replicated on every device; rank i renders the 8x8 tiles t with t % n_devices == i on device_ids[i]; the ranks' tile-major rows
+ * are gathered on device_ids[0] -- grouped ncclSend / ncclRecv over a communicator from ncclCommInitAll (RCCL, xGMI), cached per
+ * device list for the life of the process; rows of ranks that share the root's device are rendered in place -- stitched there
+ * (camera.rs:115-123) and copied once to out_rgb (HOST, height*width*3 f64).  The image is bit-identical to rt_render's for every
+ * device list (the RNG is keyed by pixel and sample).
+ *   device_ids: HIP ordinals, one per rank; an ordinal may repeat (its ranks share that device).  NULL = 0 .. n_devices-1.
+ *   n_devices:  number of ranks; 0 = one per visible device.
+ *   p->rank / p->world must be 0 / 1 (the call partitions the frame itself); p->device is ignored.
+ *   stats:      NULL or n_devices entries, entry i = rank i's render (kernel_ms, samples, ...).  stats[0].seconds = wall time of the
+ *               whole call, stats[0].reserved[2] = microseconds spent in the exchange + stitch + copy to the host,
+ *               stats[0].reserved[3] = number of rows that travelled through RCCL.
+ * Errors of any rank come back as that rank's rt_status (first failing rank wins); nothing aborts. */
+int rt_render_multi(const rt_scene* s, const rt_camera* cam, const rt_params* p, int n_devices, const int* device_ids, double* out_rgb,
+                    rt_stats* stats);
+/* the same for a host that owns a constructed Camera (its stored frame, camera.rs:12-21), as rt_render_camera_frame */
+int rt_render_multi_camera_frame(const rt_scene* s, const rt_camera_frame* frame, const rt_params* p, int n_devices, const int* device_ids,
+                                 double* out_rgb, rt_stats* stats);
+/* main.rs:52-54 as the reference really runs it, across GPUs: every rank repeats the deterministic SPPM pre-pass and renders its own
+ * tiles (rt_render_sppm_tiles_device), gathered and stitched as above. */
+int rt_render_sppm_multi(const rt_scene* s, const rt_camera* cam, const rt_params* p, const rt_sppm_config* cfg, int n_devices,
+                         const int* device_ids, double* out_rgb, rt_stats* stats);
+/* ncclGetVersion of the RCCL the library is linked with (e.g. 22606), 0 if it cannot be asked */
+int rt_rccl_version(void);
 
 /* From<Vec3> for Rgb<u8> (vec3.rs:223-231): floor(clamp(sqrt(c),0,1)*255), NaN -> 0.  Host buffers. */
 int rt_tonemap_u8(const double* rgb, size_t n_channels, uint8_t* out);

@@ -102,8 +102,10 @@ static inline double v_max(Vec3 a) { return std::fmax(std::fmax(a.x, a.y), a.z);
 // tests/golden/rng_kat.json.
 //   stream key (SplitMix64 finaliser; Steele, Lea, Flood 2014; public-domain reference by Vigna):
 //                state = mix(mix(seed + G*(pixel+1)) + H*(sample+1)), G if that is 0; (s0, s1) = its (low, high) halves
-//   generator:   xoroshiro64** (Blackman & Vigna 2018; public-domain reference), 32 bits per step
-//   next_u64     = two steps, the first in the high half
+//   generator:   the xoroshiro64 engine (Blackman & Vigna 2018; public-domain reference); ONE step yields 64 bits:
+//                upper half = xoroshiro64**'s output rotl(s0 * 0x9E3779BB, 5) * 5, lower half = s0 + s1 (of the state before the
+//                step; the map state -> 64 bits is a bijection; every consumer shifts the sum's weak low bits out)
+//   next_u64     = that; next_u32 = its upper half
 //   The float conversions are those of the reference's `rand 0.8.4` (Cargo.lock:836-837; the crate is not under /root/reference,
 //   restated from its published algorithm):
 //   gen::<f64>() = (next_u64 >> 11) as f64 * 2^-53                  `Standard`, 53 bits, [0,1)       (distributions/float.rs)
@@ -129,17 +131,14 @@ struct Rng {
         s0 = (uint32_t)s;
         s1 = (uint32_t)(s >> 32);
     }
-    inline uint32_t next_u32() {
-        const uint32_t r = rotl(s0 * 0x9E3779BBu, 5) * 5u;
+    inline uint64_t next_u64() {
+        const uint64_t out = ((uint64_t)(rotl(s0 * 0x9E3779BBu, 5) * 5u) << 32) | (uint64_t)(uint32_t)(s0 + s1);
         s1 ^= s0;
         s0 = rotl(s0, 26) ^ s1 ^ (s1 << 9);
         s1 = rotl(s1, 13);
-        return r;
+        return out;
     }
-    inline uint64_t next_u64() {
-        const uint64_t hi = next_u32();
-        return (hi << 32) | (uint64_t)next_u32();
-    }
+    inline uint32_t next_u32() { return (uint32_t)(next_u64() >> 32); }
     inline double gen_f64() {
         draws++;
         return (double)(next_u64() >> 11) * (1.0 / 9007199254740992.0);

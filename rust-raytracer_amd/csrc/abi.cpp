@@ -8,6 +8,9 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <string>
+#include <thread>
+#include <vector>
 
 #include "common/rng.h"
 #include "common/schedule.h"
@@ -83,6 +86,7 @@ int64_t rt_release_workspaces(void) {
     int64_t n = 0;
     guard([&] {
         n = (int64_t)release_workspaces();
+        exchange_release_idle();
         return (int)RT_OK;
     });
     return n;
@@ -106,6 +110,7 @@ int rt_tuning_set(const rt_tuning* t) {
         n.coop_pool = std::max(0, t->coop_pool);
         n.sppm_cap = std::max(0, t->sppm_photon_capacity);
         n.knn_cand = t->sppm_knn_candidates < 0 ? -1 : t->sppm_knn_candidates;
+        n.multi_force_rccl = t->multi_force_rccl != 0;
         n.c_box = t->sah_box_cost;
         {
             std::lock_guard<std::mutex> g(g_tuning_mu);
@@ -651,6 +656,208 @@ static int render_host(const rt_scene* s, const CameraDev& cd, const rt_params* 
     }
 }
 
+}  // extern "C"
+
+// ---- the frame across the GPUs of one node (camera.rs:74-126 has the fan-out and the stitch inside capture_image) ----
+namespace {
+struct DevMem {  // device memory that remembers which device it lives on
+    void* p = nullptr;
+    int device = -1;
+    DevMem() = default;
+    DevMem(const DevMem&) = delete;
+    DevMem& operator=(const DevMem&) = delete;
+    void alloc(int dev, size_t bytes) {
+        dev_set_device(dev);
+        p = dev_alloc(bytes);
+        device = dev;
+    }
+    ~DevMem() {
+        if (!p) return;
+        try {
+            dev_set_device(device);
+        } catch (...) {
+        }
+        dev_free(p);
+    }
+};
+struct ExchangeLease {
+    Exchange* e = nullptr;
+    ~ExchangeLease() { exchange_close(e); }
+};
+}  // namespace
+
+// per_rank(rank plan, destination rows on the rank's device, stats) renders one rank's tiles; it runs on its own host thread with
+// the rank's device current.
+template <class F>
+static int render_fanout(const rt_params* p, int n_devices, const int* device_ids, double* out_rgb, rt_stats* stats, F&& per_rank) {
+    REQUIRE(p && out_rgb, "null argument");
+    REQUIRE(p->world == 1 && p->rank == 0, "rt_render_multi partitions the frame itself: rank / world must be 0 / 1");
+    const int visible = device_count();
+    if (visible < 1) throw RtError(RT_ERR_NO_DEVICE, "no HIP device: librtamd has no CPU fallback");
+    REQUIRE(n_devices >= 0 && n_devices <= 4096, "n_devices out of range");
+    const int n = n_devices == 0 ? visible : n_devices;
+    std::vector<int> ids((size_t)n);
+    for (int i = 0; i < n; i++) {
+        ids[(size_t)i] = device_ids ? device_ids[i] : i;
+        if (ids[(size_t)i] < 0 || ids[(size_t)i] >= visible)
+            throw RtError(RT_ERR_NO_DEVICE, "device ordinal " + std::to_string(ids[(size_t)i]) + " of rank " + std::to_string(i) + " is not visible (" +
+                                                std::to_string(visible) + " device(s))");
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    const int caller_device = dev_get_device();
+    struct Restore {
+        int d;
+        ~Restore() {
+            try {
+                dev_set_device(d);
+            } catch (...) {
+            }
+        }
+    } restore{caller_device};
+    const bool force = tuning().multi_force_rccl != 0;
+    const int root = ids[0];
+    std::vector<RenderPlan> plans((size_t)n);
+    for (int i = 0; i < n; i++) {
+        rt_params q = *p;
+        q.rank = i;
+        q.world = n;
+        q.device = -1;
+        plans[(size_t)i] = make_plan(&q);
+    }
+    const int64_t stride = plans[0].tiles_owned;  // rank 0 owns the most tiles: every rank's rows are padded to it
+    const size_t row_doubles = (size_t)std::max<int64_t>(1, stride) * TILE_PIX * 3;
+    const size_t frame_bytes = (size_t)p->width * p->height * 3 * sizeof(double);
+    DevMem gathered, frame;
+    gathered.alloc(root, (size_t)n * row_doubles * sizeof(double));
+    frame.alloc(root, frame_bytes);
+    // a rank on the root's device renders straight into its slot of the gathered buffer; the others (every rank when the
+    // exchange is forced) into a row of their own on their device, which then travels
+    std::vector<DevMem> rows((size_t)n);
+    std::vector<double*> dst((size_t)n);
+    for (int i = 0; i < n; i++) {
+        double* slot = (double*)gathered.p + (size_t)i * row_doubles;
+        if (ids[(size_t)i] == root && !force) {
+            dst[(size_t)i] = slot;
+        } else {
+            rows[(size_t)i].alloc(ids[(size_t)i], row_doubles * sizeof(double));
+            dst[(size_t)i] = (double*)rows[(size_t)i].p;
+        }
+    }
+    std::vector<rt_stats> st((size_t)n);
+    std::vector<int> rc((size_t)n, (int)RT_OK);
+    std::vector<std::string> msg((size_t)n);
+    auto work = [&](int i) {
+        try {
+            dev_set_device(ids[(size_t)i]);
+            std::memset(&st[(size_t)i], 0, sizeof(rt_stats));
+            per_rank(plans[(size_t)i], dst[(size_t)i], &st[(size_t)i]);
+        } catch (const RtError& e) {
+            rc[(size_t)i] = e.code;
+            msg[(size_t)i] = e.msg;
+        } catch (const std::exception& e) {
+            rc[(size_t)i] = RT_ERR_INTERNAL;
+            msg[(size_t)i] = e.what();
+        } catch (...) {
+            rc[(size_t)i] = RT_ERR_INTERNAL;
+            msg[(size_t)i] = "unknown error";
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int i = 1; i < n; i++) th.emplace_back(work, i);
+        work(0);  // rank 0 on the calling thread, as the reference's caller blocks in capture_image
+        for (auto& t : th) t.join();
+    }
+    for (int i = 0; i < n; i++)
+        if (rc[(size_t)i] != RT_OK) throw RtError(rc[(size_t)i], "rank " + std::to_string(i) + " (device " + std::to_string(ids[(size_t)i]) + "): " + msg[(size_t)i]);
+    const auto t1 = std::chrono::steady_clock::now();
+    // ---- the exchange: rows -> their slots on the root device
+    std::vector<int> uniq;  // comm rank r = uniq[r]; the root's device first
+    auto comm_rank = [&](int dev) {
+        for (size_t r = 0; r < uniq.size(); r++)
+            if (uniq[r] == dev) return (int)r;
+        uniq.push_back(dev);
+        return (int)uniq.size() - 1;
+    };
+    comm_rank(root);
+    std::vector<RowMove> moves;
+    for (int i = 0; i < n; i++)
+        if (rows[(size_t)i].p) {
+            const size_t count = (size_t)plans[(size_t)i].tiles_owned * TILE_PIX * 3;
+            if (count) moves.push_back(RowMove{comm_rank(ids[(size_t)i]), (const double*)rows[(size_t)i].p, 0, (double*)gathered.p + (size_t)i * row_doubles, count});
+        }
+    if (!moves.empty()) {
+        ExchangeLease lease;
+        lease.e = exchange_open(uniq);
+        exchange_rows(lease.e, moves.data(), moves.size());
+    }
+    dev_set_device(root);
+    rt_params whole = *p;
+    whole.rank = 0;
+    whole.world = n;
+    assemble_frame(make_plan(&whole), (const double*)gathered.p, stride, (double*)frame.p, nullptr);
+    dev_copy_to_host(out_rgb, frame.p, frame_bytes);
+    const auto t2 = std::chrono::steady_clock::now();
+    if (stats) {
+        for (int i = 0; i < n; i++) {
+            stats[i] = st[(size_t)i];
+            uint64_t px = 0;
+            const RenderPlan& pl = plans[(size_t)i];
+            for (int64_t lt = 0; lt < pl.tiles_owned; lt++) {
+                const int64_t t = lt * pl.world + pl.rank;
+                const int tx = (int)(t % pl.tiles_x), ty = (int)(t / pl.tiles_x);
+                px += (uint64_t)std::min(TILE_W, pl.width - tx * TILE_W) * std::min(TILE_H, pl.height - ty * TILE_H);
+            }
+            stats[i].samples = px * (uint64_t)pl.spp;
+        }
+        stats[0].seconds = std::chrono::duration<double>(t2 - t0).count();
+        stats[0].reserved[2] = (uint64_t)(std::chrono::duration<double>(t2 - t1).count() * 1e6);
+        stats[0].reserved[3] = (uint64_t)moves.size();
+    }
+    return (int)RT_OK;
+}
+
+extern "C" {
+
+int rt_render_multi(const rt_scene* s, const rt_camera* cam, const rt_params* p, int n_devices, const int* device_ids, double* out_rgb,
+                    rt_stats* stats) {
+    return guard([&] {
+        REQUIRE(s && cam, "null argument");
+        if (!s->committed) throw RtError(RT_ERR_NOT_COMMITTED, "rt_scene_commit has not been called");
+        const CameraDev cd = make_camera(*cam);
+        return render_fanout(p, n_devices, device_ids, out_rgb, stats,
+                             [&](const RenderPlan& pl, double* d_rows, rt_stats* st) { render_tiles(*s, cd, pl, d_rows, nullptr, st); });
+    });
+}
+int rt_render_multi_camera_frame(const rt_scene* s, const rt_camera_frame* frame, const rt_params* p, int n_devices, const int* device_ids,
+                                 double* out_rgb, rt_stats* stats) {
+    return guard([&] {
+        REQUIRE(s && frame, "null argument");
+        for (const double* v : {frame->origin, frame->lower_left_corner, frame->horizontal, frame->vertical, frame->u, frame->v, frame->w})
+            for (int i = 0; i < 3; i++) REQUIRE(std::isfinite(v[i]), "camera frame must be finite");
+        REQUIRE(std::isfinite(frame->lens_radius), "camera frame must be finite");
+        if (!s->committed) throw RtError(RT_ERR_NOT_COMMITTED, "rt_scene_commit has not been called");
+        const CameraDev cd = camera_from_frame(*frame);
+        return render_fanout(p, n_devices, device_ids, out_rgb, stats,
+                             [&](const RenderPlan& pl, double* d_rows, rt_stats* st) { render_tiles(*s, cd, pl, d_rows, nullptr, st); });
+    });
+}
+int rt_render_sppm_multi(const rt_scene* s, const rt_camera* cam, const rt_params* p, const rt_sppm_config* cfg, int n_devices,
+                         const int* device_ids, double* out_rgb, rt_stats* stats) {
+    return guard([&] {
+        REQUIRE(s && cam && cfg && p, "null argument");
+        REQUIRE(p->spp > 0, "spp must be positive");
+        if (!s->committed) throw RtError(RT_ERR_NOT_COMMITTED, "rt_scene_commit has not been called");
+        const CameraDev cd = make_camera(*cam);
+        rt_params q = *p;
+        q.integrator = 0;  // as rt_render_sppm_tiles_device: the plan of the final pass; render_sppm switches the integrator
+        return render_fanout(&q, n_devices, device_ids, out_rgb, stats, [&](const RenderPlan& pl, double* d_rows, rt_stats* st) {
+            render_sppm(*s, cd, pl, *cfg, d_rows, nullptr, nullptr, st, nullptr);
+        });
+    });
+}
+int rt_rccl_version(void) { return exchange_library_version(); }
+
 void rt_default_sppm_config(rt_sppm_config* c) {
     if (!c) return;
     std::memset(c, 0, sizeof(*c));
@@ -746,7 +953,7 @@ int rt_debug_rng_floats(uint64_t seed, uint64_t pixel, uint64_t sample, int n, d
         r.seed_stream(seed, pixel, sample);
         for (int i = 0; i < n; i++) out_gen[i] = r.gen_f64();
         r.seed_stream(seed, pixel, sample);
-        for (int i = 0; i < n; i++) out_range[i] = r.gen_range(lo, hi);
+        for (int i = 0; i < n; i++) out_range[i] = (lo == -1. && hi == 1.) ? r.gen_range_pm1() : r.gen_range(lo, hi);
         return (int)RT_OK;
     });
 }

@@ -1,6 +1,7 @@
 // Host-callable launch interface of the HIP kernels (device/kernels.hip).
 #pragma once
 #include <cstdint>
+#include <vector>
 
 #include "../common/flat.h"
 #include "../host/scene.h"
@@ -42,5 +43,22 @@ void dev_copy_to_host(void* dst, const void* src, size_t n);
 void dev_set_device(int d);
 void free_device_copies(rt_scene& s);
 size_t release_workspaces();
+int dev_get_device();
+void dev_synchronize();  // the current device
+
+// ---- the exchange of the multi-device frame (device/exchange.hip: RCCL; rt_render_multi in abi.cpp drives it) ----
+struct Exchange;  // communicators + one stream per device of a device list (cached per process, leased)
+struct RowMove {  // `count` f64 from `src` on comm rank src_rank's device to `dst` on comm rank dst_rank's device
+    int src_rank;
+    const double* src;
+    int dst_rank;
+    double* dst;
+    size_t count;
+};
+Exchange* exchange_open(const std::vector<int>& devices);  // comm rank r = devices[r] (distinct ordinals); ncclCommInitAll on first use
+void exchange_close(Exchange* e);                          // returns the lease; the communicators stay cached
+void exchange_rows(Exchange* e, const RowMove* moves, size_t n_moves);  // grouped ncclSend / ncclRecv; returns when the rows have arrived
+size_t exchange_release_idle();                            // destroys the idle cached communicators; returns how many sets
+int exchange_library_version();                            // ncclGetVersion
 
 }  // namespace rtamd

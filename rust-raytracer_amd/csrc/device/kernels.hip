@@ -90,8 +90,8 @@ DEV D3 refract(D3 uv, D3 n, double eta) {                              // vec3.r
 DEV D3 random_in_unit_sphere(Rng& rng) {  // vec3.rs:111-129 (Marsaglia; a point ON the sphere, Q3)
     double u, v, r2;
     for (;;) {
-        u = rng.gen_range(-1., 1.);
-        v = rng.gen_range(-1., 1.);
+        u = rng.gen_range_pm1();
+        v = rng.gen_range_pm1();
         r2 = u * u + v * v;
         if (r2 <= 1.) break;
     }
@@ -100,8 +100,8 @@ DEV D3 random_in_unit_sphere(Rng& rng) {  // vec3.rs:111-129 (Marsaglia; a point
 }
 DEV D3 random_in_unit_disk(Rng& rng) {  // vec3.rs:153-162
     for (;;) {
-        double a = rng.gen_range(-1.0, 1.0);
-        double b = rng.gen_range(-1.0, 1.0);
+        double a = rng.gen_range_pm1();
+        double b = rng.gen_range_pm1();
         if (a * a + b * b + 0. * 0. >= 1.) continue;
         return mk(a, b, 0.);
     }
@@ -2724,7 +2724,7 @@ __global__ void rng_floats_kernel(uint64_t seed, uint64_t pixel, uint64_t sample
     r.seed_stream(seed, pixel, sample);
     for (int i = 0; i < n; i++) out[i] = r.gen_f64();
     r.seed_stream(seed, pixel, sample);
-    for (int i = 0; i < n; i++) out[n + i] = r.gen_range(lo, hi);
+    for (int i = 0; i < n; i++) out[n + i] = (lo == -1. && hi == 1.) ? r.gen_range_pm1() : r.gen_range(lo, hi);  // (the form the samplers call)
 }
 __global__ void math_kernel(int op, size_t n, const double* a, const double* b, double* out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

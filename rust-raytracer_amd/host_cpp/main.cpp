@@ -3,7 +3,9 @@
 // and the same "Total / RT" timing print.  Also renders the reference's scene files.
 //   rtamd_render [--scene cornell|FILE.json|FILE.yaml] [--cube data/mesh/cube.obj] [-w W] [-h H] [--spp N]
 //                [--depth D] [--seed S] [--aspect A] [--integrator 0|1] [--sppm ITERATIONS PHOTONS_PER_ITER]
-//                [-o out.png] [--describe] [--vec3-selftest]
+//                [--gpus N | --devices 0,1,...] [-o out.png] [--describe] [--vec3-selftest]
+// --gpus N spreads the frame over N GPUs of this node inside ONE capture_image call (rt_render_multi: tiles dealt round-robin, RCCL
+// gather; 0 = all visible); --devices names the HIP ordinal of every rank (an ordinal may repeat).
 // `rtamd_render --cube data/mesh/cube.obj --sppm 50 500000` is the reference binary: SPPM pre-pass + 256 spp, output/test.png
 #include <chrono>
 #include <cstdio>
@@ -58,6 +60,14 @@ int main(int argc, char** argv) {
         else if (a == "--aspect") aspect = std::atof(next());
         else if (a == "--integrator") cfg.integrator = std::atoi(next());
         else if (a == "--sppm") { cfg.sppm_iterations = std::atoi(next()); cfg.sppm_photons_per_iter = std::atoi(next()); }
+        else if (a == "--gpus") cfg.gpus = std::atoi(next());
+        else if (a == "--devices") {
+            for (const char* q = next(); *q;) {
+                cfg.devices.push_back((int)std::strtol(q, const_cast<char**>(&q), 10));
+                if (*q == ',') q++;
+                else if (*q) { std::fprintf(stderr, "--devices wants a comma-separated list of ordinals\n"); return 2; }
+            }
+        }
         else if (a == "-o") out = next();
         else if (a == "--describe") describe = true;
         else if (a == "--vec3-selftest") return vec3_selftest();
@@ -79,7 +89,8 @@ int main(int argc, char** argv) {
         if (describe) return 0;
         auto rt_start = std::chrono::steady_clock::now();
         rt_stats st{};
-        RgbImage result = world->capture_image(cfg, &st);
+        std::vector<rt_stats> ranks;
+        RgbImage result = world->capture_image(cfg, &st, nullptr, &ranks);
         result.save(out);
         auto end = std::chrono::steady_clock::now();
         double total = std::chrono::duration<double>(end - start_time).count(), rt = std::chrono::duration<double>(end - rt_start).count();
@@ -87,6 +98,10 @@ int main(int argc, char** argv) {
         std::printf("Total: %.3fs\n\tSPPM: %.3fs\n\tRT: %.3fs\n", total, sppm, rt - sppm);  // main.rs:57-71
         std::printf("%.2f Msamples/s (%llu samples, kernel %.1f ms in %d launches, scene %s)\n", st.samples / st.seconds / 1e6,
                     (unsigned long long)st.samples, st.kernel_ms, st.launches, st.scene_in_lds ? "in LDS" : "in L2/HBM");
+        for (size_t i = 0; i < ranks.size(); i++)
+            std::printf("\trank %zu: kernel %d, %.1f ms, %llu samples%s\n", i, ranks[i].kernel_used, ranks[i].kernel_ms, (unsigned long long)ranks[i].samples,
+                        i == 0 ? (", exchange + stitch " + std::to_string(ranks[0].reserved[2] * 1e-3) + " ms, " + std::to_string(ranks[0].reserved[3]) + " rows through RCCL " +
+                                  std::to_string(rt_rccl_version())).c_str() : "");
     } catch (const Error& e) {
         std::fprintf(stderr, "error %d: %s\n", e.code, e.what());
         return 1;

@@ -321,6 +321,10 @@ struct Config {
     int integrator = 0;             // 0 BSDF sampling (the reference's structure); 1 light/cosine mixture pdf
     // SPPMIntegrator::new's constants (photon_mapper.rs:17-19,148-149); sppm_iterations == 0: no SPPM pre-pass
     int sppm_iterations = 0, sppm_photons_per_iter = 500000;
+    // GPUs of this node the frame is spread over (rt_render_multi: image tiles dealt round-robin, one host thread per GPU inside the
+    // library, RCCL gather of the rows); 1 = rt_render on the current device; 0 = every visible GPU.  The image does not depend on it.
+    int gpus = 1;
+    std::vector<int> devices;       // explicit HIP ordinals, one per rank (overrides gpus; an ordinal may repeat)
 };
 
 // world.rs:8-30.  World::new(hitable_list, cam, lights): root = BVHNode::new(hitable_list).
@@ -352,7 +356,12 @@ class World {
     const rt_scene* handle() const { return s_; }
 
     // Camera::capture_image (camera.rs:66-128): radiance via the HIP path, then From<Vec3> for Rgb<u8>
-    RgbImage capture_image(const Config& cfg = Config(), rt_stats* stats = nullptr, std::vector<double>* radiance = nullptr) const {
+    RgbImage capture_image(const Config& cfg = Config(), rt_stats* stats = nullptr, std::vector<double>* radiance = nullptr,
+                           std::vector<rt_stats>* per_rank = nullptr) const {
+        const bool multi = cfg.gpus != 1 || !cfg.devices.empty();
+        const int n_ranks = !cfg.devices.empty() ? (int)cfg.devices.size() : cfg.gpus == 0 ? std::max(1, rt_device_count()) : cfg.gpus;
+        const int* ids = cfg.devices.empty() ? nullptr : cfg.devices.data();
+        std::vector<rt_stats> rank_stats(multi ? (size_t)n_ranks : 0);
         rt_params p;
         rt_default_params(&p);
         p.width = cfg.width; p.height = cfg.height; p.spp = cfg.sample_per_pixel; p.max_depth = cfg.max_depth;
@@ -363,10 +372,20 @@ class World {
             rt_default_sppm_config(&sc);
             sc.iterations = cfg.sppm_iterations;
             sc.photons_per_iter = cfg.sppm_photons_per_iter;
-            check(rt_render_sppm(s_, &cam.c, &p, &sc, rad.data(), nullptr, nullptr, stats));
+            if (multi) check(rt_render_sppm_multi(s_, &cam.c, &p, &sc, n_ranks, ids, rad.data(), rank_stats.data()));
+            else check(rt_render_sppm(s_, &cam.c, &p, &sc, rad.data(), nullptr, nullptr, stats));
         } else {
-            check(rt_render(s_, &cam.c, &p, rad.data(), stats));
+            if (multi) check(rt_render_multi(s_, &cam.c, &p, n_ranks, ids, rad.data(), rank_stats.data()));
+            else check(rt_render(s_, &cam.c, &p, rad.data(), stats));
         }
+        if (multi && stats) {  // the frame's totals: rank 0's record with the samples and kernel time of all ranks (max over ranks: they run side by side)
+            *stats = rank_stats[0];
+            for (size_t i = 1; i < rank_stats.size(); i++) {
+                stats->samples += rank_stats[i].samples;
+                stats->kernel_ms = std::max(stats->kernel_ms, rank_stats[i].kernel_ms);
+            }
+        }
+        if (per_rank) *per_rank = rank_stats;
         RgbImage img;
         img.width = cfg.width;
         img.height = cfg.height;

@@ -65,7 +65,7 @@ class rt_sppm_config(C.Structure):
 class rt_tuning(C.Structure):
     _fields_ = [("no_lds", C.c_int32), ("top_nodes", C.c_int32), ("sub_spp", C.c_int32), ("coop_pool", C.c_int32),
                 ("max_leaf", C.c_int32), ("sppm_photon_capacity", C.c_int32), ("sppm_knn_candidates", C.c_int32),
-                ("sah_box_cost", C.c_double)]
+                ("multi_force_rccl", C.c_int32), ("sah_box_cost", C.c_double)]
 
 
 class rt_object_desc(C.Structure):
@@ -141,6 +141,12 @@ _SIGS = [
     ("rt_default_sppm_config", None, [C.POINTER(rt_sppm_config)]),
     ("rt_render_sppm", C.c_int, [C.c_void_p, C.POINTER(rt_camera), C.POINTER(rt_params), C.POINTER(rt_sppm_config), _dp, _dp,
                                  C.POINTER(C.c_uint64), C.POINTER(rt_stats)]),
+    ("rt_render_multi", C.c_int, [C.c_void_p, C.POINTER(rt_camera), C.POINTER(rt_params), C.c_int, C.POINTER(C.c_int), _dp, C.POINTER(rt_stats)]),
+    ("rt_render_multi_camera_frame", C.c_int, [C.c_void_p, C.POINTER(rt_camera_frame), C.POINTER(rt_params), C.c_int, C.POINTER(C.c_int), _dp,
+                                      C.POINTER(rt_stats)]),
+    ("rt_render_sppm_multi", C.c_int, [C.c_void_p, C.POINTER(rt_camera), C.POINTER(rt_params), C.POINTER(rt_sppm_config), C.c_int, C.POINTER(C.c_int), _dp,
+                              C.POINTER(rt_stats)]),
+    ("rt_rccl_version", C.c_int, []),
     ("rt_render_tiles_device", C.c_int, [C.c_void_p, C.POINTER(rt_camera), C.POINTER(rt_params), C.c_void_p, C.c_void_p,
                                          C.POINTER(rt_stats)]),
     ("rt_render_sppm_tiles_device", C.c_int, [C.c_void_p, C.POINTER(rt_camera), C.POINTER(rt_params), C.POINTER(rt_sppm_config), C.c_void_p,
@@ -161,10 +167,13 @@ ABI_SYMBOLS = [s[0] for s in _SIGS]
 
 
 def _share_hip_runtime_with_torch():
-    """One process must hold ONE HIP/HSA runtime.  PyTorch-ROCm bundles its own libamdhip64.so.7 (same SONAME
-    as /opt/rocm's): whichever is loaded first serves both.  If torch is installed but not imported yet, load
-    ITS runtime first so that a later `import torch` in the same process (bench.py, the tests) does not bring
-    up a second HSA runtime and report "No HIP GPUs are available".  RTAMD_HIP_RUNTIME=system skips this."""
+    """One process must hold ONE HIP/HSA runtime and ONE RCCL.  PyTorch-ROCm bundles its own libamdhip64.so.7 and librccl.so.1
+    (same SONAMEs as /opt/rocm's, which librtamd.so names as its dependencies): whichever copy is loaded first serves both.  If torch is
+    installed but not imported yet, import it FIRST, so that a later `import torch` in the same process (bench.py, the tests) does not
+    find the system's runtime under its own kernels -- "No HIP GPUs are available" -- or the system's RCCL under its `nccl` backend.
+    (Pre-loading torch's libraries one by one instead is not safe: with librccl.so loaded before torch's own loader asks for it the
+    process ends in `double free or corruption` at exit.)  RTAMD_HIP_RUNTIME=system skips this: /opt/rocm's runtime and RCCL, for hosts
+    that never import torch."""
     import importlib.util
     import sys
     if "torch" in sys.modules or os.environ.get("RTAMD_HIP_RUNTIME", "") == "system":
@@ -173,14 +182,12 @@ def _share_hip_runtime_with_torch():
         spec = importlib.util.find_spec("torch")
     except (ImportError, ValueError):
         spec = None
-    if spec is None or not spec.submodule_search_locations:
+    if spec is None:
         return
-    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
-    if os.path.exists(cand):
-        try:
-            C.CDLL(cand, mode=C.RTLD_GLOBAL)
-        except OSError:
-            pass
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
 
 
 def lib():
@@ -425,6 +432,41 @@ class World:
         st = rt_stats()
         _chk(self.L.rt_render(self.h, C.byref(camera.c), C.byref(p), out.ctypes.data_as(_dp), C.byref(st)))
         return out, st.as_dict()
+
+    def render_multi(self, camera, devices=None, gpus=0, width=800, height=800, spp=256, max_depth=50, t_min=1e-3, seed=1, spp_chunk=0,
+                     kernel=0, integrator=0):
+        """rt_render_multi: the frame across the GPUs of this node in ONE call (one host thread per rank inside the library, rows
+        gathered on devices[0] through RCCL).  devices = HIP ordinals, one per rank (may repeat); or gpus = N for devices 0..N-1
+        (0 = all visible).  Returns (radiance [H,W,3], [per-rank stats dicts]); stats[0] also carries 'exchange_seconds' and
+        'rows_through_rccl'."""
+        p = default_params(width=width, height=height, spp=spp, max_depth=max_depth, t_min=t_min, seed=seed, spp_chunk=spp_chunk,
+                           kernel=kernel, integrator=integrator)
+        n = len(devices) if devices is not None else int(gpus)
+        ids = (C.c_int * n)(*[int(d) for d in devices]) if devices is not None else None
+        n_st = n if n > 0 else max(1, device_count())
+        st = (rt_stats * n_st)()
+        out = np.zeros((height, width, 3), dtype=np.float64)
+        _chk(self.L.rt_render_multi(self.h, C.byref(camera.c), C.byref(p), n, ids, out.ctypes.data_as(_dp), st))
+        ds = [s.as_dict() for s in st]
+        ds[0]["exchange_seconds"] = st[0].reserved[2] * 1e-6
+        ds[0]["rows_through_rccl"] = int(st[0].reserved[3])
+        return out, ds
+
+    def render_sppm_multi(self, camera, devices=None, gpus=0, width=800, height=800, spp=256, max_depth=50, t_min=1e-3, seed=1, kernel=0, **sppm):
+        """rt_render_sppm_multi: main.rs:52-54 across GPUs (every rank repeats the SPPM pre-pass, renders its tiles)."""
+        p = default_params(width=width, height=height, spp=spp, max_depth=max_depth, t_min=t_min, seed=seed, kernel=kernel)
+        cfg = rt_sppm_config()
+        self.L.rt_default_sppm_config(C.byref(cfg))
+        for k, v in sppm.items():
+            if not hasattr(cfg, k):
+                raise TypeError("unknown SPPM setting %r" % k)
+            setattr(cfg, k, v)
+        n = len(devices) if devices is not None else int(gpus)
+        ids = (C.c_int * n)(*[int(d) for d in devices]) if devices is not None else None
+        st = (rt_stats * (n if n > 0 else max(1, device_count())))()
+        out = np.zeros((height, width, 3), dtype=np.float64)
+        _chk(self.L.rt_render_sppm_multi(self.h, C.byref(camera.c), C.byref(p), C.byref(cfg), n, ids, out.ctypes.data_as(_dp), st))
+        return out, [s.as_dict() for s in st]
 
     def render_camera_frame(self, frame, **kw):
         """rt_render_camera_frame: `frame` is an rt_camera_frame (the Camera struct's stored fields)."""

@@ -129,6 +129,7 @@ pub struct rt_tuning {
     pub max_leaf: i32,
     pub sppm_photon_capacity: i32,
     pub sppm_knn_candidates: i32,
+    pub multi_force_rccl: i32,
     pub sah_box_cost: c_double,
 }
 
@@ -137,7 +138,7 @@ pub struct rt_tuning {
 impl Default for rt_tuning {
     fn default() -> Self {
         let mut t = rt_tuning { no_lds: 0, top_nodes: -1, sub_spp: 0, coop_pool: 0, max_leaf: 0, sppm_photon_capacity: 0,
-                                sppm_knn_candidates: -1, sah_box_cost: 0.0 };
+                                sppm_knn_candidates: -1, multi_force_rccl: 0, sah_box_cost: 0.0 };
         unsafe { rt_tuning_default(&mut t) };
         t
     }
@@ -231,6 +232,10 @@ extern "C" {
     pub fn rt_render_camera_frame(s: *const rt_scene, frame: *const rt_camera_frame, p: *const rt_params, out_rgb: *mut c_double, stats: *mut rt_stats) -> c_int;
     pub fn rt_camera_frame_from(cam: *const rt_camera, out: *mut rt_camera_frame) -> c_int;
     pub fn rt_default_sppm_config(c: *mut rt_sppm_config);
+    pub fn rt_render_multi(s: *const rt_scene, cam: *const rt_camera, p: *const rt_params, n_devices: c_int, device_ids: *const c_int, out_rgb: *mut c_double, stats: *mut rt_stats) -> c_int;
+    pub fn rt_render_multi_camera_frame(s: *const rt_scene, frame: *const rt_camera_frame, p: *const rt_params, n_devices: c_int, device_ids: *const c_int, out_rgb: *mut c_double, stats: *mut rt_stats) -> c_int;
+    pub fn rt_render_sppm_multi(s: *const rt_scene, cam: *const rt_camera, p: *const rt_params, cfg: *const rt_sppm_config, n_devices: c_int, device_ids: *const c_int, out_rgb: *mut c_double, stats: *mut rt_stats) -> c_int;
+    pub fn rt_rccl_version() -> c_int;
     pub fn rt_render_sppm(s: *const rt_scene, cam: *const rt_camera, p: *const rt_params, cfg: *const rt_sppm_config, out_rgb: *mut c_double, stats_out: *mut c_double, photons_stored: *mut u64, stats: *mut rt_stats) -> c_int;
     pub fn rt_render_tiles_device(s: *const rt_scene, cam: *const rt_camera, p: *const rt_params, d_tiles: *mut c_double, hip_stream: *mut c_void, stats: *mut rt_stats) -> c_int;
     pub fn rt_render_sppm_tiles_device(s: *const rt_scene, cam: *const rt_camera, p: *const rt_params, cfg: *const rt_sppm_config, d_tiles: *mut c_double, hip_stream: *mut c_void, stats: *mut rt_stats) -> c_int;
@@ -466,6 +471,23 @@ impl Scene {
         check(unsafe { rt_render_camera_frame(self.raw, frame, p, out.as_mut_ptr(), &mut st) })?;
         Ok((out, st))
     }
+    /// The frame across `gpus` GPUs of this node in ONE call (0 = every visible GPU): the fan-out over the devices, the RCCL
+    /// gather of the ranks' tile rows and the stitch happen inside the library, as the pool, the channel and the stitch happen
+    /// inside `capture_image` (camera.rs:74-126).  Per-rank statistics come back in the vector.
+    pub fn render_multi(&self, frame: &rt_camera_frame, p: &rt_params, gpus: usize) -> Result<(Vec<f64>, Vec<rt_stats>), RtError> {
+        let n = if gpus == 0 { (unsafe { rt_device_count() }).max(1) as usize } else { gpus };
+        let mut out = vec![0.0f64; (p.width as usize) * (p.height as usize) * 3];
+        let mut st = vec![rt_stats::default(); n];
+        check(unsafe { rt_render_multi_camera_frame(self.raw, frame, p, n as c_int, std::ptr::null(), out.as_mut_ptr(), st.as_mut_ptr()) })?;
+        Ok((out, st))
+    }
+    pub fn render_sppm_multi(&self, cam: &rt_camera, p: &rt_params, cfg: &rt_sppm_config, gpus: usize) -> Result<(Vec<f64>, Vec<rt_stats>), RtError> {
+        let n = if gpus == 0 { (unsafe { rt_device_count() }).max(1) as usize } else { gpus };
+        let mut out = vec![0.0f64; (p.width as usize) * (p.height as usize) * 3];
+        let mut st = vec![rt_stats::default(); n];
+        check(unsafe { rt_render_sppm_multi(self.raw, cam, p, cfg, n as c_int, std::ptr::null(), out.as_mut_ptr(), st.as_mut_ptr()) })?;
+        Ok((out, st))
+    }
     pub fn render_sppm(&self, cam: &rt_camera, p: &rt_params, cfg: &rt_sppm_config) -> Result<(Vec<f64>, rt_stats), RtError> {
         let mut out = vec![0.0f64; (p.width as usize) * (p.height as usize) * 3];
         let mut st = rt_stats::default();
@@ -668,10 +690,13 @@ pub struct RenderConfig {
     pub seed: u64,
     /// 0 = sample_ray with the Diffuse continuation (photon_mapper.rs:346-347); 1 = light/cosine mixture pdf
     pub integrator: i32,
+    /// GPUs of this node the frame is spread over (image tiles dealt round-robin, RCCL gather); 0 = every visible GPU.  The image does
+    /// not depend on it.
+    pub gpus: usize,
 }
 impl RenderConfig {
     pub fn new(width: usize, height: usize) -> Self {
-        Self { width, height, sample_per_pixel: 256, max_depth: 50, t_min: 0.001, seed: 1, integrator: 0 }
+        Self { width, height, sample_per_pixel: 256, max_depth: 50, t_min: 0.001, seed: 1, integrator: 0, gpus: 0 }
     }
     fn params(&self) -> rt_params {
         let mut p = rt_params::default();
@@ -708,7 +733,7 @@ pub fn describe_world(world: &World) -> Result<Scene, RtError> {
 /// From<Vec3> for Rgb<u8> (vec3.rs:223-231) inside the library.
 pub fn capture_image(world: &World, cfg: &RenderConfig) -> Result<image::RgbImage, RtError> {
     let scene = describe_world(world)?;
-    let (radiance, _stats) = scene.render(&camera_frame(&world.cam), &cfg.params())?;
+    let (radiance, _stats) = scene.render_multi(&camera_frame(&world.cam), &cfg.params(), cfg.gpus)?; // one call, all GPUs of the node
     let mut px = vec![0u8; radiance.len()];
     check(unsafe { rt_tonemap_u8(radiance.as_ptr(), radiance.len(), px.as_mut_ptr()) })?;
     Ok(image::RgbImage::from_raw(cfg.width as u32, cfg.height as u32, px).expect("buffer size"))
@@ -720,7 +745,7 @@ pub fn capture_image_sppm(world: &World, cam_args: &rt_camera, cfg: &RenderConfi
     let scene = describe_world(world)?;
     let mut sc = rt_sppm_config::default();
     unsafe { rt_default_sppm_config(&mut sc) };
-    let (radiance, _stats) = scene.render_sppm(cam_args, &cfg.params(), &sc)?;
+    let (radiance, _stats) = scene.render_sppm_multi(cam_args, &cfg.params(), &sc, cfg.gpus)?;
     let mut px = vec![0u8; radiance.len()];
     check(unsafe { rt_tonemap_u8(radiance.as_ptr(), radiance.len(), px.as_mut_ptr()) })?;
     Ok(image::RgbImage::from_raw(cfg.width as u32, cfg.height as u32, px).expect("buffer size"))

@@ -11,3 +11,6 @@ ASAN=$(gcc -print-file-name=libasan.so); UBSAN=$(gcc -print-file-name=libubsan.s
 LD_PRELOAD="$ASAN $UBSAN" ASAN_OPTIONS=detect_leaks=0 RTAMD_HIP_RUNTIME=system RTAMD_LIB=$PWD/tests/asan/librtamd_host_asan.so \
   ORACLE_LIB=$PWD/oracle/librt_oracle_asan.so python -m pytest tests/test_host_loader.py tests/test_abi_symbols.py tests/test_schedule.py tests/test_oracle_kat.py \
   tests/test_oracle_vec3.py tests/test_golden.py tests/test_mixture.py tests/test_sppm.py -q -m "not gpu" -p no:cacheprovider "$@"
+# the fan-out / partition / gather / stitch logic of rt_render_multi on the stub's fake devices (host memory; see device_stub.cpp)
+LD_PRELOAD="$ASAN $UBSAN" ASAN_OPTIONS=detect_leaks=0 RTAMD_HIP_RUNTIME=system RTAMD_LIB=$PWD/tests/asan/librtamd_host_asan.so RTAMD_STUB_DEVICES=4 \
+  python -m pytest tests/test_multi_stub.py -q -p no:cacheprovider "$@"

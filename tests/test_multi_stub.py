@@ -1,0 +1,90 @@
+"""rt_render_multi's HOST logic -- argument checks, the deal of tiles to ranks, the slot of every rank's rows in the gathered buffer,
+which rows travel and between which communicator ranks, the stitch -- on the sanitizer build's FAKE devices (tests/asan/device_stub.cpp:
+host memory, rows filled with a pattern of (global tile, pixel, channel), exchange = memcpy).  Runs only inside tests/asan/run_host_asan.sh
+(RTAMD_STUB_DEVICES set, librtamd_host_asan.so loaded under ASan + UBSan); the real thing -- HIP kernels and RCCL -- is covered by the
+-m gpu tests of tests/test_multi_gpu.py."""
+import os
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.skipif(not os.environ.get("RTAMD_STUB_DEVICES"), reason="needs the sanitizer build's fake devices (run_host_asan.sh)")
+
+
+def _expected(width, height, seed):
+    y, x = np.mgrid[0:height, 0:width]
+    t = (y // 8) * ((width + 7) // 8) + x // 8
+    pix = (y % 8) * 8 + x % 8
+    return np.stack([t * 1000.0 + pix * 3 + c + (seed % 7) * 0.125 for c in range(3)], axis=-1)
+
+
+def _world():
+    import rtamd
+    from conftest import scene_path
+    return rtamd.load_scene_file(scene_path("scene_10.json"))
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 1], [0, 1, 2, 3], [2, 0, 2, 1, 0], [1, 1, 1], [3, 3, 0, 0, 3, 0, 1]])
+@pytest.mark.parametrize("size", [(64, 40), (37, 21), (8, 8), (5, 3)])
+def test_every_tile_reaches_its_place_in_the_frame(devices, size):
+    import rtamd
+    world, cam = _world()
+    w, h = size
+    for force in (0, 1):
+        rtamd.set_tuning(multi_force_rccl=force)
+        try:
+            img, st = world.render_multi(cam, devices=devices, width=w, height=h, spp=1, seed=3)
+        finally:
+            rtamd.set_tuning()
+        assert np.array_equal(img, _expected(w, h, 3))
+        assert len(st) == len(devices)
+        total = (w * h)
+        assert sum(s["samples"] for s in st) == total             # every pixel belongs to exactly one rank
+        travelled = sum(1 for i, d in enumerate(devices) if (force or d != devices[0]) and (((w + 7) // 8) * ((h + 7) // 8) > i))
+        assert st[0]["rows_through_rccl"] == travelled            # rows on the root's device stay where they were rendered
+
+
+def test_gpus_n_means_devices_0_to_n_minus_1_and_zero_means_all():
+    world, cam = _world()
+    a, st = world.render_multi(cam, gpus=3, width=40, height=24, spp=1, seed=5)
+    assert np.array_equal(a, _expected(40, 24, 5)) and len(st) == 3 and st[0]["rows_through_rccl"] == 2
+    b, st = world.render_multi(cam, gpus=0, width=40, height=24, spp=1, seed=5)
+    assert np.array_equal(b, a) and len(st) == int(os.environ["RTAMD_STUB_DEVICES"])
+
+
+def test_more_ranks_than_tiles_leaves_empty_ranks():
+    world, cam = _world()
+    img, st = world.render_multi(cam, devices=[0, 1, 2, 3, 0, 1], width=16, height=8, spp=1, seed=1)   # 2 tiles, 6 ranks
+    assert np.array_equal(img, _expected(16, 8, 1))
+    assert [s["samples"] for s in st] == [64, 64, 0, 0, 0, 0] and st[0]["rows_through_rccl"] == 1
+
+
+def test_argument_errors_come_back_as_status_codes():
+    import ctypes as C
+    import rtamd
+    world, cam = _world()
+    with pytest.raises(rtamd.RtError) as e:
+        world.render_multi(cam, devices=[0, 7], width=16, height=16, spp=1)
+    assert e.value.code == -9 and "rank 1" in str(e.value)                       # RT_ERR_NO_DEVICE names the rank
+    with pytest.raises(rtamd.RtError):
+        world.render_multi(cam, devices=[-1], width=16, height=16, spp=1)
+    p = rtamd.default_params(width=16, height=16, spp=1, rank=1, world=2)        # the call partitions the frame itself
+    out = np.zeros((16, 16, 3))
+    rc = world.L.rt_render_multi(world.h, C.byref(cam.c), C.byref(p), 2, None, out.ctypes.data_as(C.POINTER(C.c_double)), None)
+    assert rc == -1 and b"rank / world must be 0 / 1" in world.L.rt_last_error()
+    p = rtamd.default_params(width=16, height=16, spp=1)
+    assert world.L.rt_render_multi(world.h, C.byref(cam.c), C.byref(p), 2, None, None, None) == -1
+    assert world.L.rt_render_multi(world.h, C.byref(cam.c), C.byref(p), -2, None, out.ctypes.data_as(C.POINTER(C.c_double)), None) == -1
+
+
+def test_the_callers_current_device_is_restored():
+    import rtamd
+    world, cam = _world()
+    world.render_multi(cam, devices=[3, 1], width=16, height=16, spp=1)
+    img, _ = world.render_multi(cam, devices=[0], width=16, height=16, spp=1, seed=2)   # would fail the stub's "rows on the current device" check otherwise
+    assert np.array_equal(img, _expected(16, 16, 2))
+
+
+def test_sppm_multi_takes_the_same_path():
+    world, cam = _world()
+    img, st = world.render_sppm_multi(cam, devices=[1, 0, 1], width=24, height=16, spp=1, seed=4, iterations=1, photons_per_iter=10)
+    assert np.array_equal(img, _expected(24, 16, 4)) and len(st) == 3

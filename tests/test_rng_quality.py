@@ -1,5 +1,5 @@
 """Statistics of the shipped RNG (rtamd-rng-3, csrc/common/rng.h): gen::<f64>() = (next_u64 >> 11) * 2^-53 (rand 0.8.4's
-conversion) of a xoroshiro64** stream keyed by (seed, pixel, sample); a next_u64 is two 32-bit steps.  The path tracer uses ADJACENT keys (neighbouring pixels, consecutive
+conversion) of a xoroshiro64 stream keyed by (seed, pixel, sample); one step yields 64 bits (** scrambler << 32 | + scrambler).  The path tracer uses ADJACENT keys (neighbouring pixels, consecutive
 sample indices), so uniformity and independence are checked across adjacent keys as well as along a stream, on the product's
 host implementation (rt_debug_rng_host through the C ABI) and on the oracle's independent restatement; the device
 implementation is pinned to both bit for bit elsewhere (tests/test_parity_gpu.py::test_rng_device_matches_oracle_and_host).
@@ -47,23 +47,29 @@ def test_first_draws_of_adjacent_keys_are_uniform_and_uncorrelated(which):
 @pytest.mark.parametrize("which", ["product (host)", "oracle"])
 def test_draws_along_one_stream_are_uniform_and_uncorrelated(which):
     draw = _impls()[which]
-    u = np.asarray(draw(7, 123456, 789, 32768), dtype=np.uint64)
-    f = np.concatenate([(u >> np.uint64(32)), (u & np.uint64(0xFFFFFFFF))]).reshape(2, -1).T.ravel().astype(np.float64) * 2.0 ** -32  # draw order
-    n = f.size
-    hist = np.bincount((f * 256).astype(int), minlength=256)
-    chi2 = ((hist - n / 256.0) ** 2 / (n / 256.0)).sum()
-    assert 160.0 < chi2 < 370.0, chi2
-    x = f - 0.5
-    for lag in (1, 2, 3):
-        r = (x[:-lag] * x[lag:]).sum() / (x * x).sum()
-        assert abs(r) < 4.0 / np.sqrt(n), (lag, r)
-    assert f.min() >= 0.0 and f.max() < 1.0                     # [0, 1): 1.0 is never produced
-    g = (u >> np.uint64(11)).astype(np.float64) * 2.0 ** -53    # the same stream as 53-bit draws (two steps each)
-    x = g - 0.5
-    for lag in (1, 2, 3):
-        r = (x[:-lag] * x[lag:]).sum() / (x * x).sum()
-        assert abs(r) < 4.0 / np.sqrt(g.size), (lag, r)
-    assert g.min() >= 0.0 and g.max() < 1.0
+    u = np.asarray(draw(7, 123456, 789, 65536), dtype=np.uint64)
+    n = u.size
+
+    def check(f, bins=256):
+        hist = np.bincount((f * bins).astype(int), minlength=bins)
+        chi2 = ((hist - n / bins) ** 2 / (n / bins)).sum()
+        assert 160.0 < chi2 < 370.0, chi2
+        x = f - 0.5
+        for lag in (1, 2, 3):
+            r = (x[:-lag] * x[lag:]).sum() / (x * x).sum()
+            assert abs(r) < 4.0 / np.sqrt(n), (lag, r)
+        assert f.min() >= 0.0 and f.max() < 1.0                 # [0, 1): 1.0 is never produced
+
+    g = (u >> np.uint64(11)).astype(np.float64) * 2.0 ** -53    # gen::<f64>()
+    check(g)
+    check((u >> np.uint64(32)).astype(np.float64) * 2.0 ** -32)                     # the ** half alone (next_u32)
+    low21 = ((u >> np.uint64(11)) & np.uint64(0x1FFFFF)).astype(np.float64) * 2.0 ** -21   # the 21 bits the + scrambler contributes to a draw
+    check(low21)
+    check(((u >> np.uint64(11)) & np.uint64(0xFF)).astype(np.float64) / 256.0)      # ... and the lowest 8 of them
+    x, y = low21[:-1] - 0.5, g[1:] - 0.5                         # low bits of one draw against the next draw
+    assert abs((x * y).sum() / np.sqrt((x * x).sum() * (y * y).sum())) < 4.0 / np.sqrt(n)
+    x, y = low21 - 0.5, (u >> np.uint64(32)).astype(np.float64) * 2.0 ** -32 - 0.5   # ... and against the upper half of the SAME step
+    assert abs((x * y).sum() / np.sqrt((x * x).sum() * (y * y).sum())) < 4.0 / np.sqrt(n)
 
 
 def _unxorshift(z, k):
@@ -83,17 +89,9 @@ def _unmix(z):
 
 
 def _key_with_first_draw_zero():
-    """(seed, pixel, sample) = (seed, 0, 0) whose first next_u64 has its upper 53 bits clear, i.e. gen::<f64>() == 0.0 exactly.
-    xoroshiro64**'s output is rotl(s0 * K, 5) * 5 with K and 5 odd: a state whose s0 is 0 outputs 0 (the high half); the next state's
-    s0 is s1 ^ (s1 << 9) -- an invertible map of s1 -- so s1 is chosen such that the second output is 1 (< 2^11)."""
-    K, M32 = 0x9E3779BB, (1 << 32) - 1
-    rotr = lambda x, k: ((x >> k) | (x << (32 - k))) & M32
-    s0_next = (rotr(pow(5, -1, 1 << 32) * 1 & M32, 5) * pow(K, -1, 1 << 32)) & M32   # rotl(s0' * K, 5) * 5 == 1
-    s1 = 0
-    for b in range(32):                                          # solve s1 ^ (s1 << 9) == s0_next bit by bit from the low end
-        s1 |= (((s0_next >> b) & 1) ^ ((s1 >> (b - 9)) & 1 if b >= 9 else 0)) << b
-    assert (s1 ^ (s1 << 9)) & M32 == s0_next and s1 != 0
-    s = s1 << 32
+    """(seed, pixel, sample) = (seed, 0, 0) whose stream starts in the state (s0, s1) = (0, 1): the step's upper half is
+    rotl(s0 * K, 5) * 5 = 0 and its lower half s0 + s1 = 1, so next_u64 >> 11 == 0 and gen::<f64>() == 0.0 exactly."""
+    s = 1 << 32
     h = (_unmix(s) - 0xD1B54A32D192ED03 * 1) & M64
     return (_unmix(h) - 0x9E3779B97F4A7C15 * 1) & M64, 0, 0
 
