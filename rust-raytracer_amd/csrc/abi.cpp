@@ -953,7 +953,7 @@ int rt_debug_rng_floats(uint64_t seed, uint64_t pixel, uint64_t sample, int n, d
         r.seed_stream(seed, pixel, sample);
         for (int i = 0; i < n; i++) out_gen[i] = r.gen_f64();
         r.seed_stream(seed, pixel, sample);
-        for (int i = 0; i < n; i++) out_range[i] = (lo == -1. && hi == 1.) ? r.gen_range_pm1() : r.gen_range(lo, hi);
+        for (int i = 0; i < n; i++) out_range[i] = (lo == -1. && hi == 1.) ? r.gen_range_pm1() : (lo == 0. && hi == 1.) ? r.gen_range_01() : r.gen_range(lo, hi);
         return (int)RT_OK;
     });
 }

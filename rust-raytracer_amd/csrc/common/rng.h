@@ -91,6 +91,8 @@ struct Rng {
     // gen_range(-1.0..1.0) (vec3.rs:118-119,156) in one instruction: (v - 1) * 2 + (-1) == 2 v - 3, and every operation of both
     // forms is exact (v in [1, 2) with 52 fraction bits), so the fused form returns the same number
     RT_HD double gen_range_pm1() { return __builtin_fma(gen_12(), 2.0, -3.0); }
+    // gen_range(0.0..1.0) (light.rs:150): (v - 1) * 1 + 0 == v - 1
+    RT_HD double gen_range_01() { return gen_12() - 1.0; }
     RT_HD uint32_t gen_below3() { return (uint32_t)(((uint64_t)next_u32() * 3ULL) >> 32); }
 };
 

@@ -1061,7 +1061,7 @@ DEV D3 light_random(const Acc& A, uint2 l, D3 o, Rng& rng, int* err) {
     }
     const double2* r = A.rects + 3 * l.y;
     double2 r0 = r[0], r1 = r[1], r2 = r[2];
-    double u = rng.gen_range(0., 1.), v = rng.gen_range(0., 1.);
+    double u = rng.gen_range_01(), v = rng.gen_range_01();
     D3 p = mk(r0.x + (r1.x - r0.x) * u, r2.x, r0.y + (r1.y - r0.y) * v);
     return sub(p, o);
 }
@@ -2724,7 +2724,7 @@ __global__ void rng_floats_kernel(uint64_t seed, uint64_t pixel, uint64_t sample
     r.seed_stream(seed, pixel, sample);
     for (int i = 0; i < n; i++) out[i] = r.gen_f64();
     r.seed_stream(seed, pixel, sample);
-    for (int i = 0; i < n; i++) out[n + i] = (lo == -1. && hi == 1.) ? r.gen_range_pm1() : r.gen_range(lo, hi);  // (the form the samplers call)
+    for (int i = 0; i < n; i++) out[n + i] = (lo == -1. && hi == 1.) ? r.gen_range_pm1() : (lo == 0. && hi == 1.) ? r.gen_range_01() : r.gen_range(lo, hi);  // (the forms the samplers call)
 }
 __global__ void math_kernel(int op, size_t n, const double* a, const double* b, double* out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

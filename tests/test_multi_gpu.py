@@ -69,9 +69,10 @@ def test_multi_sppm_equals_the_single_device_sppm(tuning):
     import rtamd
     world, cam = rtamd.select_scene(scene_path("cube.obj"), 1.0, 1)
     ref, _, _, _ = world.render_sppm(cam, width=24, height=24, spp=3, seed=1, iterations=3, photons_per_iter=6000)
+    assert np.isfinite(ref).mean() > 0.9
     tuning(multi_force_rccl=1)
     img, st = world.render_sppm_multi(cam, devices=[0, 0, 0], width=24, height=24, spp=3, seed=1, iterations=3, photons_per_iter=6000)
-    assert np.array_equal(img, ref) and len(st) == 3
+    assert np.array_equal(img, ref, equal_nan=True) and len(st) == 3     # (under-filled photon maps leave NaN estimates, in the reference too)
 
 
 def test_multi_errors_are_status_codes():
