@@ -246,7 +246,7 @@ int rt_scene_commit(rt_scene* s);
 /* introspection of the flattened form (tests, INTEGRATION) */
 typedef struct rt_scene_info {
     int32_t n_nodes, n_boxes, n_spheres, n_rects, n_tris, n_xforms, n_materials, n_textures;
-    int32_t n_verts, max_depth, committed, reserved;
+    int32_t n_verts, max_depth, committed, n_cubes;   /* a Cube is one record and one node (six sides scanned by the kernel's cube_hit) */
     uint64_t bytes;
     int32_t accel_ok, accel_nodes, accel_items, accel_instances, accel_stack, accel_compact;  /* accel_compact: 1 if the compact object-space copies kernel 5 needs were built */
 } rt_scene_info;

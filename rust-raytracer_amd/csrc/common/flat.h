@@ -30,7 +30,15 @@ enum NodeKind : uint32_t {
     // subtree is emitted TWICE between three brackets; payload = medium index:
     NK_MEDIUM_BEGIN = 9,  // save the outer best hit; query A: boundary.hit(r, -inf, +inf)
     NK_MEDIUM_MID = 10,   // A missed -> jump to END (skip link); else query B: boundary.hit(r, t_A + 0.0001, +inf)
-    NK_MEDIUM_END = 11    // restore the outer state; clip [t_A, t_B] to [t_min, best], draw, accept t = t_A + dist / |dir| or nothing
+    NK_MEDIUM_END = 11,   // restore the outer state; clip [t_A, t_B] to [t_min, best], draw, accept t = t_A + dist / |dir| or nothing
+    // 12 = NK_INSTANCE_INLINE (accel items only, below)
+    // Cube::hit (cube.rs:64-66) = the list scan of hit.rs:56-67 over its six sides, as ONE node and ONE accel item: the record sits in
+    // the rect table (same 48 bytes: (min.x, min.y) (min.z, max.x) (max.y, max.z); rect_mat holds its material) and the sides are
+    // tested in Cube::new's order (cube.rs:17-54) with the shrinking closest_so_far.  payload = 8 * record index + side, side = 0
+    // in the program and in accel items; a Hit's kp carries the winning side (0 XY z=min, 1 XY z=max, 2 XZ y=min, 3 XZ y=max,
+    // 4 YZ x=min, 5 YZ x=max).  The six sides are contiguous in the reference's visit order, so one program index per cube
+    // resolves exact ties against other objects exactly as six would; ties among the sides are resolved inside the scan.
+    NK_CUBE = 13
 };
 static const uint32_t NK_BITS = 4;
 static const uint32_t NK_MASK = 15;

@@ -273,6 +273,40 @@ DEV bool rect_hit(const double2* r, int axis, D3 o, D3 d, double t_min, double t
     t_out = t;
     return true;
 }
+// Cube::hit = self.sides.hit(r, t_min, t_max) (cube.rs:64-66): the list scan of hit.rs:56-67 over the six rectangles of Cube::new
+// (cube.rs:17-54) in their order -- XY z=min.z, XY z=max.z, XZ y=min.y, XZ y=max.y, YZ x=min.x, YZ x=max.x -- each one rectangle.rs's
+// test (:20-25, :58-63, :95-100: t = (k - o) / d; reject t < t_min || t > closest_so_far; then the two bounds) with the closest hit so
+// far shrinking from side to side, so a later side wins an exact tie and a NaN t (a ray in a side's plane) propagates as
+// in the reference.  c: (min.x, min.y) (min.z, max.x) (max.y, max.z).  Returns the winning side.
+DEV bool cube_hit(const double2* c, D3 o, D3 d, double t_min, double t_max, double& t_out, uint32_t& side_out) {
+    const double2 c0 = c[0], c1 = c[1], c2 = c[2];
+    const double mnx = c0.x, mny = c0.y, mnz = c1.x, mxx = c1.y, mxy = c2.x, mxz = c2.y;
+    double best = t_max;
+    bool any = false;
+    uint32_t side = 0;
+#define RT_CUBE_SIDE(S, K, OK, DK, OA, DA, A0, A1, OB, DB, B0, B1)     \
+    {                                                                  \
+        const double t = ((K) - (OK)) / (DK);                          \
+        if (!(t < t_min || t > best)) {                                \
+            const double pa = (OA) + (DA) * t, pb = (OB) + (DB) * t;   \
+            if (!(pa < (A0) || pa > (A1) || pb < (B0) || pb > (B1))) { \
+                best = t;                                              \
+                side = (S);                                            \
+                any = true;                                            \
+            }                                                          \
+        }                                                              \
+    }
+    RT_CUBE_SIDE(0u, mnz, o.z, d.z, o.x, d.x, mnx, mxx, o.y, d.y, mny, mxy)
+    RT_CUBE_SIDE(1u, mxz, o.z, d.z, o.x, d.x, mnx, mxx, o.y, d.y, mny, mxy)
+    RT_CUBE_SIDE(2u, mny, o.y, d.y, o.x, d.x, mnx, mxx, o.z, d.z, mnz, mxz)
+    RT_CUBE_SIDE(3u, mxy, o.y, d.y, o.x, d.x, mnx, mxx, o.z, d.z, mnz, mxz)
+    RT_CUBE_SIDE(4u, mnx, o.x, d.x, o.y, d.y, mny, mxy, o.z, d.z, mnz, mxz)
+    RT_CUBE_SIDE(5u, mxx, o.x, d.x, o.y, d.y, mny, mxy, o.z, d.z, mnz, mxz)
+#undef RT_CUBE_SIDE
+    t_out = best;
+    side_out = side;
+    return any;
+}
 DEV D3 ld3(const double* p, uint32_t i) { return mk(p[3 * i], p[3 * i + 1], p[3 * i + 2]); }
 // Triangle::hit, mesh.rs:57-102 ; returns t and the barycentrics b1,b2
 DEV bool tri_hit_v(D3 pa, D3 e0, D3 e1, D3 o, D3 dir, double t_min, double t_max, double& t_out, double& b1o, double& b2o);
@@ -389,6 +423,15 @@ DEV Hit traverse(const Acc& A, D3 wo, D3 wd, double t_min, double t_max, Rng* rn
                     h.node = (int)n;
                     h.xf = cur_xf;
                     h.kp = m.x;
+                }
+            } else if (kind == NK_CUBE) {
+                double t;
+                uint32_t side;
+                if (cube_hit(A.rects + 3 * (pl >> 3), o, d, t_min, h.t, t, side)) {
+                    h.t = t;
+                    h.node = (int)n;
+                    h.xf = cur_xf;
+                    h.kp = m.x + (side << NK_BITS);
                 }
             } else if (kind == NK_TRI) {
                 double t, b1, b2;
@@ -658,6 +701,7 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
                 uint32_t kind = it.x & NK_MASK, pl = it.x >> NK_BITS;
                 double t = 0.;
                 bool got = false;
+                uint32_t cube_side = 0u;  // NK_CUBE: the winning side goes into the hit's kp
                 const double t_far = TRACK ? track_bound(*track, h.t) : h.t;  // how far a candidate may lie
                 if (LIMIT && it.y >= order_limit) {
                     // visited by the reference after the medium in question (an instance's subtree is contiguous in the program and
@@ -667,6 +711,8 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
                 } else if (GENERAL) {
                     if (kind == NK_RECT_YZ || kind == NK_RECT_XZ || kind == NK_RECT_XY) {
                         got = rect_hit(A.rects + 3 * pl, (int)kind - (int)NK_RECT_YZ, o, d, t_min, t_far, t);
+                    } else if (kind == NK_CUBE) {
+                        got = cube_hit(A.rects + 3 * (pl >> 3), o, d, t_min, t_far, t, cube_side);
                     } else if (kind == NK_TRI) {
                         double b1, b2;
                         got = tri_hit(A.tripre2 + 5 * (first + i), o, d, t_min, t_far, t, b1, b2);
@@ -684,7 +730,7 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
                             h.t = t;
                             h.node = (int)it.y;
                             h.xf = cur_xf;
-                            h.kp = it.x;
+                            h.kp = it.x + (cube_side << NK_BITS);
                             best_all32 = ray32_best(t);
                         }
                         r.best = ray32_best(track_bound(*track, h.t));
@@ -694,7 +740,7 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
                     h.t = t;
                     h.node = (int)it.y;
                     h.xf = cur_xf;
-                    h.kp = it.x;
+                    h.kp = it.x + (cube_side << NK_BITS);
                     r.best = ray32_best(t);
                 }
             }
@@ -921,9 +967,21 @@ DEV Rec materialize(const Acc& A, const Hit& h, D3 wo, D3 wd, int* err) {
     } else if (GENERAL && kind == NK_MEDIUM_END) {  // ConstantMedium: arbitrary normal (1,0,0), uv (0,0), phase function (medium.rs:43-49)
         rec.mat = A.media[pl].mat;
         outward = mk(1., 0., 0.);
-    } else if (GENERAL && kind != NK_TRI) {  // rectangles
+    } else if (GENERAL && kind != NK_TRI) {  // rectangles, and the winning side of a Cube (cube.rs:17-54: the side's rectangle from the corners)
         int axis = (int)kind - (int)NK_RECT_YZ;
-        double2 r0 = A.rects[3 * pl], r1 = A.rects[3 * pl + 1];
+        double2 r0, r1;
+        if (kind == NK_CUBE) {
+            const uint32_t side = pl & 7u;
+            pl >>= 3;
+            const double2 c0 = A.rects[3 * pl], c1 = A.rects[3 * pl + 1], c2 = A.rects[3 * pl + 2];  // (min.x, min.y) (min.z, max.x) (max.y, max.z)
+            axis = side < 2u ? 2 : (side < 4u ? 1 : 0);
+            if (axis == 2) { r0 = c0; r1.x = c1.y; r1.y = c2.x; }                                   // xy0 = min.xy(), xy1 = max.xy()
+            else if (axis == 1) { r0.x = c0.x; r0.y = c1.x; r1.x = c1.y; r1.y = c2.y; }             // xz0 = min.xz(), xz1 = max.xz()
+            else { r0.x = c0.y; r0.y = c1.x; r1.x = c2.x; r1.y = c2.y; }                            // yz0 = min.yz(), yz1 = max.yz()
+        } else {
+            r0 = A.rects[3 * pl];
+            r1 = A.rects[3 * pl + 1];
+        }
         rec.mat = A.rect_mat[pl];
         outward = mk(axis == 0 ? 1. : 0., axis == 1 ? 1. : 0., axis == 2 ? 1. : 0.);
         if (A.texs[A.mats[rec.mat].tex].type == 2) {
@@ -1917,10 +1975,13 @@ DEV void blas_pass(const Acc& A, bool act, uint32_t* stk, const int stride, D3 o
             const uint32_t kind = it.x & NK_MASK, pl = it.x >> NK_BITS;
             double t = 0.;
             bool got = false;
+            uint32_t cube_side = 0u;
             if (kind == NK_SPHERE) {
                 got = sphere_hit(A.spheres + 2 * pl, o, d, a, t_min, ht, t);
             } else if (kind == NK_RECT_YZ || kind == NK_RECT_XZ || kind == NK_RECT_XY) {
                 got = rect_hit(A.rects + 3 * pl, (int)kind - (int)NK_RECT_YZ, o, d, t_min, ht, t);
+            } else if (kind == NK_CUBE) {
+                got = cube_hit(A.rects + 3 * (pl >> 3), o, d, t_min, ht, t, cube_side);
             } else if (kind == NK_TRI) {
                 double b1, b2;
                 got = tri_hit(A.tripre2 + 5 * (first + i), o, d, t_min, ht, t, b1, b2);
@@ -1930,7 +1991,7 @@ DEV void blas_pass(const Acc& A, bool act, uint32_t* stk, const int stride, D3 o
             if (got && (t < ht || (int)it.y > hnode || !(t == t))) {
                 ht = t;
                 hnode = (int)it.y;
-                hkp = it.x;
+                hkp = it.x + (cube_side << NK_BITS);
                 r.best = ray32_best(t);
             }
         }

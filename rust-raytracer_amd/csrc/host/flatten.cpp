@@ -2,7 +2,7 @@
 // (layout: common/flat.h).  The emission order IS the reference's visit order:
 //   BVHNode::hit   box, then left subtree, then right subtree   (bvh.rs:86-102)
 //   Vec<..>::hit   items in insertion order                     (hit.rs:57-67)
-//   Cube::hit      its 6 sides as a list                        (cube.rs:64-66)
+//   Cube::hit      its 6 sides as a list -- ONE node, the scan is inside the kernel's cube_hit  (cube.rs:64-66)
 //   Mesh::hit      its inner BVHNode                            (mesh.rs:201-203)
 //   Transform::hit enter object space, inner object, leave      (transform.rs:152-165)
 // so the kernel's closest-hit update ("accept when t <= best", later wins ties)
@@ -31,7 +31,8 @@ struct Builder {
     double media_extent = 0.;  // largest |coordinate| of the media's bounding boxes: scatter points inside a medium are ray origins too
     std::map<int, uint32_t> medium_of;
     int medium_depth = 0;
-    std::map<int, uint32_t> sphere_of, rect_of, tri_of, xform_of;
+    std::map<int, uint32_t> sphere_of, rect_of, tri_of, xform_of;  // (rect_of: rectangles and cubes share the rect table)
+    int n_cubes = 0;
     std::vector<uint32_t> mesh_base;
     uint32_t kinds = 0;
     int xf_depth = 0, depth = 0, max_depth = 0;
@@ -131,7 +132,19 @@ struct Builder {
                 }
                 break;
             }
-            case OBJ_CUBE:
+            case OBJ_CUBE: {  // one record in the rect table + one node (flat.h NK_CUBE); o.box is exactly (box_min, box_max), cube.rs:67-69
+                auto it = rect_of.find(id);
+                if (it == rect_of.end()) {
+                    it = rect_of.emplace(id, (uint32_t)rect_mat.size()).first;
+                    rects.insert(rects.end(), {o.box.mn[0], o.box.mn[1], o.box.mn[2], o.box.mx[0], o.box.mx[1], o.box.mx[2]});
+                    rect_mat.push_back(o.material);
+                    n_cubes++;
+                }
+                if (it->second >= (1u << (32 - NK_BITS - 3))) throw RtError(RT_ERR_UNSUPPORTED, "scene too large for the cube payload (record index * 8 + side)");
+                uint32_t n = node(NK_CUBE, it->second * 8u);
+                accel_item(id, o, NK_CUBE | ((it->second * 8u) << NK_BITS), n);
+                break;
+            }
             case OBJ_LIST:
             case OBJ_MESH:
                 for (int c : o.children) emit(c);
@@ -677,7 +690,8 @@ void flatten(rt_scene& s) {
     in.n_nodes = (int32_t)v.n_nodes;
     in.n_boxes = (int32_t)(b.boxes.size() / 6);
     in.n_spheres = (int32_t)b.sphere_mat.size();
-    in.n_rects = (int32_t)b.rect_mat.size();
+    in.n_rects = (int32_t)b.rect_mat.size() - b.n_cubes;
+    in.n_cubes = b.n_cubes;
     in.n_tris = (int32_t)(b.tris.size() / 4);
     in.n_xforms = (int32_t)(b.xforms.size() / 32);
     in.n_materials = (int32_t)mats.size();

@@ -77,7 +77,7 @@ OBJECT_TYPES = ("Sphere", "Rect", "Cube", "Triangle", "Mesh", "Transform", "Hita
 
 class rt_scene_info(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("n_nodes", "n_boxes", "n_spheres", "n_rects", "n_tris", "n_xforms", "n_materials",
-                                         "n_textures", "n_verts", "max_depth", "committed", "reserved")] + [("bytes", C.c_uint64)] + \
+                                         "n_textures", "n_verts", "max_depth", "committed", "n_cubes")] + [("bytes", C.c_uint64)] + \
                [(n, C.c_int32) for n in ("accel_ok", "accel_nodes", "accel_items", "accel_instances", "accel_stack", "accel_compact")]
 
     def as_dict(self):

@@ -168,7 +168,7 @@ pub struct rt_scene_info {
     pub n_verts: i32,
     pub max_depth: i32,
     pub committed: i32,
-    pub reserved: i32,
+    pub n_cubes: i32,
     pub bytes: u64,
     pub accel_ok: i32,
     pub accel_nodes: i32,

@@ -1,0 +1,176 @@
+"""`Cube` as ONE device primitive (flat.h NK_CUBE; objects/cube.rs:9-70): a cube is one 48-byte record, one node of the reference-order
+program and one accel item; the kernel's cube_hit restates Cube::hit = the six-rectangle scan of hit.rs:56-67 in Cube::new's side order
+with the shrinking closest_so_far.  The oracle keeps the reference's shape (six rectangle objects in a Vec), so every comparison below
+is "one-primitive scan on the GPU" against "six objects on the CPU": closest-hit records on explicit rays (incl. rays lying exactly in
+a side's plane -- SURVEY a11's NaN -- rays along edges and through corners, origins on faces and inside), exact ties between cubes that
+share a face and between a cube side and a coplanar rectangle (the later-visited object wins), cubes under rotated / non-uniform
+Transforms, image-textured cubes (uv of the winning side), and rendered images with every traversal kernel."""
+import numpy as np
+import pytest
+
+from conftest import scene_path
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(B, variant):
+    """the same scene on both builders (rtamd.World / oracle.Scene share the reference's constructor names)"""
+    rng = np.random.default_rng(5)
+    white = B.Lambertian(B.ConstantTexture((0.73, 0.73, 0.73)))
+    red = B.Lambertian(B.ConstantTexture((0.65, 0.05, 0.05)))
+    glass = B.Dielectric(1.5, B.ConstantTexture((1.0, 1.0, 1.0)))
+    metal = B.Metal(B.ConstantTexture((0.8, 0.85, 0.88)), 0.1)
+    yy, xx = np.mgrid[0:16, 0:32]
+    img = np.stack([(xx * 8) % 256, (yy * 16) % 256, ((xx + yy) * 5) % 256], axis=-1).astype(np.uint8)
+    tex = B.Lambertian(B.ImageTexture(img))
+    light = B.DiffuseLight(B.ConstantTexture((6.0, 6.0, 6.0)))
+    items = [
+        B.Cube((0.0, 0.0, 0.0), (2.0, 1.0, 2.0), white),
+        B.Cube((2.0, 0.0, 0.0), (4.0, 1.5, 2.0), red),            # shares the face x = 2 with the first (exact ties on it)
+        B.Cube((0.0, 1.0, 0.0), (2.0, 2.0, 1.0), tex),            # stacked: shares y = 1; image texture -> uv of the winning side
+        B.Cube((-3.0, 0.0, -1.0), (-1.0, 2.5, 1.0), glass),       # paths refract through it, origins end up ON its faces
+        B.Cube((5.0, 0.0, -2.0), (6.0, 3.0, -1.0), metal),
+        B.XZRectangle((0.0, 0.0), (2.0, 2.0), 1.0, red),          # coplanar with the first cube's top and the third's bottom
+        B.XYRectangle((-10.0, -1.0), (10.0, 8.0), 6.0, white),    # back wall
+        B.XZRectangle((-10.0, -10.0), (10.0, 10.0), 0.0, white),  # floor: coplanar with every cube's bottom
+        B.XZRectangle((-2.0, -2.0), (4.0, 3.0), 7.5, light),
+        B.Sphere((1.0, 2.6, 0.5), 0.6, glass),
+    ]
+    if variant >= 1:   # cubes under Transforms (rotated, non-uniform scale) and many small ones in a BVH of their own
+        items.append(B.Transform((20.0, 35.0, 10.0), (1.5, 0.7, 1.2), (-4.0, 3.0, 2.0), B.Cube((-1.0, -1.0, -1.0), (1.0, 1.0, 1.0), tex)))
+        small = []
+        for _ in range(40):
+            c = rng.uniform(-6.0, 6.0, 3)
+            e = rng.uniform(0.1, 0.6, 3)
+            small.append(B.Cube(tuple(float(v) for v in c - e), tuple(float(v) for v in c + e), white if rng.random() < 0.5 else metal))
+        items.append(B.Transform((0.0, 30.0, 0.0), (1.0, 1.0, 1.0), (0.0, 4.0, 0.0), B.BVHNode_new(small, 7)))
+        items.append(B.Cube((7.0, 0.0, 0.0), (7.0, 2.0, 2.0), red))   # degenerate: zero thickness along x
+    return items
+
+
+def _pair(variant, as_list=False):
+    import oracle
+    import rtamd
+    w = rtamd.World()
+    o = oracle.Scene()
+    if as_list:   # a plain Vec<Arc<dyn Hitable>> root: the reference-order program is a list scan, the cubes keep their file order
+        w.set_root(w.HitableList(_build(w, variant)))
+        w.commit()
+        o.set_root(o.HitableList(_build(o, variant)))
+    else:
+        w.new(_build(w, variant), bvh_seed=3)
+        o.World(_build(o, variant), 3)
+    cam_args = ((1.0, 3.0, -9.0), (1.0, 1.5, 0.0), (0.0, 1.0, 0.0), 45.0, 4.0 / 3.0, 0.05, 9.0)
+    o.Camera(*cam_args)
+    f, t, up, vfov, asp, ap, fd = cam_args
+    return w, rtamd.Camera((f, t), up, vfov, asp, ap, fd), o
+
+
+def _rays():
+    rng = np.random.default_rng(9)
+    rays = []
+    for _ in range(1500):                                           # random rays towards the cubes from outside
+        o = rng.uniform(-8.0, 8.0, 3) + np.array([0.0, 4.0, -6.0])
+        rays.append(np.concatenate([o, rng.uniform(-3.0, 5.0, 3) - o]))
+    for _ in range(400):                                            # origins inside the first cubes
+        o = rng.uniform(0.05, 0.95, 3) * np.array([4.0, 1.0, 2.0])
+        rays.append(np.concatenate([o, rng.normal(size=3)]))
+    # axis-parallel rays: zero direction components -> t = +-inf / NaN in the side tests
+    for o in [(1.0, 0.5, -5.0), (1.0, 1.0, -5.0), (2.0, 0.5, -5.0), (0.0, 0.0, -5.0), (2.0, 1.0, -5.0), (3.0, 1.5, -5.0)]:
+        rays.append(np.array(o + (0.0, 0.0, 1.0)))                  # along z: in the planes y = 1, x = 2, through edges and corners
+    for o in [(-5.0, 0.5, 1.0), (-5.0, 1.0, 1.0), (-5.0, 1.0, 2.0), (-5.0, 0.0, 0.0), (-5.0, 1.5, 1.0)]:
+        rays.append(np.array(o + (1.0, 0.0, 0.0)))
+    for o in [(1.0, 9.0, 1.0), (2.0, 9.0, 1.0), (2.0, 9.0, 2.0), (0.0, 9.0, 0.0), (3.0, 9.0, 0.5)]:
+        rays.append(np.array(o + (0.0, -1.0, 0.0)))
+    rays.append(np.array([-5.0, 1.0, -5.0, 1.0, 0.0, 1.0]))         # in the plane y = 1, diagonal
+    rays.append(np.array([2.0, -3.0, 1.0, 0.0, 1.0, 0.0]))          # in the plane x = 2 shared by two cubes
+    rays.append(np.array([0.0, 0.0, 0.0, 1.0, 1.0, 1.0]))           # from a corner along the diagonal
+    rays.append(np.array([2.0, 1.0, 2.0, -1.0, -0.5, -1.0]))        # from a corner into the cube
+    return np.array(rays)
+
+
+@pytest.mark.parametrize("as_list", [False, True])
+@pytest.mark.parametrize("variant", [0, 1])
+def test_cube_hit_records_match_the_six_rectangle_scan(variant, as_list):
+    world, _, ref = _pair(variant, as_list)
+    info = world.info()
+    assert info["n_cubes"] == (5 if variant == 0 else 47) and info["n_rects"] == 4
+    rays = _rays()
+    outs = {k: world.debug_hit(rays, t_min=1e-3, kernel=k) for k in (1, 2, 3)}
+    nhit = nan = 0
+    for i, r in enumerate(rays):
+        h = ref.hit(r[:3], r[3:], t_min=1e-3)
+        for k, out in outs.items():
+            got = out[i]
+            if h is not None and not (h["t"] == h["t"]):             # a NaN hit (ray in a side's plane): kernel 1 follows the reference's order
+                nan += k == 1
+                if k == 1:
+                    assert got[0] == 1.0 and not (got[1] == got[1]), (i, got)
+                continue
+            assert (h is not None) == bool(got[0]), "ray %d kernel %d: hit/miss mismatch (%s)" % (i, k, r)
+            if h is None:
+                continue
+            assert got[1] == h["t"], (i, k, got[1], h["t"])
+            assert np.array_equal(got[2:5], h["p"]) and np.array_equal(got[5:8], h["normal"]) and bool(got[8]) == h["front_face"], (i, k)
+            assert (got[9], got[10]) == h["uv"], (i, k, got[9:11], h["uv"])   # uv of the winning SIDE (the rectangle's own formula)
+        nhit += h is not None
+    assert nhit > len(rays) // 3
+    assert np.array_equal(outs[1], outs[2], equal_nan=True) or nan > 0       # incl. the winning node's reference-order index
+    finite = np.isfinite(outs[1][:, 1])
+    assert np.array_equal(outs[1][finite], outs[2][finite]) and np.array_equal(outs[2][finite], outs[3][finite])
+
+
+@pytest.mark.parametrize("kernel", [0, 1, 2])
+@pytest.mark.parametrize("variant,as_list", [(0, False), (1, False), (1, True)])
+def test_cube_scene_renders_bit_exact(variant, as_list, kernel):
+    world, cam, ref = _pair(variant, as_list)
+    img, st = world.render(cam, width=96, height=72, spp=12, seed=4, kernel=kernel)
+    exp, _ = ref.render(96, 72, 12, seed=4)
+    assert np.array_equal(img, exp, equal_nan=True), "%d pixels differ" % int((img != exp).any(axis=2).sum())
+    assert img.max() > 0 and (kernel == 0 or st["kernel_used"] == kernel)
+    if kernel != 1:
+        img1, _ = world.render(cam, width=96, height=72, spp=12, seed=4, integrator=0, kernel=1)
+        assert np.array_equal(img, img1, equal_nan=True)
+
+
+def test_cube_with_light_sampling_and_sppm_bit_exact():
+    """the other two integrators on a scene whose diffuse surfaces are cube sides"""
+    import oracle
+    import rtamd
+    def build(B):
+        white = B.Lambertian(B.ConstantTexture((0.73, 0.73, 0.73)))
+        light = B.XZRectLight((1.0, 1.0), (3.0, 3.0), 5.9, (4.0, 4.0, 4.0), 1000.0)
+        items = [B.Cube((0.0, 0.0, 0.0), (1.5, 1.0, 1.5), white), B.Cube((2.0, 0.0, 2.0), (3.5, 2.0, 3.5), B.Metal(B.ConstantTexture((0.9, 0.9, 0.9)), 0.0)),
+                 B.XZRectangle((-1.0, -1.0), (5.0, 5.0), 0.0, white), B.XZRectangle((-1.0, -1.0), (5.0, 5.0), 6.0, white),
+                 B.XYRectangle((-1.0, 0.0), (5.0, 6.0), 5.0, white), B.YZRectangle((0.0, -1.0), (6.0, 5.0), -1.0, white),
+                 B.YZRectangle((0.0, -1.0), (6.0, 5.0), 5.0, white), light]
+        return items, light
+    w = rtamd.World()
+    items, light = build(w)
+    w.new(items, lights=[light], bvh_seed=2)
+
+    class OB:  # the oracle's builder has no light constructors: compose them as light.rs:134-146 does
+        def __init__(self, o):
+            self.o = o
+
+        def __getattr__(self, n):
+            return getattr(self.o, n)
+
+        def XZRectLight(self, xz0, xz1, y, flux, scale):
+            return self.o.XZRectangle(xz0, xz1, y, self.o.DiffuseLight(self.o.ConstantTexture(flux)))
+
+    o = oracle.Scene()
+    items, light = build(OB(o))
+    o.World(items, 2)
+    o.set_lights([light], flux=[(4.0, 4.0, 4.0)], scale=[1000.0])
+    cam_args = ((2.0, 3.0, -7.0), (2.0, 2.0, 2.0), (0.0, 1.0, 0.0), 50.0, 1.0, 0.0, 10.0)
+    o.Camera(*cam_args)
+    f, t, up, vfov, asp, ap, fd = cam_args
+    cam = rtamd.Camera((f, t), up, vfov, asp, ap, fd)
+    for kernel in (1, 2):
+        img, _ = w.render(cam, width=48, height=48, spp=8, seed=2, integrator=1, kernel=kernel)
+        exp, _ = o.render(48, 48, 8, seed=2, integrator=1)
+        assert np.array_equal(img, exp, equal_nan=True)
+    img, stats, tot, _ = w.render_sppm(cam, width=32, height=32, spp=3, seed=2, iterations=3, photons_per_iter=5000)
+    exp, est, etot = o.render_sppm(32, 32, 3, iterations=3, photons_per_iter=5000, k_global=100, k_caustic=50, seed=2)
+    assert tot == etot and np.array_equal(stats, est) and np.array_equal(img, exp, equal_nan=True)

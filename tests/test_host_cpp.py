@@ -24,7 +24,7 @@ def test_vec3_selftest_of_the_cpp_mirror():
 
 def test_cornell_graph_walk_and_scene_files():
     r = run("--describe", "--cube", scene_path("cube.obj"))
-    assert r.returncode == 0 and "60 nodes (26 boxes, 2 spheres, 12 rects, 12 tris, 1 xforms)" in r.stdout, r.stdout + r.stderr
+    assert r.returncode == 0 and "55 nodes (26 boxes, 2 spheres, 6 rects, 12 tris, 1 xforms)" in r.stdout, r.stdout + r.stderr
     r = run("--describe", "--scene", scene_path("scene_500.json"))
     assert r.returncode == 0 and "999 boxes, 1005 spheres" in r.stdout
     r = run("--describe", "--scene", scene_path("test.json"))

@@ -142,8 +142,8 @@ def test_cornell_box_scene_structure():
     import rtamd
     w, cam = rtamd.select_scene(scene_path("cube.obj"))
     info = w.info()
-    # scene.rs:16-112: 5 walls + light + 6 cube sides = 12 rects, 2 spheres, 12 mesh triangles in one Transform
-    assert (info["n_rects"], info["n_spheres"], info["n_tris"], info["n_xforms"]) == (12, 2, 12, 1)
+    # scene.rs:16-112: 5 walls + light = 6 rects, 1 Cube (one record, its 6 sides are scanned by the kernel), 2 spheres, 12 mesh triangles in one Transform
+    assert (info["n_rects"], info["n_cubes"], info["n_spheres"], info["n_tris"], info["n_xforms"]) == (6, 1, 2, 12, 1)
     assert tuple(cam.c.look_from) == (278.0, 278.0, -800.0) and cam.c.vfov == 50.0 and cam.c.aperture == 0.0
 
 
