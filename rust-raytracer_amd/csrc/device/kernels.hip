@@ -278,12 +278,16 @@ DEV bool rect_hit(const double2* r, int axis, D3 o, D3 d, double t_min, double t
 // test (:20-25, :58-63, :95-100: t = (k - o) / d; reject t < t_min || t > closest_so_far; then the two bounds) with the closest hit so
 // far shrinking from side to side, so a later side wins an exact tie and a NaN t (a ray in a side's plane) propagates as
 // in the reference.  c: (min.x, min.y) (min.z, max.x) (max.y, max.z).  Returns the winning side.
-DEV bool cube_hit(const double2* c, D3 o, D3 d, double t_min, double t_max, double& t_out, uint32_t& side_out) {
-    const double2 c0 = c[0], c1 = c[1], c2 = c[2];
-    const double mnx = c0.x, mny = c0.y, mnz = c1.x, mxx = c1.y, mxy = c2.x, mxz = c2.y;
+// Kept OUT OF LINE: inlined into the leaf loops it raised the spill count of every GENERAL kernel by a quarter (pt_kernel<true, true, 2, 0>:
+// 100 -> 126 spilled VGPRs) and cost the Cornell box 17 % although one ray in a dozen meets its cube.
+struct CubeHit {
+    double t;
+    int side;  // -1: no side was hit
+};
+__device__ __attribute__((noinline)) CubeHit cube_hit_sides(double mnx, double mny, double mnz, double mxx, double mxy, double mxz, double ox, double oy,
+                                                            double oz, double dx, double dy, double dz, double t_min, double t_max) {
     double best = t_max;
-    bool any = false;
-    uint32_t side = 0;
+    int side = -1;
 #define RT_CUBE_SIDE(S, K, OK, DK, OA, DA, A0, A1, OB, DB, B0, B1)     \
     {                                                                  \
         const double t = ((K) - (OK)) / (DK);                          \
@@ -292,20 +296,27 @@ DEV bool cube_hit(const double2* c, D3 o, D3 d, double t_min, double t_max, doub
             if (!(pa < (A0) || pa > (A1) || pb < (B0) || pb > (B1))) { \
                 best = t;                                              \
                 side = (S);                                            \
-                any = true;                                            \
             }                                                          \
         }                                                              \
     }
-    RT_CUBE_SIDE(0u, mnz, o.z, d.z, o.x, d.x, mnx, mxx, o.y, d.y, mny, mxy)
-    RT_CUBE_SIDE(1u, mxz, o.z, d.z, o.x, d.x, mnx, mxx, o.y, d.y, mny, mxy)
-    RT_CUBE_SIDE(2u, mny, o.y, d.y, o.x, d.x, mnx, mxx, o.z, d.z, mnz, mxz)
-    RT_CUBE_SIDE(3u, mxy, o.y, d.y, o.x, d.x, mnx, mxx, o.z, d.z, mnz, mxz)
-    RT_CUBE_SIDE(4u, mnx, o.x, d.x, o.y, d.y, mny, mxy, o.z, d.z, mnz, mxz)
-    RT_CUBE_SIDE(5u, mxx, o.x, d.x, o.y, d.y, mny, mxy, o.z, d.z, mnz, mxz)
+    RT_CUBE_SIDE(0, mnz, oz, dz, ox, dx, mnx, mxx, oy, dy, mny, mxy)
+    RT_CUBE_SIDE(1, mxz, oz, dz, ox, dx, mnx, mxx, oy, dy, mny, mxy)
+    RT_CUBE_SIDE(2, mny, oy, dy, ox, dx, mnx, mxx, oz, dz, mnz, mxz)
+    RT_CUBE_SIDE(3, mxy, oy, dy, ox, dx, mnx, mxx, oz, dz, mnz, mxz)
+    RT_CUBE_SIDE(4, mnx, ox, dx, oy, dy, mny, mxy, oz, dz, mnz, mxz)
+    RT_CUBE_SIDE(5, mxx, ox, dx, oy, dy, mny, mxy, oz, dz, mnz, mxz)
 #undef RT_CUBE_SIDE
-    t_out = best;
-    side_out = side;
-    return any;
+    CubeHit r;
+    r.t = best;
+    r.side = side;
+    return r;
+}
+DEV bool cube_hit(const double2* c, D3 o, D3 d, double t_min, double t_max, double& t_out, uint32_t& side_out) {
+    const double2 c0 = c[0], c1 = c[1], c2 = c[2];
+    const CubeHit r = cube_hit_sides(c0.x, c0.y, c1.x, c1.y, c2.x, c2.y, o.x, o.y, o.z, d.x, d.y, d.z, t_min, t_max);
+    t_out = r.t;
+    side_out = r.side < 0 ? 0u : (uint32_t)r.side;
+    return r.side >= 0;
 }
 DEV D3 ld3(const double* p, uint32_t i) { return mk(p[3 * i], p[3 * i + 1], p[3 * i + 2]); }
 // Triangle::hit, mesh.rs:57-102 ; returns t and the barycentrics b1,b2
