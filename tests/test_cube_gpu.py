@@ -98,10 +98,17 @@ def test_cube_hit_records_match_the_six_rectangle_scan(variant, as_list):
     rays = _rays()
     outs = {k: world.debug_hit(rays, t_min=1e-3, kernel=k) for k in (1, 2, 3)}
     nhit = nan = nuv = touch = 0
+    planes = [{0.0, 2.0, 4.0, -3.0, -1.0, 5.0, 6.0, 7.0}, {0.0, 1.0, 1.5, 2.0, 2.5, 3.0}, {0.0, 1.0, 2.0, -1.0, -2.0}]
     for i, r in enumerate(rays):
         h = ref.hit(r[:3], r[3:], t_min=1e-3)
+        # a ray lying exactly IN a side's plane: that side's t is 0/0 = NaN, which passes every reject of rectangle.rs and then poisons
+        # closest_so_far for whatever the reference visits next: the outcome depends on the visit order, which only the
+        # reference-order kernel shares (measure zero)
+        in_plane = any(r[3 + a] == 0.0 and r[a] in planes[a] for a in range(3))
         for k, out in outs.items():
             got = out[i]
+            if in_plane and k != 1:
+                continue
             if h is not None and not (h["t"] == h["t"]):             # a NaN hit (ray in a side's plane): kernel 1 follows the reference's order
                 nan += k == 1
                 if k == 1:
@@ -126,7 +133,7 @@ def test_cube_hit_records_match_the_six_rectangle_scan(variant, as_list):
         nhit += h is not None
     assert nhit > len(rays) // 3 and nuv > 10
     assert touch <= 2 * 40, touch                                            # only rays that start inside a cube and leave through a shared face
-    finite = np.isfinite(outs[1][:, 1])
+    finite = np.isfinite(outs[1][:, 1]) & np.isfinite(outs[2][:, 1]) & np.array([not any(r[3 + a] == 0.0 and r[a] in planes[a] for a in range(3)) for r in rays])
     same = finite & (outs[1][:, 11] == outs[2][:, 11])
     assert same.sum() >= finite.sum() - 40
     assert np.array_equal(outs[1][same], outs[2][same]) and np.array_equal(outs[2][finite], outs[3][finite])   # incl. the winning node's reference-order index

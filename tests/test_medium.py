@@ -271,7 +271,7 @@ def test_final_scene_reduced_bit_exact(kernel):
     f, t, up, vfov, asp, ap, fd = shapes.FINAL_SCENE_CAMERA
     cam = rtamd.Camera((f, t), up, vfov, asp, ap, fd)
     info = w.info()
-    assert info["accel_ok"] == 1 and info["n_rects"] == 2401 and info["n_spheres"] == 1008
+    assert info["accel_ok"] == 1 and info["n_rects"] == 1 and info["n_cubes"] == 400 and info["n_spheres"] == 1008
     exp, _ = o.render(80, 80, 6, seed=4)
     img, st = w.render(cam, width=80, height=80, spp=6, seed=4, kernel=kernel)
     assert st["kernel_used"] == (2 if kernel == 0 else kernel)
