@@ -125,6 +125,7 @@ def test_cube_hit_records_match_the_six_rectangle_scan(variant, as_list):
                 # shares with the next) is never visited, and the earlier object keeps the hit; kernel 1 walks the reference's own boxes
                 # and agrees with the oracle (asserted above for k == 1), the accel kernels test every candidate and give the tie to the
                 # later object.  Same t, p, normal, front_face -- checked above -- but another object's material / uv.
+                assert 1500 <= i < 1900, i                               # only rays that START inside a cube leave it through a shared face
                 touch += 1
                 continue
             if got[9] != 0.0 or got[10] != 0.0:                        # (the product computes uv only for a material that reads it: an ImageTexture)
@@ -132,10 +133,10 @@ def test_cube_hit_records_match_the_six_rectangle_scan(variant, as_list):
                 nuv += k == 1
         nhit += h is not None
     assert nhit > len(rays) // 3 and nuv > 10
-    assert touch <= 2 * 40, touch                                            # only rays that start inside a cube and leave through a shared face
+    assert touch == 0 or not as_list                                         # (a list root has no boxes: nothing is culled, every tie goes to the later object)
     finite = np.isfinite(outs[1][:, 1]) & np.isfinite(outs[2][:, 1]) & np.array([not any(r[3 + a] == 0.0 and r[a] in planes[a] for a in range(3)) for r in rays])
     same = finite & (outs[1][:, 11] == outs[2][:, 11])
-    assert same.sum() >= finite.sum() - 40
+    assert same.sum() >= finite.sum() - touch
     assert np.array_equal(outs[1][same], outs[2][same]) and np.array_equal(outs[2][finite], outs[3][finite])   # incl. the winning node's reference-order index
 
 
