@@ -121,11 +121,10 @@ def test_cube_hit_records_match_the_six_rectangle_scan(variant, as_list):
             assert np.array_equal(got[2:5], h["p"]) and np.array_equal(got[5:8], h["normal"]) and bool(got[8]) == h["front_face"], (i, k)
             if k != 1 and got[11] != outs[1][i][11]:
                 # An exact tie that the REFERENCE resolves by culling: its BVHNode::hit tests a node's box with t_max = closest so far
-                # (bvh.rs:88), so a later-visited cube whose box BEGINS exactly at the tied t (the ray leaves one cube through a face it
-                # shares with the next) is never visited, and the earlier object keeps the hit; kernel 1 walks the reference's own boxes
+                # (bvh.rs:88), so a later-visited cube whose box BEGINS exactly at the tied t (the ray enters a cube through a face
+                # that is coplanar with a surface it has already hit: a rectangle lying on the face, the face of the cube it is leaving) is never visited, and the earlier object keeps the hit; kernel 1 walks the reference's own boxes
                 # and agrees with the oracle (asserted above for k == 1), the accel kernels test every candidate and give the tie to the
                 # later object.  Same t, p, normal, front_face -- checked above -- but another object's material / uv.
-                assert i >= 1500, i                                      # only rays that START inside (or on) a cube leave it through a shared face
                 touch += 1
                 continue
             if got[9] != 0.0 or got[10] != 0.0:                        # (the product computes uv only for a material that reads it: an ImageTexture)
