@@ -50,7 +50,10 @@ struct MediumDev {  // objects/medium.rs:9-13
     int32_t pad;
     // where the medium sits in the reference-order program (the accel kernel walks the two copies of the boundary's subtree itself:
     // [n_begin + 1, n_mid) and [n_mid + 1, n_end)); n_end is also the node index of the medium's hit (tie rule)
-    uint32_t n_begin, n_mid, n_end, pad2;
+    uint32_t n_begin, n_mid, n_end;
+    // kind | payload << 4 of the boundary when it is ONE world-space sphere (0 otherwise): the accel kernel then answers the two boundary
+    // queries with two sphere tests instead of two walks over the medium's part of the program (the same Sphere::hit calls, medium.rs:26-27)
+    uint32_t boundary_kp;
 };
 struct MatDev {   // material.rs:88-212 (+ :213-231, the commented-out Isotropic)
     int32_t type;  // 0 Lambertian, 1 Metal, 2 Dielectric, 3 DiffuseLight, 4 Isotropic

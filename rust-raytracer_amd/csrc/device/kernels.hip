@@ -815,6 +815,24 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
 // final surface candidate is S; a medium's hit depends only on t_max at its visit = what precedes it, which is what S_M and the
 // earlier media hits give; the reference's own box tests cull a medium exactly when its clipped interval is empty (no draw
 // either way), up to rays that graze a reference box within f64 rounding (the measure-zero caveat of kernel 2).
+// rec1 = boundary.hit(r, -inf, +inf); rec2 = boundary.hit(r, rec1.t + 0.0001, +inf) (medium.rs:26-27): false unless both exist.
+// A boundary that is one world-space sphere (MediumDev::boundary_kp) is asked directly -- the walk over its one-node subtree would make
+// exactly these two Sphere::hit calls, after three f64 divisions for box tests that never come.
+DEV bool medium_boundary(const Acc& A, const MediumDev& M, D3 o, D3 d, double& t_a, double& t_b) {
+    if (M.boundary_kp != 0u) {
+        const double2* s = A.spheres + 2 * (M.boundary_kp >> NK_BITS);
+        const double a = sqlen(d);
+        if (!sphere_hit(s, o, d, a, -INFINITY, INFINITY, t_a)) return false;
+        return sphere_hit(s, o, d, a, t_a + 0.0001, INFINITY, t_b);
+    }
+    const Hit r1h = traverse<true, false>(A, o, d, -INFINITY, INFINITY, nullptr, M.n_begin + 1u, M.n_mid);
+    if (r1h.node < 0) return false;
+    const Hit r2h = traverse<true, false>(A, o, d, r1h.t + 0.0001, INFINITY, nullptr, M.n_mid + 1u, M.n_end);
+    if (r2h.node < 0) return false;
+    t_a = r1h.t;
+    t_b = r2h.t;
+    return true;
+}
 template <bool GENERAL, bool TOP, bool WIDE>
 DEV Hit traverse2_media(const Acc& A, uint32_t n_media, uint32_t* stk, const int stride, D3 o, D3 d, double t_min, Rng& rng) {
     // 1. the boundary queries of the media (no random number is drawn here); the first two media the ray crosses are TRACKED by the
@@ -829,16 +847,14 @@ DEV Hit traverse2_media(const Acc& A, uint32_t n_media, uint32_t* stk, const int
     double ta0 = 0., tb0 = 0., ta1 = 0., tb1 = 0.;
     for (uint32_t k = 0; k < n_media; k++) {
         const MediumDev M = A.media[k];
-        const Hit r1h = traverse<true, false>(A, o, d, -INFINITY, INFINITY, nullptr, M.n_begin + 1u, M.n_mid);
-        if (r1h.node < 0) continue;
-        const Hit r2h = traverse<true, false>(A, o, d, r1h.t + 0.0001, INFINITY, nullptr, M.n_mid + 1u, M.n_end);
-        if (r2h.node < 0) continue;
+        double qa, qb;
+        if (!medium_boundary(A, M, o, d, qa, qb)) continue;
         if (tk0 == 0xFFFFFFFFu) {
-            tk0 = k; ta0 = r1h.t; tb0 = r2h.t;
-            K.lim[0] = M.n_begin; K.exitt[0] = r2h.t;
+            tk0 = k; ta0 = qa; tb0 = qb;
+            K.lim[0] = M.n_begin; K.exitt[0] = qb;
         } else {
-            tk1 = k; ta1 = r1h.t; tb1 = r2h.t;
-            K.lim[1] = M.n_begin; K.exitt[1] = r2h.t;
+            tk1 = k; ta1 = qa; tb1 = qb;
+            K.lim[1] = M.n_begin; K.exitt[1] = qb;
             k_rest = k + 1u;
             break;
         }
@@ -860,12 +876,7 @@ DEV Hit traverse2_media(const Acc& A, uint32_t n_media, uint32_t* stk, const int
             t_max = fmin(t_max, (k == tk0) ? K.T[0] : K.T[1]);
         } else if (k >= k_rest) {  // a third, fourth ... crossed medium: its own queries, and a restricted walk where needed
             M = A.media[k];
-            const Hit r1h = traverse<true, false>(A, o, d, -INFINITY, INFINITY, nullptr, M.n_begin + 1u, M.n_mid);
-            if (r1h.node < 0) continue;
-            const Hit r2h = traverse<true, false>(A, o, d, r1h.t + 0.0001, INFINITY, nullptr, M.n_mid + 1u, M.n_end);
-            if (r2h.node < 0) continue;
-            t_a = r1h.t;
-            t_b = r2h.t;
+            if (!medium_boundary(A, M, o, d, t_a, t_b)) continue;
             if (S.node >= 0) {
                 if ((uint32_t)S.node < M.n_begin) {
                     t_max = fmin(t_max, S.t);

@@ -222,6 +222,12 @@ struct Builder {
                 media[mi].n_begin = beg;
                 media[mi].n_mid = mid;
                 media[mi].n_end = end;
+                {
+                    const ObjectRec& bo = s.objects[o.children[0]];
+                    auto si = sphere_of.find(o.children[0]);
+                    if (bo.type == OBJ_SPHERE && xf_depth == 0 && si != sphere_of.end() && mid == beg + 2 && end == mid + 2)
+                        media[mi].boundary_kp = NK_SPHERE | (si->second << NK_BITS);
+                }
                 medium_depth--;
                 break;
             }
