@@ -820,10 +820,30 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
 // exactly these two Sphere::hit calls, after three f64 divisions for box tests that never come.
 DEV bool medium_boundary(const Acc& A, const MediumDev& M, D3 o, D3 d, double& t_a, double& t_b) {
     if (M.boundary_kp != 0u) {
+        // Both Sphere::hit calls (sphere.rs:24-43) see the same ray and sphere, so oc, half_b, c, the discriminant and its root are the
+        // same numbers in both: computed once; each call's root selection is then replayed on the two roots with its own [t_min, t_max].
         const double2* s = A.spheres + 2 * (M.boundary_kp >> NK_BITS);
-        const double a = sqlen(d);
-        if (!sphere_hit(s, o, d, a, -INFINITY, INFINITY, t_a)) return false;
-        return sphere_hit(s, o, d, a, t_a + 0.0001, INFINITY, t_b);
+        const double2 c0 = s[0], c1 = s[1];
+        const D3 oc = mk(o.x - c0.x, o.y - c0.y, o.z - c1.x);
+        const double radius = c1.y, a = sqlen(d);
+        const double half_b = dot(oc, d);
+        const double c = sqlen(oc) - radius * radius;
+        const double disc = half_b * half_b - a * c;
+        if (disc < 0.) return false;
+        const double sq = sqrt(disc);
+        const double r1 = (-half_b - sq) / a, r2 = (-half_b + sq) / a;
+        // rec1 = hit(r, -inf, +inf): the near root unless it is NaN, then the far one
+        double ta = r1;
+        if (!(ta >= -INFINITY && ta <= INFINITY)) ta = r2;
+        if (!(ta >= -INFINITY && ta <= INFINITY)) return false;
+        // rec2 = hit(r, rec1.t + 0.0001, +inf)
+        const double lo = ta + 0.0001;
+        double tb = r1;
+        if (!(tb >= lo && tb <= INFINITY)) tb = r2;
+        if (!(tb >= lo && tb <= INFINITY)) return false;
+        t_a = ta;
+        t_b = tb;
+        return true;
     }
     const Hit r1h = traverse<true, false>(A, o, d, -INFINITY, INFINITY, nullptr, M.n_begin + 1u, M.n_mid);
     if (r1h.node < 0) return false;
