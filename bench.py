@@ -28,6 +28,14 @@ Extra objects on the JSON line (definitions and formulas: DESIGN.md s5):
   roofline_hbm      -- physical HBM traffic (PMC, carried over) / kernel time against the HBM peak.
   cpu_baseline      -- the oracle (a C++ port of the reference's CPU path; the Rust binary cannot be
                        built here) on this box's host cores, bounded sample, rank 0 at N=1 only.
+  ranks             -- one entry per rank (all_gather at the end of the timed region): tiles owned, samples, summed pt_kernel time
+                       (HIP events inside librtamd), time of gather + stitch (HIP events on the step's stream; the RCCL gather is
+                       ordered against it by torch), wall time of the rank's timed loop.  Lets an N-GPU line tell imbalance from
+                       exchange from launch cost.  Present at every world size (one entry at world 1).
+
+`--single-process` renders the same frames through rt_render_multi instead (ONE process, one host thread per GPU inside librtamd,
+RCCL gather linked into the library -- what a Rust / C++ host calls); same JSON line, "launch": "single-process".  The default,
+and what the driver starts, is one process per GPU over torch.distributed.
 """
 import argparse
 import json
@@ -179,6 +187,14 @@ def roofline_objects(stats_acc, dt_kernel_s, clock_note=None, model_path=None, a
         peak = N_SIMDS * clk / cyc
         frac = achieved / peak if peak > 0 else None
         roof.update({"achieved": achieved, "peak": peak, "frac": frac, "lane_utilisation": model["lane_utilisation"],
+                     # the counter that does not depend on any cycle table: 4 * SQ_ACTIVE_INST_VALU / SIMD cycles of the PMC pass
+                     "valu_busy_measured": model.get("valu_busy_measured"),
+                     "cost_table": {"cycles_per_wave64_instruction": model.get("valu_class_cycles"),
+                                    "measured_classes": "f32 add/mul/fma, f64 add/mul/fma/ldexp/div_fixup, conversions, v_mul_lo_u32, integer add/xor/shift/alignbit, "
+                                                        "compare + v_cndmask, f32 min/max, f32 and f64 rcp/rsq/sqrt (tools/microbench/valu_cost.hip, "
+                                                        "profiles/r03/valu_cost_microbench.txt; anchored on f64 fma = 4 cycles)",
+                                    "unmeasured_priced_as_other": "v_mov, v_readlane / v_writelane (SGPR spill moves), LDS-address adds, v_perm / bfe: priced at "
+                                                                  "the 3.5-cycle average of the measured integer / compare classes"},
                      "useful_frac": frac * model["lane_utilisation"] if frac else None,
                      "valu_insts_per_sample": ipc, "valu_issue_cycles_per_inst": cyc, "clock_ghz": clk, "clock_ghz_in_pmc_pass": model["clock_ghz"],
                      "valu_mix_per_sample": model.get("valu_mix_per_sample"),
@@ -198,6 +214,58 @@ def roofline_objects(stats_acc, dt_kernel_s, clock_note=None, model_path=None, a
     return roof, contract, hbm
 
 
+def single_process(args):
+    """`--single-process`: the same frames through rt_render_multi -- what a Rust / C++ host's one capture_image call does.  The timed
+    region per step is the whole call: fan-out over the devices, render, RCCL gather of the rows to devices[0], stitch, copy to the host
+    (34.6 MB: the PCIe-inclusive figure; the per-GPU-process mode above keeps the frame on the device)."""
+    import rtamd
+    n_dev = rtamd.device_count()
+    if n_dev < 1:
+        raise SystemExit("bench.py needs a HIP device: the product has no CPU fallback")
+    devices = [int(x) for x in args.devices.split(",")] if args.devices else list(range(args.gpus))
+    if len(devices) != args.gpus and args.devices:
+        args.gpus = len(devices)
+    if max(devices) >= n_dev:
+        raise SystemExit("bench.py: device ordinal %d asked for, %d HIP device(s) visible" % (max(devices), n_dev))
+    world, cam = rtamd.load_scene_file(SCENE)
+    kw = dict(devices=devices, width=args.width, height=args.height, spp=args.spp, max_depth=50, t_min=1e-3, seed=args.seed, kernel=args.kernel)
+    for _ in range(args.warmup):
+        world.render_multi(cam, **kw)
+    acc = [{"kernel_ms": 0.0, "samples": 0, "launches": 0} for _ in devices]
+    exch = 0.0
+    rows = 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        img, st = world.render_multi(cam, **kw)
+        for a, s in zip(acc, st):
+            a["kernel_ms"] += s["kernel_ms"]; a["samples"] += s["samples"]; a["launches"] += s["launches"]
+        exch += st[0]["exchange_seconds"]
+        rows = st[0]["rows_through_rccl"]
+    dt = time.perf_counter() - t0
+    total = args.width * args.height * args.spp * args.steps
+    slowest = max(acc, key=lambda a: a["kernel_ms"])
+    roof, contract, hbm = roofline_objects(slowest, dt)
+    out = {"metric": "Msamples/sec (px*spp), scene_500 %dx%d %dspp" % (args.width, args.height, args.spp), "value": total / dt / 1e6, "unit": "Msamples/s",
+           "n_gpus": len(set(devices)), "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+           "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+           "data": "the reference's own scene file data/scene_500.json (committed copy, minified); no dataset or checkpoint involved",
+           "config": {"workload": "tests/golden/scenes/scene_500.json: 1005 spheres, 999-node file BVH, %dx%d, %d spp, depth 50, seed %d" % (args.width, args.height, args.spp, args.seed),
+                      "parallelism": "rt_render_multi: image tiles 8x8 dealt round-robin to %d rank(s) on HIP devices %s, one host thread per rank, RCCL gather inside librtamd" % (len(devices), devices)},
+           "launch": "single-process", "wall_s": dt, "rccl_version": rtamd.lib().rt_rccl_version(), "rows_through_rccl_per_step": rows,
+           "includes": "host copy of the stitched frame (PCIe) in every step",
+           "ranks": [{"rank": i, "device": d, "samples": a["samples"], "kernel_ms": a["kernel_ms"], "kernel_ms_per_step": a["kernel_ms"] / max(1, args.steps)}
+                     for i, (d, a) in enumerate(zip(devices, acc))],
+           "exchange_stitch_copy_ms_per_step": exch / max(1, args.steps) * 1e3,
+           "roofline": roof, "roofline_contract": contract}
+    if hbm is not None:
+        out["roofline_hbm"] = hbm
+    if args.frame_out:
+        import numpy as np
+        np.save(args.frame_out, img)
+    print(json.dumps(out))
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -213,10 +281,15 @@ def main():
                     help="world 1 only: create the RCCL process group anyway and drive the N-rank exchange through it (init, gather of "
                          "the f64 device rows, barrier, all_reduce(MAX)); also RTAMD_BENCH_FORCE_PG=1")
     ap.add_argument("--frame-out", default=None, help="rank 0 writes the stitched f64 frame [H, W, 3] of the last step to this .npy file")
+    ap.add_argument("--single-process", action="store_true",
+                    help="render through rt_render_multi: one process, one host thread per GPU inside librtamd, RCCL gather linked into the library")
+    ap.add_argument("--devices", default=None, help="--single-process only: comma-separated HIP ordinals, one per rank (may repeat; default 0..gpus-1)")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
 
+    if args.single_process:
+        sys.exit(single_process(args))
     ws_env = os.environ.get("WORLD_SIZE")
     if ws_env is None:
         if args.gpus > 1:
@@ -263,7 +336,7 @@ def main():
 
     world, cam = rtamd.load_scene_file(SCENE)
     params = rtamd.default_params(width=args.width, height=args.height, spp=args.spp, max_depth=50, t_min=1e-3, seed=args.seed,
-                                  rank=rank, world=world_size, kernel=args.kernel)
+                                  rank=rank, world=world_size, kernel=args.kernel, device=dev_index)
     from rtamd.distributed import TileLayout, TileGather
     layout = TileLayout(args.width, args.height, world_size)
     p0 = rtamd.default_params(width=args.width, height=args.height, spp=args.spp, rank=0, world=world_size)
@@ -276,13 +349,20 @@ def main():
 
     stats_acc = {"kernel_ms": 0.0, "launches": 0, "samples": 0}
     last = {}
+    ex_events = []  # (before the gather, after the stitch) per timed step, on the step's stream
 
     def step(timed):
         st = world.render_tiles_device(cam, params, d_tiles.data_ptr(), stream)
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         # the stitch of camera.rs:115-123 across GPUs: ONE framebuffer gather to rank 0 over RCCL/xGMI
         src = gather(d_tiles)
         if rank == 0:
             rtamd.assemble_frame_device(p0, src.data_ptr(), stride, frame.data_ptr(), stream)
+        if timed:
+            e1.record()
+            ex_events.append((e0, e1))
         if timed:
             stats_acc["kernel_ms"] += st["kernel_ms"]
             stats_acc["launches"] += st["launches"]
@@ -303,10 +383,17 @@ def main():
         step(True)
     sync()
     dt = time.perf_counter() - t0
+    # per-rank record: [tiles owned, samples, pt_kernel ms (HIP events in librtamd), gather + stitch ms (HIP events), wall s of the timed loop]
+    mine = [float(layout.owned(rank)), float(stats_acc["samples"]), stats_acc["kernel_ms"], sum(a.elapsed_time(b) for a, b in ex_events), dt]
+    per_rank = [mine]
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        rec = torch.tensor(mine, dtype=torch.float64, device="cpu" if rehearse else dev)
+        recs = [torch.zeros_like(rec) for _ in range(world_size)]
+        dist.all_gather(recs, rec)
+        per_rank = [[float(x) for x in r.cpu()] for r in recs]
 
     if rank == 0:
         total = args.width * args.height * args.spp * args.steps
@@ -330,9 +417,12 @@ def main():
         }
         if hbm is not None:
             out["roofline_hbm"] = hbm
+        out["launch"] = "one process per GPU (torch.distributed)" if world_size > 1 or force_pg else "one process"
+        out["ranks"] = [{"rank": i, "tiles": int(r[0]), "samples": int(r[1]), "kernel_ms": r[2], "exchange_ms": r[3], "loop_wall_s": r[4],
+                         "kernel_ms_per_step": r[2] / max(1, args.steps), "exchange_ms_per_step": r[3] / max(1, args.steps)} for i, r in enumerate(per_rank)]
         if backend is not None:
             out["process_group"] = {"backend": backend + (" (RCCL)" if backend == "nccl" else ""), "world": world_size, "forced_at_world_1": bool(force_pg),
-                                    "calls": ["init_process_group", "gather", "barrier", "all_reduce(MAX)"]}
+                                    "calls": ["init_process_group", "gather", "barrier", "all_reduce(MAX)", "all_gather"]}
         if args.frame_out:
             import numpy as np
             np.save(args.frame_out, frame.cpu().numpy().reshape(args.height, args.width, 3))

@@ -515,6 +515,7 @@ int rt_render_tiles_device(const rt_scene* s, const rt_camera* cam, const rt_par
         if (device_count() < 1) throw RtError(RT_ERR_NO_DEVICE, "no HIP device: librtamd has no CPU fallback");
         auto t0 = std::chrono::steady_clock::now();
         RenderPlan pl = make_plan(p);
+        if (p->device >= 0) dev_set_device(p->device);  // (d_tiles and hip_stream must belong to it)
         CameraDev cd = make_camera(*cam);
         if (stats) std::memset(stats, 0, sizeof(*stats));
         render_tiles(*s, cd, pl, d_tiles, hip_stream, stats);
@@ -545,6 +546,7 @@ int rt_render_sppm_tiles_device(const rt_scene* s, const rt_camera* cam, const r
         rt_params q = *p;
         q.integrator = 0;
         RenderPlan pl = make_plan(&q);
+        if (p->device >= 0) dev_set_device(p->device);
         CameraDev cd = make_camera(*cam);
         rt_stats st{};
         render_sppm(*s, cd, pl, *cfg, d_tiles, nullptr, hip_stream, &st, nullptr);

@@ -103,6 +103,10 @@ def test_two_rank_branch_of_bench_rehearsed_on_one_gpu():
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and "rehearsal" in out
     assert out["value"] > 0 and "cpu_baseline" not in out
+    # the per-rank record that makes an N-GPU line diagnosable: tiles, samples, kernel time, gather + stitch time, loop wall time
+    assert [r["rank"] for r in out["ranks"]] == [0, 1] and sum(r["tiles"] for r in out["ranks"]) == 12 * 9
+    assert sum(r["samples"] for r in out["ranks"]) == 96 * 72 * 8 and all(r["kernel_ms"] > 0 and r["loop_wall_s"] > 0 for r in out["ranks"])
+    assert all("exchange_ms" in r for r in out["ranks"]) and out["ranks"][0]["exchange_ms"] > 0
     # without the rehearsal switch the same command must refuse to run two ranks on one device
     r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--width", "96", "--height", "72", "--spp", "8", "--cpu-spp", "0"])
     import rtamd
@@ -153,11 +157,31 @@ def test_forced_process_group_runs_the_rccl_exchange_at_world_1(how, tmp_path):
         assert k in out, k
     assert out["steps"] == 2 and out["warmup"] == 1 and out["higher_is_better"] is True and out["vs_baseline"] is None and out["dtype"] == "f64"
     assert "workload" in out["config"] and "model" not in out["config"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "valu_busy_measured", "cost_table"):
         assert k in out["roofline"], k
+    assert "measured_classes" in out["roofline"]["cost_table"] and "unmeasured_priced_as_other" in out["roofline"]["cost_table"]
+    assert len(out["ranks"]) == 1 and out["ranks"][0]["tiles"] == 12 * 9 and out["ranks"][0]["samples"] == 96 * 72 * 8 * 2
+    assert out["ranks"][0]["kernel_ms"] > 0 and out["ranks"][0]["exchange_ms"] > 0 and "all_gather" in pg["calls"]
     if how == "flag":
         cb = out["cpu_baseline"]
         assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb and "cpu_model" in cb and cb["reference_default"]["cores"] <= 8
     assert len([ln for ln in r.stdout.splitlines() if ln.strip()]) == 1      # ONE line on stdout (RCCL's banner goes to stderr)
     got = np.load(out_npy)
     assert got.shape == (72, 96, 3) and np.array_equal(got, _plain_frame(96, 72, 8))
+
+
+@pytest.mark.gpu
+def test_single_process_mode_renders_through_rt_render_multi(tmp_path):
+    """`bench.py --single-process --devices 0,0`: the frame through ONE rt_render_multi call per step (two ranks on the one device there
+    is), same JSON contract, frame bit-identical to the plain render."""
+    import numpy as np
+    out_npy = str(tmp_path / "frame.npy")
+    r = _run(["--single-process", "--devices", "0,0", "--steps", "2", "--warmup", "1", "--width", "96", "--height", "72", "--spp", "8", "--cpu-spp", "0",
+              "--frame-out", out_npy])
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["launch"] == "single-process" and out["n_gpus"] == 1 and out["value"] > 0 and out["rccl_version"] >= 20000
+    assert [x["device"] for x in out["ranks"]] == [0, 0] and sum(x["samples"] for x in out["ranks"]) == 96 * 72 * 8 * 2
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in out, k
+    assert np.array_equal(np.load(out_npy), _plain_frame(96, 72, 8))
