@@ -90,10 +90,10 @@ typedef struct rt_params {
     int32_t kernel;      /* 0 = auto; 1 = reference-order stackless traversal; 2 = SAH-BVH2 accel traversal (auto whenever the
                             scene has a usable accel); 5 = kernel 2's BVH with the cooperative instance service: the walks
                             through mesh instances are queued per workgroup and served by full waves (auto when an
-                            instance's object-space BVH has >= 64 nodes; needs 1..32 instances of f32-vertex triangles);
+                            instance's object-space BVH has >= 64 nodes; needs 1..64 instances, at least one of f32-vertex triangles);
                             6 = the same service across the whole GPU and across launches (parked paths in HBM pools, a
-                            dedicated walk launch per cycle; 1..64 instances; auto only for 33..64 large instances -- it is
-                            slower than kernel 5 where both apply; workspace ~8.6 GB).
+                            dedicated walk launch per cycle; 1..64 instances; by request only -- it is slower than
+                            kernel 5; workspace within rt_tuning.wf_workspace_mb, default 1.9 GB).
                             All give bit-identical images (same f64 primitive tests, same tie rule). */
     int32_t device;      /* HIP device ordinal; -1 = current */
     int32_t integrator;  /* 0 = sample_ray as the reference structures it (BSDF sampling only; default);
@@ -135,6 +135,8 @@ typedef struct rt_tuning {
     int32_t sppm_knn_candidates;   /* >= 0: k-nearest candidates kept in LDS (0 forces the out-of-LDS selection); -1 auto */
     int32_t multi_force_rccl;      /* 1: rt_render_multi sends EVERY rank's rows through the RCCL communicator, also those that already sit on
                                       the root device (a rank then sends to itself): exercises the exchange on a one-GPU box; 0 auto      */
+    int32_t wf_workspace_mb;       /* > 0: kernel 6's workspace budget in MB (unit buffers + record pools; default 1900); 8600 = what round 3 took */
+    int32_t reserved;
     double sah_box_cost;           /* > 0: accel builder, SAH cost of a box-pair test relative to 2.0 per primitive; 0 auto */
 } rt_tuning;
 void rt_tuning_default(rt_tuning* t);

@@ -111,6 +111,7 @@ int rt_tuning_set(const rt_tuning* t) {
         n.sppm_cap = std::max(0, t->sppm_photon_capacity);
         n.knn_cand = t->sppm_knn_candidates < 0 ? -1 : t->sppm_knn_candidates;
         n.multi_force_rccl = t->multi_force_rccl != 0;
+        n.wf_workspace_mb = std::max(0, t->wf_workspace_mb);
         n.c_box = t->sah_box_cost;
         {
             std::lock_guard<std::mutex> g(g_tuning_mu);

@@ -1855,9 +1855,9 @@ static_assert(COOP_RING >= 2 * COOP_POOL && COOP_POOL <= 32768 && (COOP_RING & (
 #ifndef COOP_SUSPEND_TH
 #define COOP_SUSPEND_TH 24  // ... and suspends its walks when fewer than this are left and no request waits
 #endif
-static const int COOP_MAX_INST = 32;     // one pending bit per instance
+static const int COOP_MAX_INST = 64;     // one pending bit per instance (the upper 32 travel in the record's last unit, only when a scene has more than 32)
 static const int COOP_STACK_MAX = 40;    // stack entries a suspended walk can save (scenes with deeper BVHs use kernel 2)
-static const int COOP_REC = 20 + COOP_STACK_MAX / 2;  // u64 per pool slot, read and written in 16-byte units (two u64):
+static const int COOP_REC = 20 + COOP_STACK_MAX / 2 + 2;  // u64 per pool slot, read and written in 16-byte units (two u64):
 //   unit 0..2  [0..5]  the segment's ray o, d in WORLD space (the serving lane applies the instance's M^-1: transform.rs:153-156)
 //   unit 3     [6] best t so far   [7] kind|payload of the best hit so far << 32 | its order          (as posted with the request)
 //   unit 4     [8] node to continue at (initially the instance's root) << 32 | xform of the best hit so far + 1
@@ -1865,6 +1865,7 @@ static const int COOP_REC = 20 + COOP_STACK_MAX / 2;  // u64 per pool slot, read
 //   unit 5     [10] t   [11] kind|payload << 32 | order      of the walk so far / of the answer (order unchanged = nothing closer inside)
 //   unit 6..9  [12..14] beta   [15..17] L   [18] rng   [19] depth << 32 | pix_id
 //   unit 10..  the saved stack of a suspended walk, four entries per unit
+//   unit 20    [40] instances 32..63 still deferred (written and read only by scenes with more than 32 instances)
 // Records are only touched by waves of one workgroup, i.e. of one CU, whose L1 they share: plain loads and stores, ordered by
 // s_waitcnt vmcnt(0) before the slot id is published through LDS (workgroup-scope release / acquire on gfx950).
 typedef unsigned long long U2 __attribute__((ext_vector_type(2)));
@@ -2320,13 +2321,13 @@ __device__ __attribute__((noinline)) void coop_serve(const CoopArgs* args, char*
 }
 
 // A path whose deferred instances cannot be parked (pool exhausted; rare): walk them here, as the plain kernel would.
-__device__ __attribute__((noinline)) Hit coop_walk_inline(const CoopArgs* args, char* lds0, uint32_t* stk_generic, D3 o, D3 d, Hit h, uint32_t pend) {
+__device__ __attribute__((noinline)) Hit coop_walk_inline(const CoopArgs* args, char* lds0, uint32_t* stk_generic, D3 o, D3 d, Hit h, uint64_t pend) {
     const CoopCtx X = coop_ctx(args, lds0);
     const Acc& A = X.A;
     uint32_t* stk = AS_LDS(uint32_t, stk_generic);
-    while (pend != 0u) {
-        const uint32_t ni = (uint32_t)(__ffs((int)pend) - 1);
-        pend &= pend - 1u;
+    while (pend != 0ull) {
+        const uint32_t ni = (uint32_t)(__ffsll((long long)pend) - 1);
+        pend &= pend - 1ull;
         const uint2 in = A.inst2[ni];
         const double* Minv = A.xforms + 32 * in.x;
         const D3 oo = xf_point(Minv, o), dd = xf_dir(Minv, d);
@@ -2452,7 +2453,8 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
     D3 o = mk(0, 0, 0), d = mk(0, 0, 1), beta = mk(1, 1, 1), L = mk(0, 0, 0);
     int depth = 0, pix_id = 0;
     uint32_t out_slot = 0;  // owner wave << 12 | (ring slot * UNIT_SPP + sample within the unit) * 64 + pixel
-    uint32_t pend = 0u;
+    uint64_t pend = 0ull;  // deferred instances of the current segment, one bit each
+    const bool wide_pend = sv.n_inst2 > 32u;  // (wave-uniform: the upper half travels in the record's last unit)
     int dec_slot = -1;      // a finished path whose unit counter still has to be decremented (owner wave << 12 | slot index)
     int fold_wait = 0;      // iterations until the head of the ring is looked at again (wave-uniform)
     Rng rng;
@@ -2528,16 +2530,16 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
                     out_slot = ((uint32_t)wave << 12) | (((uint32_t)cur_slot * (uint32_t)UNIT_SPP + (uint32_t)(k >> 6)) * (uint32_t)TILE_PIX + (uint32_t)pix);
                     alive = true;
                     ready = false;
-                    pend = 0u;
+                    pend = 0ull;
                 }
             }
         }
         COOP_TIME(0);
         // ---- world-space walk of the lanes that start a segment, instances deferred ----
-        if (__ballot(alive && !ready && pend == 0u) != 0ull) COOP_STAT(2, __ballot(alive && !ready && pend == 0u));
-        if (alive && !ready && pend == 0u) {  // (pend != 0: a path between two deferred instances of one segment)
-            h = traverse2<true, true, true, false, uint32_t, false, MIXED>(A, stk, stk_stride, o, d, rk.t_min, INFINITY, &pend);
-            if (pend == 0u) ready = true;
+        if (__ballot(alive && !ready && pend == 0ull) != 0ull) COOP_STAT(2, __ballot(alive && !ready && pend == 0ull));
+        if (alive && !ready && pend == 0ull) {  // (pend != 0: a path between two deferred instances of one segment)
+            h = traverse2<true, true, true, false, uint64_t, false, MIXED>(A, stk, stk_stride, o, d, rk.t_min, INFINITY, &pend);
+            if (pend == 0ull) ready = true;
         }
         COOP_TIME(1);
         // ---- enter the first deferred instance of each such path: the top of its BVH is in LDS (NodeQ cache), so the lane walks
@@ -2550,7 +2552,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
                 uint32_t ent_cur = REF_DONE, ni = 0u;
                 int ent_sp = 0;
                 if (want) {
-                    ni = (uint32_t)(__ffs((int)pend) - 1);
+                    ni = (uint32_t)(__ffsll((long long)pend) - 1);
                     const double* Minv = A.xforms + 32 * A.inst2[ni].x;
                     const D3 oo = xf_point(Minv, o), dd = xf_dir(Minv, d);
                     const double* g = qgrid_lds + 8 * ni;
@@ -2584,8 +2586,8 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
                         }
                     }
                     if (ent_cur == REF_DONE) {  // nothing of this instance within reach: next one (next iteration), or shade
-                        pend &= pend - 1u;
-                        if (pend == 0u) ready = true;
+                        pend &= pend - 1ull;
+                        if (pend == 0ull) ready = true;
                     }
                 }
                 const bool need = want && ent_cur != REF_DONE;
@@ -2594,7 +2596,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
                 COOP_RING_T1;
                 const bool park = need && id >= 0;
                 if (park) {
-                    pend &= pend - 1u;
+                    pend &= pend - 1ull;
                     const int n = ent_sp / stk_stride;
                     uint64_t* q = pool_mem + (size_t)COOP_REC * (size_t)id;
                     st_unit(q, 0, dbits(o.x), dbits(o.y));
@@ -2602,7 +2604,8 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
                     st_unit(q, 2, dbits(d.y), dbits(d.z));
                     st_unit(q, 3, dbits(h.t), ((uint64_t)h.kp << 32) | (uint64_t)(uint32_t)h.node);
                     st_unit(q, 4, ((uint64_t)ent_cur << 32) | (uint64_t)(uint32_t)(h.xf + 1),
-                            ((uint64_t)pend << 32) | ((uint64_t)(n + 1) << 24) | (uint64_t)(ni << 16) | (uint64_t)out_slot);  // a suspended walk
+                            (pend << 32) | ((uint64_t)(n + 1) << 24) | (uint64_t)(ni << 16) | (uint64_t)out_slot);  // a suspended walk
+                    if (wide_pend) st_unit(q, 10 + COOP_STACK_MAX / 4, pend >> 32, 0ull);
                     st_unit(q, 5, dbits(h.t), (uint64_t)(uint32_t)h.node);  // its best so far: what the world-space walk found
                     st_unit(q, 6, dbits(beta.x), dbits(beta.y));
                     st_unit(q, 7, dbits(beta.z), dbits(L.x));
@@ -2620,7 +2623,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
                 if (__ballot(need && id < 0) != 0ull) {
                     if (need && id < 0) {
                         h = coop_walk_inline(cargs, smem, stk, o, d, h, pend);
-                        pend = 0u;
+                        pend = 0ull;
                         ready = true;
                     }
                 }
@@ -2655,14 +2658,16 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
                         h.kp = (uint32_t)(u5.y >> 32);
                         h.xf = (int)A.inst2[inst].x;
                     }
-                    pend = (uint32_t)(u4.y >> 32);
+                    pend = u4.y >> 32;
+                    if (wide_pend) pend |= ld_unit(q, 10 + COOP_STACK_MAX / 4).x << 32;
                     out_slot = (uint32_t)u4.y & 0xffffu;
-                    if (pend != 0u) {  // next deferred instance of the same segment: the path stays parked, new request
-                        const uint32_t ni = (uint32_t)(__ffs((int)pend) - 1);
-                        pend &= pend - 1u;
+                    if (pend != 0ull) {  // next deferred instance of the same segment: the path stays parked, new request
+                        const uint32_t ni = (uint32_t)(__ffsll((long long)pend) - 1);
+                        pend &= pend - 1ull;
                         st_unit(q, 3, dbits(h.t), ((uint64_t)h.kp << 32) | (uint64_t)(uint32_t)h.node);
                         st_unit(q, 4, ((uint64_t)A.inst2[ni].y << 32) | (uint64_t)(uint32_t)(h.xf + 1),
-                                ((uint64_t)pend << 32) | (uint64_t)(ni << 16) | (uint64_t)out_slot);
+                                (pend << 32) | (uint64_t)(ni << 16) | (uint64_t)out_slot);
+                        if (wide_pend) st_unit(q, 10 + COOP_STACK_MAX / 4, pend >> 32, 0ull);
                         repost = true;
                     } else {
                         o = mk(bitsd(u0.x), bitsd(u0.y), bitsd(u1.x));
@@ -2721,7 +2726,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
                 }
             }
             ready = false;
-            pend = 0u;
+            pend = 0ull;
             if (done) {  // into the ring slot of the wave that generated the path; its unit counter moves next iteration
                 double* dst = bring + (size_t)(out_slot >> 12) * RING_UNITS * UNIT_DOUBLES + 3 * (size_t)(out_slot & 0xfffu);
                 dst[0] = L.x;
@@ -3116,11 +3121,11 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
     // kernel 5 / kernel 2 in Msamples/s: 120 triangles 1351 / 1182 (kernel 2 LDS-resident), 1 600: 1263 / 822, 25 600: 1035 / 517,
     // 102 400: 861 / 427, 409 600: 746 / 370; the 12-triangle cube of the reference's Cornell box: 2507 / 2533)
     // (kernel 6, the wavefront form of the same service, reaches 766 Msamples/s on C4 where kernel 5 reaches 891 and kernel 2 469: it is
-    // the automatic choice only where kernel 5 does not apply -- 33..64 instances -- and otherwise by request)
+    // since round 4 kernel 5 takes up to 64 instances too, so kernel 6 runs by request only)
     if (kernel == 0)
         kernel = accel2_usable ? ((coop_usable && view.max_inst_nodes2 >= 64u) ? 5 : (wf_usable && !coop_usable && view.max_inst_nodes2 >= 64u) ? 6 : 2) : 1;
     if (kernel == 5 && !coop_usable)
-        throw RtError(RT_ERR_UNSUPPORTED, "kernel 5 (cooperative instance service) needs a usable accel, 1..32 instances of which at least one holds only triangles with f32 vertices (an OBJ mesh), of BVH depth <= 40");
+        throw RtError(RT_ERR_UNSUPPORTED, "kernel 5 (cooperative instance service) needs a usable accel, 1..64 instances of which at least one holds only triangles with f32 vertices (an OBJ mesh), of BVH depth <= 40");
     if (kernel == 6 && !wf_usable)
         throw RtError(RT_ERR_UNSUPPORTED, "kernel 6 (wavefront instance service) needs a usable accel and 1..64 instances of which at least one holds only triangles with f32 vertices (an OBJ mesh)");
     if ((kernel == 2 || kernel == 5) && !accel2_usable)
@@ -3374,11 +3379,22 @@ static void render_tiles_wf(const rt_scene& s, const FlatView& view, const Camer
     HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc_w, (const void*)wf_walk_kernel, WF_WALK_BLOCK, lds_walk));
     if (bpc_w < 1) bpc_w = 1;
     const int grid_w = di.cus * bpc_w;
-    uint32_t seg = WF_SEG_DEFAULT;
+    // Workspace within a budget (rt_tuning.wf_workspace_mb; default 1 900 MB -- the first version took 8.6 GB flat: 96 unit buffers per
+    // wave and 32 768 records per workgroup segment, twice): 60 % of it for the waves' unit buffers, never more than the launch has units
+    // for; 40 % for the two record pools.  Fewer buffers / shorter segments cost speed (waves sit on full rings, the gate closes more
+    // often), never results.
+    const size_t budget = (size_t)(tun.wf_workspace_mb > 0 ? tun.wf_workspace_mb : 1900) * 1000000u;
+    const size_t n_waves6 = (size_t)grid * (PT_BLOCK / 64);
+    const int64_t units_per_tile = (std::min(plan.spp, plan.spp_chunk) + plan.sub_spp - 1) / plan.sub_spp;
+    const int64_t need_units = (plan.tiles_owned * units_per_tile + (int64_t)n_waves6 - 1) / (int64_t)n_waves6 + 2;
+    uint32_t ring_units = (uint32_t)std::min<size_t>((size_t)WF_RING_UNITS, (budget * 6 / 10) / (n_waves6 * UNIT_DOUBLES * sizeof(double)));
+    ring_units = std::max<uint32_t>(8u, std::min<uint32_t>(ring_units, (uint32_t)std::min<int64_t>(need_units, WF_RING_UNITS)));
+    uint32_t seg = (uint32_t)std::min<size_t>((size_t)WF_SEG_DEFAULT, (budget * 4 / 10) / ((size_t)2 * grid * WF_REC_U * 16) / WF_CHUNK * WF_CHUNK);
+    seg = std::max<uint32_t>(seg, 2 * WF_GATE);
     if (tun.coop_pool > 0) seg = std::max<uint32_t>(2 * WF_GATE, ((uint32_t)tun.coop_pool + WF_CHUNK - 1) / WF_CHUNK * WF_CHUNK);  // rt_tuning test hook: small segments
 
     const int64_t n_pix = plan.tiles_owned * TILE_PIX;
-    const size_t ring_bytes = (size_t)grid * (PT_BLOCK / 64) * WF_RING_UNITS * UNIT_DOUBLES * sizeof(double);
+    const size_t ring_bytes = n_waves6 * ring_units * UNIT_DOUBLES * sizeof(double);
     const size_t pool_bytes = (size_t)grid * seg * WF_REC_U * 16;
     const size_t off_cnt = 2 * pool_bytes, off_book = off_cnt + 2 * (size_t)grid * 4, off_misc = off_book + (size_t)grid * WF_BOOK_WORDS * 4;
     const size_t wf_bytes = off_misc + 256;  // misc: cursor, WF_BATCH unfinished words
@@ -3432,6 +3448,7 @@ static void render_tiles_wf(const rt_scene& s, const FlatView& view, const Camer
                 wa.unfinished = unf + b;
                 wa.seg = seg;
                 wa.first = cycle == 0 ? 1 : 0;
+                wa.ring_units = ring_units;
                 hipLaunchKernelGGL(fn, dim3(grid), dim3(PT_BLOCK), lds_pt, stream, view, ck, rk, (double*)lease.w->ring, (double*)lease.w->accum,
                                    (unsigned int*)lease.w->tickets, counter, err, wa);
                 HIP_CHECK(hipGetLastError());

@@ -93,7 +93,7 @@ namespace rtamd {
 
 // rt_tuning_set's process-wide state (abi.cpp): the only thing besides the arguments that influences a render
 struct Tuning {
-    int no_lds = 0, n_top = -1, sub_spp = 0, max_leaf = 0, sppm_cap = 0, knn_cand = -1, coop_pool = 0, multi_force_rccl = 0;
+    int no_lds = 0, n_top = -1, sub_spp = 0, max_leaf = 0, sppm_cap = 0, knn_cand = -1, coop_pool = 0, multi_force_rccl = 0, wf_workspace_mb = 0;
     double c_box = 0.;
 };
 Tuning tuning();  // a snapshot (copied under a mutex): take one per API call

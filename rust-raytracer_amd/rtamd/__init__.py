@@ -65,7 +65,7 @@ class rt_sppm_config(C.Structure):
 class rt_tuning(C.Structure):
     _fields_ = [("no_lds", C.c_int32), ("top_nodes", C.c_int32), ("sub_spp", C.c_int32), ("coop_pool", C.c_int32),
                 ("max_leaf", C.c_int32), ("sppm_photon_capacity", C.c_int32), ("sppm_knn_candidates", C.c_int32),
-                ("multi_force_rccl", C.c_int32), ("sah_box_cost", C.c_double)]
+                ("multi_force_rccl", C.c_int32), ("wf_workspace_mb", C.c_int32), ("reserved", C.c_int32), ("sah_box_cost", C.c_double)]
 
 
 class rt_object_desc(C.Structure):

@@ -130,6 +130,8 @@ pub struct rt_tuning {
     pub sppm_photon_capacity: i32,
     pub sppm_knn_candidates: i32,
     pub multi_force_rccl: i32,
+    pub wf_workspace_mb: i32,
+    pub reserved: i32,
     pub sah_box_cost: c_double,
 }
 
@@ -138,7 +140,7 @@ pub struct rt_tuning {
 impl Default for rt_tuning {
     fn default() -> Self {
         let mut t = rt_tuning { no_lds: 0, top_nodes: -1, sub_spp: 0, coop_pool: 0, max_leaf: 0, sppm_photon_capacity: 0,
-                                sppm_knn_candidates: -1, multi_force_rccl: 0, sah_box_cost: 0.0 };
+                                sppm_knn_candidates: -1, multi_force_rccl: 0, wf_workspace_mb: 0, reserved: 0, sah_box_cost: 0.0 };
         unsafe { rt_tuning_default(&mut t) };
         t
     }

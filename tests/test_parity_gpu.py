@@ -775,8 +775,10 @@ def test_wavefront_kernel_image_does_not_depend_on_partition_chunking_unit_size_
     assert st["launches"] > 8
 
 
-def test_wavefront_kernel_64_instances_bit_exact():
-    """64 Transform instances of three meshes (one pending bit per instance: the limit of kernel 6; kernel 5 stops at 32)."""
+@pytest.mark.parametrize("kernel", [5, 6])
+def test_wavefront_kernel_64_instances_bit_exact(kernel):
+    """64 Transform instances of three meshes (one pending bit per instance: the limit of kernels 5 and 6; kernel 5 stopped at 32 until
+    round 4 and carries the upper half of its mask in the last unit of a parked path's record)."""
     import rtamd
     from rtamd import shapes
     rng = np.random.default_rng(64)
@@ -794,17 +796,15 @@ def test_wavefront_kernel_64_instances_bit_exact():
     assert info["accel_instances"] == 64 and info["accel_compact"] == 1
     cam = _c4_scene()["cam"]
     a, _ = w.render(cam, width=128, height=128, spp=4, seed=8, kernel=2)
-    b, st = w.render(cam, width=128, height=128, spp=4, seed=8, kernel=6)
-    assert st["kernel_used"] == 6
-    _assert_same(b, a, "64 instances, kernel 6 against kernel 2")
+    b, st = w.render(cam, width=128, height=128, spp=4, seed=8, kernel=kernel)
+    assert st["kernel_used"] == kernel
+    _assert_same(b, a, "64 instances, kernel %d against kernel 2" % kernel)
     auto, st0 = w.render(cam, width=128, height=128, spp=4, seed=8)
-    assert st0["kernel_used"] == 6      # 33..64 large instances: kernel 5 does not apply, kernel 6 is the automatic choice
+    assert st0["kernel_used"] == 5      # kernel 5 applies up to 64 instances: kernel 6 runs by request only
     _assert_same(auto, a, "64 instances, automatic kernel")
     k1, _ = w.render(cam, width=48, height=48, spp=2, seed=8, kernel=1)
-    k6, _ = w.render(cam, width=48, height=48, spp=2, seed=8, kernel=6)
-    _assert_same(k6, k1, "64 instances, kernel 6 against the reference-order kernel")
-    with pytest.raises(rtamd.RtError):
-        w.render(cam, width=32, height=32, spp=1, seed=8, kernel=5)   # more than 32 instances
+    k6, _ = w.render(cam, width=48, height=48, spp=2, seed=8, kernel=kernel)
+    _assert_same(k6, k1, "64 instances, kernel %d against the reference-order kernel" % kernel)
 
 
 def test_flat_and_single_triangle_instances_bit_exact():
@@ -886,3 +886,24 @@ def test_mixed_instances_keep_the_instance_service():
     for k in (5, 6):
         b, _ = w.render(cam, width=200, height=200, spp=8, seed=5, kernel=k)
         _assert_same(b, a, "mixed instances at 200 x 200 x 8, kernel %d against kernel 2" % k)
+
+
+def test_wavefront_kernel_workspace_stays_within_its_budget(tuning):
+    """kernel 6 sizes its unit buffers and record pools from the launch and from rt_tuning.wf_workspace_mb (default 1 900 MB; round 3 took
+    8.6 GB flat): C4's frame stays below 2 GB, a smaller budget shrinks it further, and the image does not depend on the budget."""
+    import rtamd
+    c4 = _c4_scene()
+    w, cam = c4["world"], c4["cam"]
+    rtamd.release_workspaces()
+    img, st = w.render(cam, width=1200, height=1200, spp=8, seed=1, kernel=6)      # C4's own frame (its units per wave exceed any ring)
+    assert st["kernel_used"] == 6 and st["workspace_bytes"] < 2.0e9, st["workspace_bytes"]
+    tuning(wf_workspace_mb=700)
+    small, st2 = w.render(cam, width=1200, height=1200, spp=8, seed=1, kernel=6)
+    assert st2["workspace_bytes"] < 1.0e9 and np.array_equal(small, img)
+    tuning(wf_workspace_mb=8600)
+    rtamd.release_workspaces()
+    big, st3 = w.render(cam, width=1200, height=1200, spp=8, seed=1, kernel=6)
+    assert st3["workspace_bytes"] > st["workspace_bytes"] and np.array_equal(big, img)
+    k5, _ = w.render(cam, width=1200, height=1200, spp=8, seed=1, kernel=5)
+    assert np.array_equal(k5, img)
+    rtamd.release_workspaces()
