@@ -2347,7 +2347,9 @@ __device__ __attribute__((noinline)) Hit coop_walk_inline(const CoopArgs* args, 
     return h;
 }
 
-template <int INTEG, bool MIXED = false, bool EARLY = false>
+// PEND: the type of the per-path mask of deferred instances: uint32_t for scenes with up to 32 instances, uint64_t for 33..64 (the wider
+// mask costs the 32-instance scenes 5 % in registers: C4 837 instead of 883 Msamples/s, so it is a variant, not the default)
+template <int INTEG, bool MIXED = false, bool EARLY = false, typename PEND = uint32_t>
 __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam, RenderK rk, double* __restrict__ ring, double* accum,
                                                            unsigned int* tickets, unsigned int* __restrict__ counter, int* __restrict__ err, uint64_t* coop) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -2453,8 +2455,8 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
     D3 o = mk(0, 0, 0), d = mk(0, 0, 1), beta = mk(1, 1, 1), L = mk(0, 0, 0);
     int depth = 0, pix_id = 0;
     uint32_t out_slot = 0;  // owner wave << 12 | (ring slot * UNIT_SPP + sample within the unit) * 64 + pixel
-    uint64_t pend = 0ull;  // deferred instances of the current segment, one bit each
-    const bool wide_pend = sv.n_inst2 > 32u;  // (wave-uniform: the upper half travels in the record's last unit)
+    PEND pend = 0;  // deferred instances of the current segment, one bit each
+    constexpr bool wide_pend = sizeof(PEND) == 8;  // the upper half travels in the record's last unit
     int dec_slot = -1;      // a finished path whose unit counter still has to be decremented (owner wave << 12 | slot index)
     int fold_wait = 0;      // iterations until the head of the ring is looked at again (wave-uniform)
     Rng rng;
@@ -2530,16 +2532,16 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
                     out_slot = ((uint32_t)wave << 12) | (((uint32_t)cur_slot * (uint32_t)UNIT_SPP + (uint32_t)(k >> 6)) * (uint32_t)TILE_PIX + (uint32_t)pix);
                     alive = true;
                     ready = false;
-                    pend = 0ull;
+                    pend = (PEND)0;
                 }
             }
         }
         COOP_TIME(0);
         // ---- world-space walk of the lanes that start a segment, instances deferred ----
-        if (__ballot(alive && !ready && pend == 0ull) != 0ull) COOP_STAT(2, __ballot(alive && !ready && pend == 0ull));
-        if (alive && !ready && pend == 0ull) {  // (pend != 0: a path between two deferred instances of one segment)
-            h = traverse2<true, true, true, false, uint64_t, false, MIXED>(A, stk, stk_stride, o, d, rk.t_min, INFINITY, &pend);
-            if (pend == 0ull) ready = true;
+        if (__ballot(alive && !ready && pend == (PEND)0) != 0ull) COOP_STAT(2, __ballot(alive && !ready && pend == (PEND)0));
+        if (alive && !ready && pend == (PEND)0) {  // (pend != 0: a path between two deferred instances of one segment)
+            h = traverse2<true, true, true, false, PEND, false, MIXED>(A, stk, stk_stride, o, d, rk.t_min, INFINITY, &pend);
+            if (pend == (PEND)0) ready = true;
         }
         COOP_TIME(1);
         // ---- enter the first deferred instance of each such path: the top of its BVH is in LDS (NodeQ cache), so the lane walks
@@ -2552,7 +2554,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
                 uint32_t ent_cur = REF_DONE, ni = 0u;
                 int ent_sp = 0;
                 if (want) {
-                    ni = (uint32_t)(__ffsll((long long)pend) - 1);
+                    ni = (uint32_t)(__ffsll((long long)(uint64_t)pend) - 1);
                     const double* Minv = A.xforms + 32 * A.inst2[ni].x;
                     const D3 oo = xf_point(Minv, o), dd = xf_dir(Minv, d);
                     const double* g = qgrid_lds + 8 * ni;
@@ -2586,8 +2588,8 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
                         }
                     }
                     if (ent_cur == REF_DONE) {  // nothing of this instance within reach: next one (next iteration), or shade
-                        pend &= pend - 1ull;
-                        if (pend == 0ull) ready = true;
+                        pend &= pend - (PEND)1;
+                        if (pend == (PEND)0) ready = true;
                     }
                 }
                 const bool need = want && ent_cur != REF_DONE;
@@ -2596,7 +2598,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
                 COOP_RING_T1;
                 const bool park = need && id >= 0;
                 if (park) {
-                    pend &= pend - 1ull;
+                    pend &= pend - (PEND)1;
                     const int n = ent_sp / stk_stride;
                     uint64_t* q = pool_mem + (size_t)COOP_REC * (size_t)id;
                     st_unit(q, 0, dbits(o.x), dbits(o.y));
@@ -2604,8 +2606,8 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
                     st_unit(q, 2, dbits(d.y), dbits(d.z));
                     st_unit(q, 3, dbits(h.t), ((uint64_t)h.kp << 32) | (uint64_t)(uint32_t)h.node);
                     st_unit(q, 4, ((uint64_t)ent_cur << 32) | (uint64_t)(uint32_t)(h.xf + 1),
-                            (pend << 32) | ((uint64_t)(n + 1) << 24) | (uint64_t)(ni << 16) | (uint64_t)out_slot);  // a suspended walk
-                    if (wide_pend) st_unit(q, 10 + COOP_STACK_MAX / 4, pend >> 32, 0ull);
+                            ((uint64_t)pend << 32) | ((uint64_t)(n + 1) << 24) | (uint64_t)(ni << 16) | (uint64_t)out_slot);  // a suspended walk
+                    if (wide_pend) st_unit(q, 10 + COOP_STACK_MAX / 4, (uint64_t)pend >> 32, 0ull);
                     st_unit(q, 5, dbits(h.t), (uint64_t)(uint32_t)h.node);  // its best so far: what the world-space walk found
                     st_unit(q, 6, dbits(beta.x), dbits(beta.y));
                     st_unit(q, 7, dbits(beta.z), dbits(L.x));
@@ -2623,7 +2625,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
                 if (__ballot(need && id < 0) != 0ull) {
                     if (need && id < 0) {
                         h = coop_walk_inline(cargs, smem, stk, o, d, h, pend);
-                        pend = 0ull;
+                        pend = (PEND)0;
                         ready = true;
                     }
                 }
@@ -2658,16 +2660,16 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
                         h.kp = (uint32_t)(u5.y >> 32);
                         h.xf = (int)A.inst2[inst].x;
                     }
-                    pend = u4.y >> 32;
-                    if (wide_pend) pend |= ld_unit(q, 10 + COOP_STACK_MAX / 4).x << 32;
+                    pend = (PEND)(u4.y >> 32);
+                    if (wide_pend) pend |= (PEND)(ld_unit(q, 10 + COOP_STACK_MAX / 4).x << 32);
                     out_slot = (uint32_t)u4.y & 0xffffu;
-                    if (pend != 0ull) {  // next deferred instance of the same segment: the path stays parked, new request
-                        const uint32_t ni = (uint32_t)(__ffsll((long long)pend) - 1);
-                        pend &= pend - 1ull;
+                    if (pend != (PEND)0) {  // next deferred instance of the same segment: the path stays parked, new request
+                        const uint32_t ni = (uint32_t)(__ffsll((long long)(uint64_t)pend) - 1);
+                        pend &= pend - (PEND)1;
                         st_unit(q, 3, dbits(h.t), ((uint64_t)h.kp << 32) | (uint64_t)(uint32_t)h.node);
                         st_unit(q, 4, ((uint64_t)A.inst2[ni].y << 32) | (uint64_t)(uint32_t)(h.xf + 1),
-                                (pend << 32) | (uint64_t)(ni << 16) | (uint64_t)out_slot);
-                        if (wide_pend) st_unit(q, 10 + COOP_STACK_MAX / 4, pend >> 32, 0ull);
+                                ((uint64_t)pend << 32) | (uint64_t)(ni << 16) | (uint64_t)out_slot);
+                        if (wide_pend) st_unit(q, 10 + COOP_STACK_MAX / 4, (uint64_t)pend >> 32, 0ull);
                         repost = true;
                     } else {
                         o = mk(bitsd(u0.x), bitsd(u0.y), bitsd(u1.x));
@@ -2726,7 +2728,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
                 }
             }
             ready = false;
-            pend = 0ull;
+            pend = (PEND)0;
             if (done) {  // into the ring slot of the wave that generated the path; its unit counter moves next iteration
                 double* dst = bring + (size_t)(out_slot >> 12) * RING_UNITS * UNIT_DOUBLES + 3 * (size_t)(out_slot & 0xfffu);
                 dst[0] = L.x;
@@ -3105,7 +3107,7 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
     const size_t coop_world = coop_world_bytes(view);  // world-level tables, always in LDS for this kernel
     const size_t coop_lds = (size_t)3 * COOP_RING * sizeof(uint16_t) + 8 * sizeof(uint32_t) + ((sizeof(CoopArgs) + 15) & ~size_t(15)) + coop_world;  // + three rings of pool-slot ids, counters, argument block
     const bool coop_usable = accel2_usable && general && !media && view.coop_data_ok != 0 && view.n_inst2 >= 1 && view.n_inst2 <= (uint32_t)COOP_MAX_INST &&
-                             view.inst_depth2 <= (uint32_t)COOP_STACK_MAX && coop_world <= 16384 && stack5_bytes + coop_lds <= lds_max && plan.max_depth < (1 << 24);
+                             view.inst_depth2 <= (uint32_t)COOP_STACK_MAX && coop_world <= 32768 && stack5_bytes + coop_lds <= lds_max && plan.max_depth < (1 << 24);
     // kernel 6 = the same instance service across the whole GPU and across launches (wavefront.inc)
     const uint32_t stack6 = std::max<uint32_t>(std::max(view.world_depth2 + 2u, view.stack2_inline), (uint32_t)WF_ENTRY_STACK + 1u);
     const uint32_t n_entry6 = std::min<uint32_t>((uint32_t)COOP_ENTRY_NODES, view.n_nodes2);
@@ -3150,11 +3152,14 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
     pt_fn fn = (kernel == 1) ? pick_pt_kernel<1>(lds, general, integ) : pick_pt_kernel<2>(lds, general, integ);
     pt_coop_fn fn_coop = nullptr;
     pt_coop_fn fn_coop_early = nullptr;  // the variant that folds from the main loop: for a rank that owns few tiles (see pt_kernel_coop)
-    if (kernel == 5) {
+    if (kernel == 5 && view.n_inst2 <= 32u) {
         fn_coop_early = (view.n_inline2 != 0u) ? ((integ == 1) ? pt_kernel_coop<1, true, true> : (integ == 2) ? pt_kernel_coop<2, true, true> : pt_kernel_coop<0, true, true>)
                                                : ((integ == 1) ? pt_kernel_coop<1, false, true> : (integ == 2) ? pt_kernel_coop<2, false, true> : pt_kernel_coop<0, false, true>);
         fn_coop = (view.n_inline2 != 0u) ? ((integ == 1) ? pt_kernel_coop<1, true> : (integ == 2) ? pt_kernel_coop<2, true> : pt_kernel_coop<0, true>)
                                          : ((integ == 1) ? pt_kernel_coop<1> : (integ == 2) ? pt_kernel_coop<2> : pt_kernel_coop<0>);
+    } else if (kernel == 5) {  // 33..64 instances: the 64-bit pending mask (the MIXED code covers scenes without inline instances too)
+        fn_coop_early = (integ == 1) ? pt_kernel_coop<1, true, true, uint64_t> : (integ == 2) ? pt_kernel_coop<2, true, true, uint64_t> : pt_kernel_coop<0, true, true, uint64_t>;
+        fn_coop = (integ == 1) ? pt_kernel_coop<1, true, false, uint64_t> : (integ == 2) ? pt_kernel_coop<2, true, false, uint64_t> : pt_kernel_coop<0, true, false, uint64_t>;
     }
     if (media)
         fn = (kernel == 2) ? (lds ? pt_kernel<true, true, 2, 0, true> : pt_kernel<false, true, 2, 0, true>)
