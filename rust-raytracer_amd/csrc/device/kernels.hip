@@ -49,6 +49,51 @@ namespace rtamd {
                           std::string(#expr) + ": " + hipGetErrorString(_e));                            \
     } while (0)
 
+// ---- phase statistics (tools-only build: tools/build_variant.sh phase -DRTAMD_PHASE_STATS; the product carries none of it) ----
+// Per workgroup in LDS, flushed to g_phase at the end of pt_kernel: [0..15] wave clocks (s_memtime) spent in a phase, [16..31] how
+// often a WAVE executed the phase's block, [32..47] how many LANES took part.  A phase is timed by its own clock pair, read by the
+// lanes that execute it (the clock is scalar: one value per wave), and booked by the first active lane.
+// phases: 0 regeneration, 1 traverse (all of it), 2 materialize, 3 shade (all of it), 4 Lambertian / DiffuseLight branch, 5 Isotropic,
+// 6 Metal, 7 Dielectric, 8 what follows traverse in a segment (materialize + shade + radiance + mixture / store), 9 leaf sections of
+// the traversal; events only: 10 inner-node steps, 11 leaf items, 12 cube tests, 13 segments (alive lanes), 14 mixture step
+#ifdef RTAMD_PHASE_STATS
+__shared__ unsigned long long s_ph[48];
+__device__ unsigned long long g_phase[48];
+__device__ __forceinline__ bool ph_first() { return (int)(__ffsll((long long)__ballot(1)) - 1) == (int)(threadIdx.x & 63); }
+#define PH_CLK() __builtin_amdgcn_s_memtime()
+#define PH_ADD(i, dt)                                                         \
+    do {                                                                      \
+        if (ph_first()) atomicAdd(&s_ph[(i)], (unsigned long long)(dt));      \
+    } while (0)
+#define PH_EV(i)                                                              \
+    do {                                                                      \
+        const unsigned long long _m = __ballot(1);                            \
+        if (ph_first()) {                                                     \
+            atomicAdd(&s_ph[16 + (i)], 1ull);                                 \
+            atomicAdd(&s_ph[32 + (i)], (unsigned long long)__popcll(_m));     \
+        }                                                                     \
+    } while (0)
+#define PH_BEGIN(v) const unsigned long long v = PH_CLK()
+#define PH_END(i, v)              \
+    do {                          \
+        PH_ADD(i, PH_CLK() - v);  \
+        PH_EV(i);                 \
+    } while (0)
+#else
+#define PH_ADD(i, dt) \
+    do {              \
+    } while (0)
+#define PH_EV(i) \
+    do {         \
+    } while (0)
+#define PH_BEGIN(v) \
+    do {            \
+    } while (0)
+#define PH_END(i, v) \
+    do {             \
+    } while (0)
+#endif
+
 // ---------------------------------------------------------------- math ----
 struct D3 {
     double x, y, z;
@@ -623,6 +668,7 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
     uint32_t cur = WIDE ? wide_ref(A.root2) : A.root2;
     for (;;) {
         while ((cur >> REF_TAG_SHIFT) == 0u) {  // inner node: test both children
+            PH_EV(10);
             if (WIDE) {
                 const uint32_t axx = cur + r.ax, ayy = cur + r.ay, azz = cur + r.az;
                 // seven 8-byte LDS reads, spelled out: left to itself the compiler pairs them into ds_read2_b64 / ds_read2st64_b64
@@ -704,10 +750,12 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
             }
         }
         if (cur == REF_DONE) break;
+        PH_BEGIN(ph_leaf0);
         if ((cur >> REF_TAG_SHIFT) == 1u) {  // leaf: test its items with the reference's f64 routines
             uint32_t first = cur & REF_LEAF_FIRST_MASK, cnt = ((cur >> REF_LEAF_COUNT_SHIFT) & 7u) + 1u;
             uint32_t enter = REF_DONE;
             for (uint32_t i = 0; i < cnt; i++) {
+                PH_EV(11);
                 uint2 it = A.items2[first + i];
                 uint32_t kind = it.x & NK_MASK, pl = it.x >> NK_BITS;
                 double t = 0.;
@@ -723,6 +771,7 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
                     if (kind == NK_RECT_YZ || kind == NK_RECT_XZ || kind == NK_RECT_XY) {
                         got = rect_hit(A.rects + 3 * pl, (int)kind - (int)NK_RECT_YZ, o, d, t_min, t_far, t);
                     } else if (kind == NK_CUBE) {
+                        PH_EV(12);
                         got = cube_hit(A.rects + 3 * (pl >> 3), o, d, t_min, t_far, t, cube_side);
                     } else if (kind == NK_TRI) {
                         double b1, b2;
@@ -772,6 +821,7 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
                     sp += stride;
                 }
                 cur = WIDE ? wide_ref(in.y) : in.y;
+                PH_END(9, ph_leaf0);
                 continue;
             }
         } else {  // REF_RESTORE: leave the Transform
@@ -795,6 +845,7 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
         } else {
             cur = REF_DONE;
         }
+        PH_END(9, ph_leaf0);
     }
     return h;
 }
@@ -1080,25 +1131,33 @@ DEV bool shade(const Acc& A, const Rec& rec, D3 rdir, Rng& rng, D3& emitted, D3&
     if (type != 2) rs = random_in_unit_sphere(rng);  // Metal draws its fuzz sample even when fuzz == 0 (Q4)
     const D3 u = unit(lamb ? rs : rdir, err);
     if (lamb) {  // scattered_direction, material.rs:92-98
+        PH_BEGIN(ph_b);
         D3 dir = add(rec.normal, u);
         if (near_zero(dir)) dir = rec.normal;
         out_dir = dir;
+        PH_END(4, ph_b);
         return true;
     }
     if (type == 4) {  // Isotropic (material.rs:213-231, commented out in the reference): Ray(p, random_in_unit_sphere()), albedo
+        PH_BEGIN(ph_b);
         out_dir = rs;
+        PH_END(5, ph_b);
         return true;
     }
     if (type == 1) {  // Metal, material.rs:126-139
+        PH_BEGIN(ph_b);
         D3 reflected = reflect(u, rec.normal);
         D3 dir = add(reflected, muls(rs, mt.param));
         if (dot(dir, rec.normal) > 0.) {
             out_dir = dir;
+            PH_END(6, ph_b);
             return true;
         }
+        PH_END(6, ph_b);
         return false;  // Absorb (Q15)
     }
     // Dielectric, material.rs:157-188
+    PH_BEGIN(ph_b);
     double ratio = rec.front_face ? mt.inv_ir : mt.param;  // 1.0 / ir, from the host
     const D3 ud = u;
     double cos_theta = fmin(dot(neg(ud), rec.normal), 1.0);
@@ -1114,6 +1173,7 @@ DEV bool shade(const Acc& A, const Rec& rec, D3 rdir, Rng& rng, D3& emitted, D3&
         do_reflect = refl > rng.gen_f64();
     }
     out_dir = do_reflect ? reflect(ud, rec.normal) : refract(ud, rec.normal, ratio);
+    PH_END(7, ph_b);
     return true;
 }
 
@@ -1679,8 +1739,13 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
     const unsigned long long tail_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
     int fold_wait = 0;  // iterations until the head of the ring is looked at again (wave-uniform)
+#ifdef RTAMD_PHASE_STATS
+    if (threadIdx.x < 48) s_ph[threadIdx.x] = 0ull;
+    __syncthreads();
+#endif
     {
         for (;;) {
+            PH_BEGIN(ph_it0);
             // ---- regeneration: dead lanes pull the next (pixel, sample) of the pool ----
             uint64_t dead = __ballot(!alive);
             // the regeneration code runs for the whole wave however few lanes need it: wait until REGEN_MIN lanes are free
@@ -1746,22 +1811,31 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
                     }  // (a pixel of an edge tile outside the image gets no path; finalize_kernel zeroes it whatever the fold adds)
                 }
             }
+            PH_END(0, ph_it0);
             if (__ballot(alive) == 0ull) {
                 if (next >= pool && finished) break;
                 continue;
             }
             // ---- one path segment: sample_ray's loop body, photon_mapper.rs:335-362 ----
             if (alive) {
+                PH_EV(13);
+                PH_BEGIN(ph_t0);
                 Hit h = (ACCEL == 2) ? (MEDIA ? traverse2_media<GENERAL, !LDS, LDS>(A, sv.n_media, stk, stk_stride, o, d, rk.t_min, rng)
                                                : traverse2<GENERAL, false, !LDS, LDS>(A, stk, stk_stride, o, d, rk.t_min, INFINITY))
                                      : traverse<GENERAL, MEDIA>(A, o, d, rk.t_min, INFINITY, &rng);
+                PH_END(1, ph_t0);
+                PH_BEGIN(ph_p0);
                 bool done = true;
                 if (h.node >= 0 && depth > 0) {  // Q12: depth test after the hit, before emission
                     depth -= 1;
+                    PH_BEGIN(ph_m0);
                     Rec rec = materialize<GENERAL>(A, h, o, d, err);
+                    PH_END(2, ph_m0);
                     D3 emitted, att, ndir;
                     bool diffuse;
+                    PH_BEGIN(ph_s0);
                     bool scattered = shade(A, rec, d, rng, emitted, att, ndir, diffuse, err);
+                    PH_END(3, ph_s0);
                     L = add(L, elemul(beta, emitted));  // radiance += throughput * Le
                     if (scattered) {  // Diffuse continues like Specular/Reflect/Refract (photon_mapper.rs:346-347)
                         bool go = true;
@@ -1771,6 +1845,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
                             L = add(L, elemul(beta, mk(e[3], e[4], e[5])));  // global estimate
                             go = false;
                         } else if (INTEG == 1 && diffuse) {
+                            PH_EV(14);
                             go = mixture_step(A, rec, rng, att, beta, ndir, err);
                         } else {
                             beta = elemul(beta, att);
@@ -1790,9 +1865,14 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
                     atomicSub(rmeta + 4 * (out_slot >> 9) + 3, 1u);  // one path less running in that ring slot (UNIT_SPP * 64 = 512 per slot)
                     alive = false;
                 }
+                PH_END(8, ph_p0);
             }
         }
     }
+#ifdef RTAMD_PHASE_STATS
+    __syncthreads();
+    if (threadIdx.x < 48) atomicAdd(&g_phase[threadIdx.x], s_ph[threadIdx.x]);
+#endif
 #ifdef RT_TAIL_STATS
     if (lane == 0) {
         g_tail_end[blockIdx.x * (PT_BLOCK / 64) + wave] = __builtin_amdgcn_s_memrealtime();
@@ -2980,6 +3060,9 @@ static const DevInfo& dev_info(int dev) {
     int v = 0;
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess && v > 0) di.lds_max = (size_t)v;
     if (di.lds_max > 160 * 1024) di.lds_max = 160 * 1024;
+#ifdef RTAMD_PHASE_STATS
+    di.lds_max -= 1024;  // the statistics build keeps 48 counters in static LDS
+#endif
     return g_devinfo.emplace(dev, di).first->second;
 }
 // A workspace = the waves' unit rings, the accumulator, the per-tile tickets and a small block {work counter, error flag}.
@@ -3301,6 +3384,29 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
         const char* tn[8] = {"fold + regenerate", "world-space walk", "park", "adopt", "shade", "serve (batch)", "tail: serve rest / idle", "(of park + adopt: the two ring pops)"};
         for (int i = 0; i < 8; i++) fprintf(stderr, "[coop time] %-26s %5.1f %%\n", tn[i], tot ? 100. * (double)tm[i] / (double)tot : 0.);
         HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_coop_time), z, sizeof(tm)));
+    }
+#endif
+#ifdef RTAMD_PHASE_STATS
+    if (kernel != 5) {
+        unsigned long long hp[48], z[48] = {0};
+        HIP_CHECK(hipMemcpyFromSymbol(hp, HIP_SYMBOL(g_phase), sizeof(hp)));
+        HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z)));
+        const double tot = (double)(hp[0] + hp[1] + hp[8]);
+        const char* nm[15] = {"regeneration", "traverse (all)", "materialize", "shade (all)", "  Lambertian / light branch", "  Isotropic branch", "  Metal branch",
+                              "  Dielectric branch", "after traverse (all)", "  leaf sections of traverse", "inner-node steps", "leaf items", "cube tests",
+                              "segments", "mixture steps"};
+        fprintf(stderr, "[phase] kernel %d lds %d  wave clocks per segment-iteration %.0f (iterations %llu)\n", kernel, lds ? 1 : 0, hp[16] ? tot / (double)hp[16] : 0.,
+                hp[16]);
+        for (int i = 0; i < 15; i++)
+            fprintf(stderr, "[phase] %-30s time %6.3f  wave-exec/iter %8.3f  lanes/exec %5.1f  (util %.3f)\n", nm[i], i < 10 ? (double)hp[i] / tot : 0.,
+                    hp[16] ? (double)hp[16 + i] / (double)hp[16] : 0., hp[16 + i] ? (double)hp[32 + i] / (double)hp[16 + i] : 0.,
+                    hp[16 + i] ? (double)hp[32 + i] / (64. * (double)hp[16 + i]) : 0.);
+        // what material-pure waves could return at most: every branch at full lanes instead of its measured share
+        double save = 0.;
+        for (int i = 4; i <= 7; i++)
+            if (hp[16 + i]) save += (double)hp[i] * (1. - (double)hp[32 + i] / (64. * (double)hp[16 + i]));
+        fprintf(stderr, "[phase] material branches: %.4f of wave time; re-binned to full waves they would return at most %.4f\n",
+                (double)(hp[4] + hp[5] + hp[6] + hp[7]) / tot, save / tot);
     }
 #endif
 #ifdef RT_TAIL_STATS
