@@ -10,4 +10,4 @@ mkdir -p variants
 echo " <- $name"
 # the schedule (host/schedule.cpp) takes the same -D switches (-DTAPER_R=...)
 g++ -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -I../include -Icsrc $(for f in "$@"; do case $f in -D*) echo $f;; esac; done) -c csrc/host/schedule.cpp -o variants/schedule_$name.o
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o variants/librtamd_$name.so csrc/abi.o $(ls csrc/host/*.o | grep -v schedule.o) variants/schedule_$name.o variants/kernels_$name.o
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o variants/librtamd_$name.so csrc/abi.o $(ls csrc/host/*.o | grep -v schedule.o) variants/schedule_$name.o variants/kernels_$name.o csrc/device/exchange.o -lrccl

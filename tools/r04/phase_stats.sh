@@ -4,7 +4,8 @@
 # usage: tools/r04/phase_stats.sh [config ...]   -> gpurun_out/r04_phase/<config>.txt   (is material stream sorting worth building?)
 set -o pipefail
 cd "$(dirname "$0")/../.."
-tools/build_variant.sh phase -DRTAMD_PHASE_STATS > /dev/null 2>&1 || { echo "variant build failed"; exit 1; }
+V=rust-raytracer_amd/variants/librtamd_phase.so   # (built here or beforehand: the variants directory travels with gpurun)
+if [ ! -f $V ] || [ rust-raytracer_amd/csrc/device/kernels.hip -nt $V ]; then tools/build_variant.sh phase -DRTAMD_PHASE_STATS > /dev/null 2>&1 || { echo "variant build failed"; exit 1; }; fi
 OUT=gpurun_out/r04_phase; mkdir -p $OUT
 declare -A SPP=( [scene_10]=100 [scene_500]=64 [cornell]=128 [cornell_mix]=128 [c5r]=32 )
 for CFG in ${@:-scene_500 cornell cornell_mix c5r}; do
