@@ -606,6 +606,35 @@ DEV bool box32w(float nx, float ny, float nz, float fx, float fy, float fz, cons
     asm("v_min_f32 %0, %1, %2" : "=v"(m) : "v"(tf), "v"(r.best));
     return !(tn > m) && !(r.tmin > tf);
 }
+// box32 with each axis' near / far plane already SELECTED by the sign of the ray's inverse direction (the caller picks them with one
+// v_cndmask per axis on the packed NodeQ words, serving both children): lo <= hi and fma is monotonic in its first operand, so
+// fma(near) = min(fma(lo), fma(hi)) and fma(far) = max(...) value for value, and the test decides exactly as box32 does -- six
+// v_min / v_max fewer per child.  (Same widening factor as box32: the grid's pad P has no spare margin to drop it.)
+DEV bool box32s(float nx, float ny, float nz, float fx, float fy, float fz, const Ray32& r, float& entry) {
+    const float px = __builtin_fmaf(nx, r.ix, -r.cx), qx = __builtin_fmaf(fx, r.ix, -r.cx);
+    const float py = __builtin_fmaf(ny, r.iy, -r.cy), qy = __builtin_fmaf(fy, r.iy, -r.cy);
+    const float pz = __builtin_fmaf(nz, r.iz, -r.cz), qz = __builtin_fmaf(fz, r.iz, -r.cz);
+    const float tn = fmaxf(fmaxf(px, py), pz);
+    const float tf = fminf(fminf(qx, qy), qz) * (1.0f + 9.5367431640625e-7f);
+    entry = tn;
+    return !(tn > tf) && !(tn > r.best) && !(r.tmin > tf);
+}
+// the per-axis lane masks "the ray runs down this axis" of a wave, for box32s' callers
+struct SignMasks {
+    uint64_t x, y, z;
+};
+DEV SignMasks sign_masks(const Ray32& r) {
+    SignMasks m;
+    m.x = __ballot(r.ix < 0.f);
+    m.y = __ballot(r.iy < 0.f);
+    m.z = __ballot(r.iz < 0.f);
+    return m;
+}
+DEV uint32_t sel32(uint32_t if_clear, uint32_t if_set, uint64_t lane_mask) {  // per lane: lane_mask[lane] ? if_set : if_clear
+    uint32_t v;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(v) : "v"(if_clear), "v"(if_set), "s"(lane_mask));
+    return v;
+}
 DEV bool box32(float lox, float loy, float loz, float hix, float hiy, float hiz, const Ray32& r, float& entry) {
     float px = __builtin_fmaf(lox, r.ix, -r.cx), qx = __builtin_fmaf(hix, r.ix, -r.cx);
     float py = __builtin_fmaf(loy, r.iy, -r.cy), qy = __builtin_fmaf(hiy, r.iy, -r.cy);
@@ -2150,6 +2179,7 @@ DEV void blas_pass_q(const ServeCtx& X, bool act, AS_L uint32_t* stk, const int 
     // (measured and dropped: speculative descent -- a leaf reached early is set aside while the lane walks on -- 805 against 924;
     // publishing a pass's answers one pass later, behind their stores' round trip, -1 %; ending the descent early once fewer than 16 / 24 / 32 / 40 lanes still descend -- 631 / 574 / 547 / 517
     // against 632 Msamples/s -- and testing at most 1 or 2 triangles of a leaf per pass, 543 / 612)
+    const SignMasks sm = sign_masks(r);  // (the rays of a pass do not change: refills happen between passes)
     while (act && (cur >> REF_TAG_SHIFT) == 0u) {
         u32x4 u0, u1;  // (lox, loy, loz, hix) (hiy, hiz, c0, c1); child 0 in the low halves
         if (cur < X.n_topq) {
@@ -2159,11 +2189,14 @@ DEV void blas_pass_q(const ServeCtx& X, bool act, AS_L uint32_t* stk, const int 
             const AS_G u32x4* p = X.n2q + 2 * (size_t)cur;
             u0 = p[0]; u1 = p[1];
         }
+        // near / far plane words per axis (both children at once), then the 16-bit halves
+        const uint32_t nxw = sel32(u0.x, u0.w, sm.x), fxw = sel32(u0.w, u0.x, sm.x);
+        const uint32_t nyw = sel32(u0.y, u1.x, sm.y), fyw = sel32(u1.x, u0.y, sm.y);
+        const uint32_t nzw = sel32(u0.z, u1.y, sm.z), fzw = sel32(u1.y, u0.z, sm.z);
         float e0, e1;
-        const bool h0 = box32((float)(u0.x & 0xffffu), (float)(u0.y & 0xffffu), (float)(u0.z & 0xffffu), (float)(u0.w & 0xffffu),
-                              (float)(u1.x & 0xffffu), (float)(u1.y & 0xffffu), r, e0);
-        const bool h1 = box32((float)(u0.x >> 16), (float)(u0.y >> 16), (float)(u0.z >> 16), (float)(u0.w >> 16), (float)(u1.x >> 16),
-                              (float)(u1.y >> 16), r, e1);
+        const bool h0 = box32s((float)(nxw & 0xffffu), (float)(nyw & 0xffffu), (float)(nzw & 0xffffu), (float)(fxw & 0xffffu), (float)(fyw & 0xffffu),
+                               (float)(fzw & 0xffffu), r, e0);
+        const bool h1 = box32s((float)(nxw >> 16), (float)(nyw >> 16), (float)(nzw >> 16), (float)(fxw >> 16), (float)(fyw >> 16), (float)(fzw >> 16), r, e1);
         const uint32_t c0 = u1.z, c1 = u1.w;
         if (h0 && h1) {
             const bool swap = e1 < e0;
@@ -2641,15 +2674,19 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
                     const D3 og = mk((oo.x - g[0]) * g[3] + g[6], (oo.y - g[1]) * g[4] + g[6], (oo.z - g[2]) * g[5] + g[6]);
                     const D3 dg = mk(dd.x * g[3], dd.y * g[4], dd.z * g[5]);
                     const Ray32 r = make_ray32(og, dg, rk.t_min, h.t);
+                    const SignMasks sm = sign_masks(r);
                     ent_cur = A.inst2[ni].y;
                     while ((ent_cur >> REF_TAG_SHIFT) == 0u && ent_cur < entry_top) {
                         const uint4* p = n2q_lds + 2 * ent_cur;
                         const uint4 u0 = p[0], u1 = p[1];
+                        const uint32_t nxw = sel32(u0.x, u0.w, sm.x), fxw = sel32(u0.w, u0.x, sm.x);
+                        const uint32_t nyw = sel32(u0.y, u1.x, sm.y), fyw = sel32(u1.x, u0.y, sm.y);
+                        const uint32_t nzw = sel32(u0.z, u1.y, sm.z), fzw = sel32(u1.y, u0.z, sm.z);
                         float e0, e1;
-                        const bool h0 = box32((float)(u0.x & 0xffffu), (float)(u0.y & 0xffffu), (float)(u0.z & 0xffffu), (float)(u0.w & 0xffffu),
-                                              (float)(u1.x & 0xffffu), (float)(u1.y & 0xffffu), r, e0);
-                        const bool h1 = box32((float)(u0.x >> 16), (float)(u0.y >> 16), (float)(u0.z >> 16), (float)(u0.w >> 16),
-                                              (float)(u1.x >> 16), (float)(u1.y >> 16), r, e1);
+                        const bool h0 = box32s((float)(nxw & 0xffffu), (float)(nyw & 0xffffu), (float)(nzw & 0xffffu), (float)(fxw & 0xffffu),
+                                               (float)(fyw & 0xffffu), (float)(fzw & 0xffffu), r, e0);
+                        const bool h1 = box32s((float)(nxw >> 16), (float)(nyw >> 16), (float)(nzw >> 16), (float)(fxw >> 16), (float)(fyw >> 16),
+                                               (float)(fzw >> 16), r, e1);
                         const uint32_t c0 = u1.z, c1 = u1.w;
                         if (h0 && h1) {
                             const bool swap = e1 < e0;
