@@ -1616,6 +1616,27 @@ __device__ __attribute__((noinline)) UnitInfo next_unit(uint32_t* wst_, uint32_t
     if (take && r_cnt < ring_units && (job_k < job_n || more_jobs)) {
         if (job_k >= job_n) {  // next job: job_units consecutive sample blocks of one tile
             unsigned int job = 0;
+#ifdef XCD_JOBS  // locality experiment (tools-only build, profiles/r04/c4_audit.md): the rank's tiles are cut into 8 contiguous bands, the
+                 // workgroups of XCD x (= blockIdx.x % 8: round-robin dispatch) deal band x from its own counter and move on to the next
+                 // band with work left when theirs is through; every band is dealt round by round like the whole list
+            const unsigned n_tiles = (unsigned)cfg[CFG_TILES_OWNED], rounds = (unsigned)cfg[CFG_N_JOBS] / n_tiles;
+            unsigned band_base = 0u, band_tiles = n_tiles;
+            bool found = false;
+            for (unsigned k8 = 0u; k8 < 8u && !found; k8++) {
+                const unsigned b = (blockIdx.x + k8) & 7u;
+                band_base = (unsigned)(((unsigned long long)n_tiles * b) >> 3);
+                band_tiles = (unsigned)(((unsigned long long)n_tiles * (b + 1u)) >> 3) - band_base;
+                if (band_tiles == 0u) continue;
+                if (lane == 0) job = atomicAdd(counter + 16 + b, 1u);
+                job = __builtin_amdgcn_readfirstlane(job);
+                found = job < band_tiles * rounds;
+            }
+            if (!found) {
+                more_jobs = false;
+            } else {
+                job_tile = (int)(band_base + job % band_tiles);
+                const int round = (int)(job / band_tiles);
+#else
             if (lane == 0) job = atomicAdd(counter, 1u);
             job = __builtin_amdgcn_readfirstlane(job);
             if (job >= (unsigned)cfg[CFG_N_JOBS]) {
@@ -1623,6 +1644,7 @@ __device__ __attribute__((noinline)) UnitInfo next_unit(uint32_t* wst_, uint32_t
             } else {
                 job_tile = (int)(job % (unsigned)cfg[CFG_TILES_OWNED]);  // sample-major: all tiles' round k before any tile's round k+1
                 const int round = (int)(job / (unsigned)cfg[CFG_TILES_OWNED]);
+#endif
                 job_lvl = 0;
                 while (round >= cfg[CFG_LVL + 5 * (job_lvl + 1)]) job_lvl++;  // (the entry behind the last level holds the number of rounds)
                 const AS_L int* L = cfg + CFG_LVL + 5 * job_lvl;
@@ -3363,6 +3385,9 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
         rk.coop_stack = (int)stack5;
         rk.coop_pool = tun.coop_pool > 0 ? std::min(tun.coop_pool, (int)COOP_POOL) : (int)COOP_POOL;
         HIP_CHECK(hipMemsetAsync(counter.p, 0, sizeof(unsigned int), stream));
+#ifdef XCD_JOBS
+        HIP_CHECK(hipMemsetAsync((char*)counter.p + 64, 0, 8 * sizeof(unsigned int), stream));  // the per-XCD job counters (words 16..23 of the small block)
+#endif
         HIP_CHECK(hipMemsetAsync(tickets.p, 0, std::max<size_t>(16, (size_t)plan.tiles_owned * sizeof(unsigned int)), stream));
         hipEvent_t e0 = events.make(), e1 = events.make();
         HIP_CHECK(hipEventRecord(e0, stream));
