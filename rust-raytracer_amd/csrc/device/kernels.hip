@@ -1620,21 +1620,38 @@ __device__ __attribute__((noinline)) UnitInfo next_unit(uint32_t* wst_, uint32_t
                  // workgroups of XCD x (= blockIdx.x % 8: round-robin dispatch) deal band x from its own counter and move on to the next
                  // band with work left when theirs is through; every band is dealt round by round like the whole list
             const unsigned n_tiles = (unsigned)cfg[CFG_TILES_OWNED], rounds = (unsigned)cfg[CFG_N_JOBS] / n_tiles;
-            unsigned band_base = 0u, band_tiles = n_tiles;
+            unsigned band_base = 0u, band_tiles = n_tiles, band = 0u;
             bool found = false;
+#if XCD_JOBS == 2  // ... or into chunks of XCD_CHUNK consecutive tiles dealt round-robin to the XCDs (chunk c -> XCD c % 8): balanced, no long steal phase
+#ifndef XCD_CHUNK
+#define XCD_CHUNK 256u
+#endif
+            const unsigned n_chunks = (n_tiles + XCD_CHUNK - 1u) / XCD_CHUNK, last_rem = n_tiles - (n_chunks - 1u) * XCD_CHUNK;
+#endif
             for (unsigned k8 = 0u; k8 < 8u && !found; k8++) {
                 const unsigned b = (blockIdx.x + k8) & 7u;
+#if XCD_JOBS == 2
+                const unsigned mine = b < n_chunks ? (n_chunks - b + 7u) / 8u : 0u;
+                band_tiles = mine * XCD_CHUNK - ((mine != 0u && ((n_chunks - 1u) & 7u) == b) ? XCD_CHUNK - last_rem : 0u);
+#else
                 band_base = (unsigned)(((unsigned long long)n_tiles * b) >> 3);
                 band_tiles = (unsigned)(((unsigned long long)n_tiles * (b + 1u)) >> 3) - band_base;
+#endif
                 if (band_tiles == 0u) continue;
                 if (lane == 0) job = atomicAdd(counter + 16 + b, 1u);
                 job = __builtin_amdgcn_readfirstlane(job);
                 found = job < band_tiles * rounds;
+                band = b;
             }
             if (!found) {
                 more_jobs = false;
             } else {
+#if XCD_JOBS == 2
+                const unsigned idx = job % band_tiles;
+                job_tile = (int)(((idx / XCD_CHUNK) * 8u + band) * XCD_CHUNK + idx % XCD_CHUNK);
+#else
                 job_tile = (int)(band_base + job % band_tiles);
+#endif
                 const int round = (int)(job / band_tiles);
 #else
             if (lane == 0) job = atomicAdd(counter, 1u);

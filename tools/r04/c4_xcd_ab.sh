@@ -7,11 +7,13 @@ cd "$(dirname "$0")/../.."
 export TMPDIR=/tmp
 SPP=${1:-256}
 OUT=gpurun_out/r04_xcd; rm -rf $OUT; mkdir -p $OUT
-V=rust-raytracer_amd/variants/librtamd_xcd.so
-if [ ! -f $V ] || [ rust-raytracer_amd/csrc/device/kernels.hip -nt $V ]; then tools/build_variant.sh xcd -DXCD_JOBS > /dev/null 2>&1 || { echo "variant build failed"; exit 1; }; fi
-for B in product xcd; do
-  L=$PWD/rust-raytracer_amd/librtamd.so; [ $B = xcd ] && L=$PWD/$V
-  for i in 1 2 3; do RTAMD_LIB=$L python3 tools/config_run.py c4 $SPP 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$B run $i: %.1f Msamples/s' % d['msamples_per_s_kernel'])"; done | tee -a $OUT/rates.txt
+for V in xcd:-DXCD_JOBS=1 xcd2:-DXCD_JOBS=2 xcd2s:"-DXCD_JOBS=2 -DXCD_CHUNK=64u"; do
+  F=rust-raytracer_amd/variants/librtamd_${V%%:*}.so
+  if [ ! -f $F ] || [ rust-raytracer_amd/csrc/device/kernels.hip -nt $F ]; then tools/build_variant.sh ${V%%:*} ${V#*:} > /dev/null 2>&1 || { echo "variant build failed"; exit 1; }; fi
+done
+for B in product xcd xcd2 xcd2s; do
+  L=$PWD/rust-raytracer_amd/librtamd.so; [ $B != product ] && L=$PWD/rust-raytracer_amd/variants/librtamd_$B.so
+  for i in 1 2 3 4; do RTAMD_LIB=$L python3 tools/config_run.py c4 $SPP 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$B run $i: %.1f Msamples/s' % d['msamples_per_s_kernel'])"; done | tee -a $OUT/rates.txt
   for SET in "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "FETCH_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU"; do
     N=$(echo $SET | cut -d' ' -f1)
     RTAMD_LIB=$L timeout -k 10 300 rocprofv3 --pmc $SET -d $OUT/${B}_$N --output-format csv -- python3 tools/config_run.py c4 $SPP > $OUT/${B}_$N.json 2>>$OUT/err.log || { tail -5 $OUT/err.log; exit 1; }
@@ -21,7 +23,7 @@ done
 python3 - <<PY
 import csv
 S = 1200 * 1200 * ($SPP + 2)
-for b in ("product", "xcd"):
+for b in ("product", "xcd", "xcd2", "xcd2s"):
     d = {}
     for r in csv.reader(open("$OUT/pmc_%s.csv" % b)):
         d[r[1]] = float(r[4])
