@@ -1628,11 +1628,16 @@ __device__ __attribute__((noinline)) UnitInfo next_unit(uint32_t* wst_, uint32_t
 #endif
             const unsigned n_chunks = (n_tiles + XCD_CHUNK - 1u) / XCD_CHUNK, last_rem = n_tiles - (n_chunks - 1u) * XCD_CHUNK;
 #endif
-            for (unsigned k8 = 0u; k8 < 8u && !found; k8++) {
-                const unsigned b = (blockIdx.x + k8) & 7u;
+#ifndef XCD_LISTS
+#define XCD_LISTS 8u  // job lists: 8 = one per XCD, 256 = one per workgroup / CU (a power of two)
+#endif
+            unsigned k8 = (unsigned)job_lvl >> 8;  // where this wave last found work: lists before it are through
+            job_lvl &= 0xff;
+            for (; k8 < XCD_LISTS && !found; k8++) {
+                const unsigned b = (blockIdx.x + k8) & (XCD_LISTS - 1u);
 #if XCD_JOBS == 2
-                const unsigned mine = b < n_chunks ? (n_chunks - b + 7u) / 8u : 0u;
-                band_tiles = mine * XCD_CHUNK - ((mine != 0u && ((n_chunks - 1u) & 7u) == b) ? XCD_CHUNK - last_rem : 0u);
+                const unsigned mine = b < n_chunks ? (n_chunks - b + XCD_LISTS - 1u) / XCD_LISTS : 0u;
+                band_tiles = mine * XCD_CHUNK - ((mine != 0u && ((n_chunks - 1u) & (XCD_LISTS - 1u)) == b) ? XCD_CHUNK - last_rem : 0u);
 #else
                 band_base = (unsigned)(((unsigned long long)n_tiles * b) >> 3);
                 band_tiles = (unsigned)(((unsigned long long)n_tiles * (b + 1u)) >> 3) - band_base;
@@ -1643,12 +1648,13 @@ __device__ __attribute__((noinline)) UnitInfo next_unit(uint32_t* wst_, uint32_t
                 found = job < band_tiles * rounds;
                 band = b;
             }
+            const unsigned list_cursor = found ? k8 - 1u : XCD_LISTS;
             if (!found) {
                 more_jobs = false;
             } else {
 #if XCD_JOBS == 2
                 const unsigned idx = job % band_tiles;
-                job_tile = (int)(((idx / XCD_CHUNK) * 8u + band) * XCD_CHUNK + idx % XCD_CHUNK);
+                job_tile = (int)(((idx / XCD_CHUNK) * XCD_LISTS + band) * XCD_CHUNK + idx % XCD_CHUNK);
 #else
                 job_tile = (int)(band_base + job % band_tiles);
 #endif
@@ -1669,13 +1675,16 @@ __device__ __attribute__((noinline)) UnitInfo next_unit(uint32_t* wst_, uint32_t
                 job_n = min(L[4], L[5 + 1] - job_blk0);
                 job_k = 0;
             }
+#ifdef XCD_JOBS
+            job_lvl |= (int)(list_cursor << 8);
+#endif
         }
         if (job_k < job_n) {  // start the job's next unit
             const int tile = job_tile * cfg[CFG_WORLD] + cfg[CFG_RANK];
             u.tx = tile % cfg[CFG_TILES_X];
             u.ty = tile / cfg[CFG_TILES_X];
             const int sub_i = job_blk0 + job_k;
-            const AS_L int* L = cfg + CFG_LVL + 5 * job_lvl;
+            const AS_L int* L = cfg + CFG_LVL + 5 * (job_lvl & 0xff);
             u.s0 = L[2] + (sub_i - L[1]) * L[3];
             const int s1 = min(u.s0 + L[3], L[5 + 2]);
             u.pool = (s1 - u.s0) * TILE_PIX;
@@ -3151,7 +3160,7 @@ struct Workspace {
     size_t ring_bytes = 0, accum_bytes = 0, ticket_bytes = 0, coop_bytes = 0;
 };
 static std::vector<Workspace*> g_ws;
-static const size_t WS_SMALL = 1024;
+static const size_t WS_SMALL = 2048;
 static void grow(void*& p, size_t& have, size_t need) {
     if (have >= need) return;
     if (p) (void)hipFree(p);
@@ -3403,7 +3412,7 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
         rk.coop_pool = tun.coop_pool > 0 ? std::min(tun.coop_pool, (int)COOP_POOL) : (int)COOP_POOL;
         HIP_CHECK(hipMemsetAsync(counter.p, 0, sizeof(unsigned int), stream));
 #ifdef XCD_JOBS
-        HIP_CHECK(hipMemsetAsync((char*)counter.p + 64, 0, 8 * sizeof(unsigned int), stream));  // the per-XCD job counters (words 16..23 of the small block)
+        HIP_CHECK(hipMemsetAsync((char*)counter.p + 64, 0, 256 * sizeof(unsigned int), stream));  // the per-list job counters (words 16..271 of the small block)
 #endif
         HIP_CHECK(hipMemsetAsync(tickets.p, 0, std::max<size_t>(16, (size_t)plan.tiles_owned * sizeof(unsigned int)), stream));
         hipEvent_t e0 = events.make(), e1 = events.make();

@@ -1,17 +1,17 @@
 #!/bin/bash
-# C4 locality experiment: jobs dealt from ONE counter (the product) against per-XCD counters over 8 contiguous bands
-# of the frame (tools-only build -DXCD_JOBS).  Kernel rate, L2 hit / miss and fabric bytes per sample for both builds.
+# C4 locality experiment: jobs dealt from ONE counter against per-XCD / per-CU job lists (chunks of consecutive tiles
+# dealt round-robin to the lists; tools-only builds -DXCD_JOBS=2 -DXCD_LISTS=.. -DXCD_CHUNK=..).  Kernel rate, L2 hit / miss and fabric bytes per sample for both builds.
 # usage: tools/r04/c4_xcd_ab.sh [spp]  -> gpurun_out/r04_xcd/
 set -o pipefail
 cd "$(dirname "$0")/../.."
 export TMPDIR=/tmp
 SPP=${1:-256}
 OUT=gpurun_out/r04_xcd; rm -rf $OUT; mkdir -p $OUT
-for V in xcd:-DXCD_JOBS=1 xcd2:-DXCD_JOBS=2 xcd2s:"-DXCD_JOBS=2 -DXCD_CHUNK=64u"; do
+for V in xcd2:-DXCD_JOBS=2 l32:"-DXCD_JOBS=2 -DXCD_LISTS=32u -DXCD_CHUNK=64u" l256:"-DXCD_JOBS=2 -DXCD_LISTS=256u -DXCD_CHUNK=16u" l256b:"-DXCD_JOBS=2 -DXCD_LISTS=256u -DXCD_CHUNK=64u"; do
   F=rust-raytracer_amd/variants/librtamd_${V%%:*}.so
   if [ ! -f $F ] || [ rust-raytracer_amd/csrc/device/kernels.hip -nt $F ]; then tools/build_variant.sh ${V%%:*} ${V#*:} > /dev/null 2>&1 || { echo "variant build failed"; exit 1; }; fi
 done
-for B in product xcd xcd2 xcd2s; do
+for B in product xcd2 l32 l256 l256b; do
   L=$PWD/rust-raytracer_amd/librtamd.so; [ $B != product ] && L=$PWD/rust-raytracer_amd/variants/librtamd_$B.so
   for i in 1 2 3 4; do RTAMD_LIB=$L python3 tools/config_run.py c4 $SPP 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$B run $i: %.1f Msamples/s' % d['msamples_per_s_kernel'])"; done | tee -a $OUT/rates.txt
   for SET in "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "FETCH_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU"; do
@@ -23,7 +23,7 @@ done
 python3 - <<PY
 import csv
 S = 1200 * 1200 * ($SPP + 2)
-for b in ("product", "xcd", "xcd2", "xcd2s"):
+for b in ("product", "xcd2", "l32", "l256", "l256b"):
     d = {}
     for r in csv.reader(open("$OUT/pmc_%s.csv" % b)):
         d[r[1]] = float(r[4])
