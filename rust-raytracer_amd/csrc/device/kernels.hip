@@ -1449,7 +1449,8 @@ __device__ __attribute__((noinline)) int fold_units(const uint32_t* rmeta, const
 // per 512 paths).
 //   wst: {r_head, r_cnt, job_tile, job_blk0, job_n, job_k, more_jobs, job's level}      cfg: see CFG_* below
 enum { CFG_N_JOBS, CFG_TILES_OWNED, CFG_JOB_UNITS, CFG_SUBS_PER_TILE, CFG_WORLD, CFG_RANK, CFG_TILES_X, CFG_S_BEGIN, CFG_S_END, CFG_SUB_SPP,
-       CFG_WIDTH, CFG_HEIGHT, CFG_RING_UNITS /* unit buffers per wave: RING_UNITS, kernel 6: WF_RING_UNITS */, CFG_LVL = 16 /* RenderK::lvl, 25 words */,
+       CFG_WIDTH, CFG_HEIGHT, CFG_RING_UNITS /* unit buffers per wave: RING_UNITS, kernel 6: WF_RING_UNITS */,
+       CFG_JOB_LISTS /* lists next_unit() deals the tiles from: JOB_LISTS (one per XCD) or 1 */, CFG_LVL = 16 /* RenderK::lvl, 25 words */,
        CFG_WORDS = 48 };
 static_assert(SCHED_LEVELS == 4, "RenderK::lvl holds SCHED_LEVELS + 1 rows");
 struct UnitInfo {
@@ -1628,27 +1629,29 @@ __device__ __attribute__((noinline)) UnitInfo next_unit(uint32_t* wst_, uint32_t
             // left when theirs is through (the wave remembers where it last found work).  An XCD then folds, and re-reads through
             // its own L2, the tiles of its own chunks: C4 858 -> 909 Msamples/s (TCC requests per sample 82.9 -> 71.1, fabric bytes
             // 3 524 -> 3 034; one list per CU instead: 850-880; profiles/r04/c4_audit.md).  Which wave traces what never changes the image.
+            // Kernel 5 only: the LDS-resident scenes read nothing through L2 and lose 0.4-2 % to the lists' staggered ends (cfg: 1 list).
             const unsigned n_tiles = (unsigned)cfg[CFG_TILES_OWNED], rounds = (unsigned)cfg[CFG_N_JOBS] / n_tiles;
             const unsigned n_chunks = (n_tiles + JOB_CHUNK - 1u) / JOB_CHUNK, last_rem = n_tiles - (n_chunks - 1u) * JOB_CHUNK;
             unsigned list_tiles = 0u, list = 0u;
             bool found = false;
+            const unsigned n_lists = (unsigned)cfg[CFG_JOB_LISTS];  // a power of two (1: one list = the whole sequence, sample-major)
             unsigned probe = (unsigned)job_lvl >> 8;  // lists before this one (counted from the wave's own) are through
             job_lvl &= 0xff;
-            for (; probe < JOB_LISTS && !found; probe++) {
-                list = (blockIdx.x + probe) & (JOB_LISTS - 1u);
-                const unsigned mine = list < n_chunks ? (n_chunks - list + JOB_LISTS - 1u) / JOB_LISTS : 0u;
-                list_tiles = mine * JOB_CHUNK - ((mine != 0u && ((n_chunks - 1u) & (JOB_LISTS - 1u)) == list) ? JOB_CHUNK - last_rem : 0u);
+            for (; probe < n_lists && !found; probe++) {
+                list = (blockIdx.x + probe) & (n_lists - 1u);
+                const unsigned mine = list < n_chunks ? (n_chunks - list + n_lists - 1u) / n_lists : 0u;
+                list_tiles = mine * JOB_CHUNK - ((mine != 0u && ((n_chunks - 1u) & (n_lists - 1u)) == list) ? JOB_CHUNK - last_rem : 0u);
                 if (list_tiles == 0u) continue;
                 if (lane == 0) job = atomicAdd(counter + 16 + list, 1u);
                 job = __builtin_amdgcn_readfirstlane(job);
                 found = job < list_tiles * rounds;
             }
-            const unsigned list_cursor = found ? probe - 1u : JOB_LISTS;
+            const unsigned list_cursor = found ? probe - 1u : n_lists;
             if (!found) {
                 more_jobs = false;  // every list is through, for every wave: the counters only grow
             } else {
                 const unsigned idx = job % list_tiles;
-                job_tile = (int)(((idx / JOB_CHUNK) * JOB_LISTS + list) * JOB_CHUNK + idx % JOB_CHUNK);
+                job_tile = (int)(((idx / JOB_CHUNK) * n_lists + list) * JOB_CHUNK + idx % JOB_CHUNK);
                 const int round = (int)(job / list_tiles);
                 job_lvl = 0;
                 while (round >= cfg[CFG_LVL + 5 * (job_lvl + 1)]) job_lvl++;  // (the entry behind the last level holds the number of rounds)
@@ -1772,6 +1775,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
         cfg[CFG_S_BEGIN] = rk.s_begin; cfg[CFG_S_END] = rk.s_end; cfg[CFG_SUB_SPP] = rk.sub_spp; cfg[CFG_WIDTH] = rk.width;
         cfg[CFG_HEIGHT] = rk.height;
         cfg[CFG_RING_UNITS] = RING_UNITS;
+        cfg[CFG_JOB_LISTS] = 1;
 #pragma unroll
         for (int i = 0; i < 25; i++) cfg[CFG_LVL + i] = rk.lvl[i / 5][i % 5];
     }
@@ -2566,6 +2570,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
         cfg[CFG_S_BEGIN] = rk.s_begin; cfg[CFG_S_END] = rk.s_end; cfg[CFG_SUB_SPP] = rk.sub_spp; cfg[CFG_WIDTH] = rk.width;
         cfg[CFG_HEIGHT] = rk.height;
         cfg[CFG_RING_UNITS] = RING_UNITS;
+        cfg[CFG_JOB_LISTS] = (int)JOB_LISTS;
 #pragma unroll
         for (int i = 0; i < 25; i++) cfg[CFG_LVL + i] = rk.lvl[i / 5][i % 5];
         cargs->base = sv.base;

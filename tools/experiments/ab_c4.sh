@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of kernel build variants (rust-raytracer_amd/variants/librtamd_<name>.so) on C4, interleaved; C4_KERNEL picks the kernel
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 OUT=gpurun_out/ab_c4; mkdir -p $OUT
 for R in 1 2; do for V in default $(ls rust-raytracer_amd/variants/*.so); do
   L=$PWD/$V; [ "$V" = default ] && L=$PWD/rust-raytracer_amd/librtamd.so

@@ -1,6 +1,6 @@
 """C1 (scene_10 400x225x100): kernel time against the unit size (rt_tuning.sub_spp); best of 5"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "rust-raytracer_amd"))
 import rtamd
 w, c = rtamd.load_scene_file(os.path.join(ROOT, "tests", "golden", "scenes", "scene_10.json"))

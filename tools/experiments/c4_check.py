@@ -1,6 +1,6 @@
 """C4 sanity: Cornell + 102,400-triangle torus; parity vs oracle at small size, then timing of kernels 1 and 2."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "rust-raytracer_amd")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 import rtamd, oracle

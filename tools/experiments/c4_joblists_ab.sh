@@ -1,7 +1,7 @@
 #!/bin/bash
 # C4 locality experiment: jobs dealt from ONE counter against per-XCD / per-CU job lists (chunks of consecutive tiles
 # dealt round-robin to the lists; tools-only builds -DXCD_JOBS=2 -DXCD_LISTS=.. -DXCD_CHUNK=..).  Kernel rate, L2 hit / miss and fabric bytes per sample for both builds.
-# usage: tools/r04/c4_xcd_ab.sh [spp]  -> gpurun_out/r04_xcd/
+# usage: tools/experiments/c4_joblists_ab.sh [spp]  -> gpurun_out/r04_xcd/
 set -o pipefail
 cd "$(dirname "$0")/../.."
 export TMPDIR=/tmp

@@ -1,7 +1,7 @@
 #!/bin/bash
 # PMC passes of C4 with the kernel C4_KERNEL picks (separate runs per counter set); summary + instruction-mix model
 set -o pipefail
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 export TMPDIR=/tmp
 K=${C4_KERNEL:-5}
 OUT=gpurun_out/c4pmc_k$K; rm -rf $OUT; mkdir -p $OUT

@@ -1,6 +1,6 @@
 """scene_500 (headline frame, reduced spp) against the BVH builder's knobs; usage: python tools/headline_sweep.py [spp]"""
 import os, sys, json
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "rust-raytracer_amd"))
 import rtamd
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 96

@@ -2,7 +2,7 @@
 kernel 2's MEDIA variant (accel for the surfaces, media resolved in the reference's visit order); images must be identical.
 usage: python tools/medium_bench.py [spp]"""
 import json, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "rust-raytracer_amd"))
 import numpy as np
 import rtamd

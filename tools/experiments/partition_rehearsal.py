@@ -1,7 +1,7 @@
 """Strong-scaling rehearsal on ONE GPU: rank 0's share of the headline frame for world = 1, 2, 4, 8.
 If a rank's time is ~ t1/world, the N-GPU run is bound only by the (tiny) gather."""
 import os, sys, json
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "rust-raytracer_amd"))
 import rtamd
 w, c = rtamd.load_scene_file(os.path.join(ROOT, "tests", "golden", "scenes", "scene_500.json"))

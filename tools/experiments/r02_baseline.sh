@@ -2,7 +2,7 @@
 # Round-2 "before" measurements on the round-1 kernels: block-size A/B on the final schedule (headline + C4) and the
 # C4 PMC counters (lane utilisation, wait share).  Run on the GPU box: bash tools/r02_baseline.sh
 set -o pipefail
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 export TMPDIR=/tmp
 OUT=gpurun_out/r02_baseline
 mkdir -p $OUT

@@ -1,7 +1,7 @@
 #!/bin/bash
 # kernel 5 (cooperative instance service) against kernel 2 on C4: parity first, then throughput
 set -o pipefail
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 OUT=gpurun_out/r02_k5; mkdir -p $OUT
 if [ -z "$SKIP_TESTS" ]; then
   timeout -k 10 400 python -m pytest tests/test_parity_gpu.py -x -q -m gpu -k "c4 or torus" 2>&1 | tail -15 | tee $OUT/tests.log || exit 1

@@ -2,7 +2,7 @@
 # Round-2 profiles of the bench workload (headline: scene_500 1200x1200) and of C4, for profiles/r02/ and profiles/pt_kernel_model.json.
 # PMC passes are separate runs (SQ set, GRBM, FETCH_SIZE, WRITE_SIZE); --kernel-trace/--stats in their own run.
 set -o pipefail
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 export TMPDIR=/tmp
 OUT=gpurun_out/r02_prof; rm -rf $OUT; mkdir -p $OUT
 SPP=${SPP:-96}

@@ -1,8 +1,8 @@
 #!/bin/bash
 # PMC passes of C4 (Cornell + 102,400-triangle torus, 1200x1200) with the kernel C4_KERNEL picks, SPP spp (+ the 2-spp warm-up of
-# c4_bench.py); separate runs per counter set; one model file per device kernel.   usage: tools/r03_c4_pmc.sh [tag]
+# c4_bench.py); separate runs per counter set; one model file per device kernel.   usage: tools/experiments/r03_c4_pmc.sh [tag]
 set -o pipefail
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 export TMPDIR=/tmp
 K=${C4_KERNEL:-6}
 SPP=${SPP:-128}

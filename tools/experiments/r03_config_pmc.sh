@@ -1,8 +1,8 @@
 #!/bin/bash
 # PMC model per BASELINE configuration (C1, C2, C3, C4 with the library's automatic kernel): separate rocprofv3 --pmc passes of
-# tools/config_run.py, one model file each (tools/make_pt_model.py).   usage: tools/r03_config_pmc.sh [config ...]
+# tools/config_run.py, one model file each (tools/make_pt_model.py).   usage: tools/experiments/r03_config_pmc.sh [config ...]
 set -o pipefail
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 export TMPDIR=/tmp
 declare -A SPP=( [scene_10]=100 [scene_500_c2]=500 [cornell]=2000 [cornell_mix]=2000 [c4]=1000 [c5r]=500 )  # the spp tools/config_bench.py times them with
 declare -A PIX=( [scene_10]=$((400*225)) [scene_500_c2]=$((1200*800)) [cornell]=$((800*800)) [cornell_mix]=$((800*800)) [c4]=$((1200*1200)) [c5r]=$((1600*1600)) )

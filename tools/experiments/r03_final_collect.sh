@@ -1,6 +1,6 @@
 #!/bin/bash
-# copy what tools/r03_final.sh measured (merged back into gpurun_out/) into the tracked profiles/ tree
-cd "$(dirname "$0")/.."
+# copy what tools/experiments/r03_final.sh measured (merged back into gpurun_out/) into the tracked profiles/ tree
+cd "$(dirname "$0")/../.."
 cp gpurun_out/r03_pmc_final/pt_kernel_model.json profiles/pt_kernel_model.json
 cp gpurun_out/r03_pmc_final/pmc_summary_headline.csv profiles/r03/pmc_summary_headline.csv
 for c in scene_10 scene_500_c2 cornell cornell_mix c4 c5r; do

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Round-3 PMC passes of the headline workload (scene_500 1200x1200, SPP spp): separate runs per counter set, summary + model.
-# usage: tools/r03_headline_pmc.sh [tag]   -> gpurun_out/r03_pmc_<tag>/
+# usage: tools/experiments/r03_headline_pmc.sh [tag]   -> gpurun_out/r03_pmc_<tag>/
 set -o pipefail
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 export TMPDIR=/tmp
 TAG=${1:-headline}
 OUT=gpurun_out/r03_pmc_$TAG; rm -rf $OUT; mkdir -p $OUT

@@ -2,7 +2,7 @@
 # Round-3 records of the bench command: the default bench line, the same command under rocprofv3 --kernel-trace --stats, the
 # forced-RCCL line; copied into profiles/r03/ by hand afterwards (gpurun_out/ is scratch).
 set -o pipefail
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 export TMPDIR=/tmp
 OUT=gpurun_out/r03_prof; rm -rf $OUT; mkdir -p $OUT
 timeout -k 10 400 python3 bench.py > $OUT/bench_default.json 2>>$OUT/err.log || exit 1

@@ -1,8 +1,8 @@
 #!/bin/bash
 # PMC pass of ONE rank's share of the headline frame (tools/share_one.py WORLD 1000): what a share executes per sample compared with the
-# whole frame (profiles/pt_kernel_model.json).  usage: tools/r03_share_pmc.sh [world ...]
+# whole frame (profiles/pt_kernel_model.json).  usage: tools/experiments/r03_share_pmc.sh [world ...]
 set -o pipefail
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 export TMPDIR=/tmp
 for W in ${@:-8}; do
   OUT=gpurun_out/r03_sharepmc_w$W; rm -rf $OUT; mkdir -p $OUT

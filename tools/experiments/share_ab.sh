@@ -1,6 +1,6 @@
 #!/bin/bash
 # kernel time (best of 3) of one rank's share of the headline frame (WORLDS, default 1 8 16; 1000 spp) for the default build and every variant build
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 for V in default $(ls rust-raytracer_amd/variants/*.so 2>/dev/null); do
   L=$PWD/$V; [ "$V" = default ] && L=$PWD/rust-raytracer_amd/librtamd.so
   echo -n "$(basename $V): "

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Phase statistics of pt_kernel (kernels 1 / 2) on the BASELINE configurations: wave time and lane utilisation per phase -- node loop,
 # leaf tests, materialize, the common part of shade, each material branch -- from a tools-only build (-DRTAMD_PHASE_STATS).
-# usage: tools/r04/phase_stats.sh [config ...]   -> gpurun_out/r04_phase/<config>.txt   (is material stream sorting worth building?)
+# usage: tools/phase_stats.sh [config ...]   -> gpurun_out/r04_phase/<config>.txt   (is material stream sorting worth building?)
 set -o pipefail
-cd "$(dirname "$0")/../.."
+cd "$(dirname "$0")/.."
 V=rust-raytracer_amd/variants/librtamd_phase.so   # (built here or beforehand: the variants directory travels with gpurun)
 if [ ! -f $V ] || [ rust-raytracer_amd/csrc/device/kernels.hip -nt $V ]; then tools/build_variant.sh phase -DRTAMD_PHASE_STATS > /dev/null 2>&1 || { echo "variant build failed"; exit 1; }; fi
 OUT=gpurun_out/r04_phase; mkdir -p $OUT
