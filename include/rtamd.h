@@ -100,6 +100,9 @@ typedef struct rt_params {
                             1 = light importance sampling: on Diffuse hits the direction is drawn from the
                                 0.5*lights + 0.5*cosine mixture pdf (book-3 MixturePDF semantics; needs rt_scene_set_lights);
                             2 = the reference's SPPM sample_ray (only through rt_render_sppm) */
+    double time0, time1; /* book-2 extension (the reference has no code for it: its Ray has no time, ray.rs:3-6): the camera's shutter.
+                            With time1 > time0 every sample draws a time in [time0, time1) right after its lens sample and moving spheres
+                            (rt_object_moving_sphere) are where they are at that time; default 0, 0 = no draw */
 } rt_params;
 
 typedef struct rt_stats {
@@ -154,6 +157,10 @@ void rt_scene_destroy(rt_scene* s);
 int rt_texture_constant(rt_scene* s, const double color[3]);
 int rt_texture_checker(rt_scene* s, int t0, int t1);
 int rt_texture_image(rt_scene* s, int width, int height, const uint8_t* rgb);
+/* Book-2 extension, no reference counterpart (BASELINE config C5 names it): noise_texture(scale), the marble texture
+ * 0.5 (1 + sin(scale p.z + 10 turb(p))) over Perlin noise with 7 octaves of turbulence; the 256 gradient vectors and the three
+ * permutations come from the RNG stream (seed, "perlin" key, 0); sin is the deterministic rtamd-sin-1 (csrc/common/detsin.h) */
+int rt_texture_noise(rt_scene* s, double scale, uint64_t seed);
 /* material.rs:88-212  Lambertian::new / Metal::new / Dielectric::new / DiffuseLight::new */
 int rt_material_lambertian(rt_scene* s, int albedo_tex);
 int rt_material_metal(rt_scene* s, int albedo_tex, double fuzz);
@@ -165,6 +172,10 @@ int rt_material_isotropic(rt_scene* s, int albedo_tex);
 
 /* objects/sphere.rs:9-13 */
 int rt_object_sphere(rt_scene* s, const double center[3], double radius, int material);
+/* Book-2 extension, no reference counterpart: moving_sphere(center0, center1, time0, time1, radius, material) -- Sphere::hit around
+ * the centre center0 + (center1 - center0) (ray.time - time0) / (time1 - time0); box = the union of the boxes at both times.
+ * Rendered by kernels 1 and 2 with integrators 0 and 1; needs rt_params.time1 > rt_params.time0 to move */
+int rt_object_moving_sphere(rt_scene* s, const double center0[3], const double center1[3], double time0, double time1, double radius, int material);
 /* objects/rectangle.rs:7-12,44-49,82-87 : {a0,b0}=xy0|xz0|yz0, {a1,b1}=xy1|xz1|yz1, k = z|y|x */
 int rt_object_rect_xy(rt_scene* s, double x0, double y0, double x1, double y1, double z, int material);
 int rt_object_rect_xz(rt_scene* s, double x0, double z0, double x1, double z1, double y, int material);
@@ -209,13 +220,14 @@ int rt_object_bounding_box(const rt_scene* s, int object, double out_min_max[6])
 /* Introspection of the host-side object graph (the walk a `Describe` visitor of the reference's trait objects does the
  * other way round): what an object id stands for, its parameters and its children.
  *   sphere:    v = {center[3], radius}                      (objects/sphere.rs:9-13)
+ *   moving sphere: v = {center0[3], radius, center1[3]} (its times are not reported)
  *   rect:      v = {a0, b0, a1, b1, k}, axis = constant axis (0: YZRectangle x=k, 1: XZRectangle y=k, 2: XYRectangle z=k)
  *   triangle:  v = {ia, ib, ic} vertex indices of its mesh  (objects/mesh.rs:8-14)
  *   medium:    v = {density}, material = phase function, children = {boundary}   (objects/medium.rs:9-13)
  *   cube / list / mesh / transform / bvh: children only (cube: its 6 sides; mesh: its inner BVHNode; bvh: {left, right}) */
 typedef enum rt_object_type {
     RT_OBJ_SPHERE = 0, RT_OBJ_RECT = 1, RT_OBJ_CUBE = 2, RT_OBJ_TRIANGLE = 3, RT_OBJ_MESH = 4, RT_OBJ_TRANSFORM = 5,
-    RT_OBJ_LIST = 6, RT_OBJ_BVH = 7, RT_OBJ_MEDIUM = 8
+    RT_OBJ_LIST = 6, RT_OBJ_BVH = 7, RT_OBJ_MEDIUM = 8, RT_OBJ_MOVING_SPHERE = 9
 } rt_object_type;
 typedef struct rt_object_desc {
     int32_t type;        /* rt_object_type */
@@ -341,7 +353,7 @@ int rt_debug_rng_host(uint64_t seed, uint64_t pixel, uint64_t sample, int n, uin
  * out_range[i] = the i-th gen_range(lo..hi) of another fresh stream of the same key; on_device != 0 computes them in a kernel */
 int rt_debug_rng_floats(uint64_t seed, uint64_t pixel, uint64_t sample, int n, double lo, double hi, int on_device, double* out_gen,
                         double* out_range);
-/* device f64 sqrt / divide / rtamd-ln-1, element-wise: op 0 = sqrt(a), 1 = a/b, 2 = det_ln(a) */
+/* device f64 sqrt / divide / rtamd-ln-1 / rtamd-sin-1, element-wise: op 0 = sqrt(a), 1 = a/b, 2 = det_ln(a), 3 = det_sin(a) */
 int rt_debug_math_device(int op, size_t n, const double* a_host, const double* b_host, double* out_host);
 /* closest hit of explicit world-space rays through device traversal `kernel` (1, 2, or 3 = kernel 2's LDS node table "NodeW" with
  * its own box test, which pt_kernel uses when the scene is LDS-resident): rays n*6 (orig,dir);

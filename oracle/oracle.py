@@ -80,6 +80,12 @@ def lib():
     L.orc_tonemap_u8.argtypes = [c_double_p, C.c_size_t, c_u8_p]
     L.orc_rng_stream.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, c_u64_p]
     L.orc_rng_f64.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, c_double_p]
+    L.orc_det_sin.restype = C.c_double
+    L.orc_det_sin.argtypes = [C.c_double]
+    L.orc_tex_noise.argtypes = [C.c_void_p, C.c_double, C.c_uint64]
+    L.orc_noise_value.argtypes = [C.c_void_p, C.c_int, c_double_p, c_double_p]
+    L.orc_moving_sphere.argtypes = [C.c_void_p, c_double_p, c_double_p, C.c_double, C.c_double, C.c_double, C.c_int]
+    L.orc_set_shutter.argtypes = [C.c_void_p, C.c_double, C.c_double]
     L.orc_rng_range.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_double, C.c_double, c_double_p]
     L.orc_sample_helper.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, c_double_p, c_double_p]
     L.orc_vec3_op.argtypes = [C.c_int, c_double_p, c_double_p, C.c_double, c_double_p]
@@ -138,6 +144,15 @@ class Scene:
     def CheckerTexture(self, t0, t1):
         return self._chk(self.L.orc_tex_checker(self.h, t0, t1), "CheckerTexture")
 
+    def NoiseTexture(self, scale, seed=1):
+        """D9 (book 2): Perlin marble texture 0.5 (1 + sin(scale z + 10 turb(p))); tables from the stream (seed, PERLIN_KEY, 0)"""
+        return self._chk(self.L.orc_tex_noise(self.h, float(scale), int(seed)), "NoiseTexture")
+
+    def noise_value(self, tex, p):
+        out = (C.c_double * 3)()
+        self._chk(self.L.orc_noise_value(self.h, tex, _d3(p), out), "noise_value")
+        return float(out[0]), float(out[1]), float(out[2])
+
     def ImageTexture(self, rgb_u8):
         a = np.ascontiguousarray(rgb_u8, dtype=np.uint8)
         h, w, _ = a.shape
@@ -164,6 +179,10 @@ class Scene:
     # hitables
     def Sphere(self, center, radius, mat):
         return self._chk(self.L.orc_sphere(self.h, float(center[0]), float(center[1]), float(center[2]), float(radius), mat), "Sphere")
+
+    def MovingSphere(self, center0, center1, time0, time1, radius, mat):
+        """D9 (book 2): a sphere whose centre moves linearly from center0 at time0 to center1 at time1"""
+        return self._chk(self.L.orc_moving_sphere(self.h, _d3(center0), _d3(center1), float(time0), float(time1), float(radius), mat), "MovingSphere")
 
     def XYRectangle(self, xy0, xy1, z, mat):
         return self._chk(self.L.orc_rect(self.h, 2, float(xy0[0]), float(xy0[1]), float(xy1[0]), float(xy1[1]), float(z), mat), "XYRectangle")
@@ -204,6 +223,10 @@ class Scene:
                            aspect=aspect_ratio, aperture=aperture, focus_dist=focus_dist)
         self._chk(self.L.orc_set_camera(self.h, _d3(look_from), _d3(look_at), _d3(vup), float(vfov), float(aspect_ratio),
                                         float(aperture), float(focus_dist)), "Camera::new")
+
+    def set_shutter(self, time0, time1):
+        """D9 (book 2): the camera draws a time in [time0, time1) per sample (after the lens sample) when time1 > time0"""
+        self._chk(self.L.orc_set_shutter(self.h, float(time0), float(time1)), "shutter")
 
     def camera_basis(self):
         out = (C.c_double * 22)()

@@ -257,6 +257,7 @@ static inline Vec3 transform_dir(Vec3 p, const Mat4& t) {  // vec3.rs:180-184 (w
 // ----------------------------------------------------------------------------
 struct Ray {
     Vec3 orig, dir;
+    double time = 0.;  // D9 (book-2 extension; the reference's Ray has no time, ray.rs:3-6): when the sample was taken, within the camera's shutter
     Vec3 at(double t) const { return v_add(orig, v_muls(dir, t)); }
 };
 
@@ -345,6 +346,100 @@ struct ImageTexture : Texture {  // material.rs:50,70-84 ; Q11: x==width at u==1
         if (y > h - 1) y = h - 1;
         const uint8_t* px = &rgb[((size_t)y * w + x) * 3];
         return Vec3(px[0] / 255., px[1] / 255., px[2] / 255.);  // vec3.rs:233-238
+    }
+};
+
+// ----------------------------------------------------------------------------
+// D9: the two book-2 ("Ray Tracing: The Next Week") features BASELINE's config C5 names and the reference has no code for --
+// motion blur (a time on every ray, a sphere whose centre moves linearly during the shutter) and a Perlin-noise texture.  Parity
+// exists only against this restatement.  Restated from the book's published algorithms, with two choices of
+// this build: the tables come from the seeded stream (seed, PERLIN_KEY, 0), and the marble texture's sin() is the deterministic
+// rtamd-sin-1 below (libm's last bit differs between glibc and the device library; the value feeds a colour, so oracle and
+// kernel must agree to the bit).
+// ----------------------------------------------------------------------------
+// rtamd-sin-1: sin(x) for |x| < 2^19 * pi/2 by Cody-Waite reduction x = n * pi/2 + (y0 + y1) with the two-step constants published
+// for fdlibm's e_rem_pio2.c (always two steps: good to 118 bits) and the degree-13 / degree-14 kernels of k_sin.c / k_cos.c in their
+// plain forms; IEEE + - * only, no fused operations, so every implementation returns the same bits.  |x| beyond the range -> 0.
+static double det_sin(double x) {
+    static const double INVPIO2 = 6.36619772367581382433e-01, PIO2_1 = 1.57079632673412561417e+00, PIO2_2 = 6.07710050630396597660e-11,
+                        PIO2_2T = 2.02226624879595063154e-21;
+    static const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                        S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    static const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                        C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    if (!(std::fabs(x) < 823549.0)) return 0.0;  // (also NaN)
+    const double t = std::fabs(x);
+    const int n = (int)(t * INVPIO2 + 0.5);
+    const double fn = (double)n;
+    const double r1 = t - fn * PIO2_1;
+    const double w2 = fn * PIO2_2;
+    const double r2 = r1 - w2;
+    const double w = fn * PIO2_2T - ((r1 - r2) - w2);
+    const double y0 = r2 - w, y1 = (r2 - y0) - w;
+    const double z = y0 * y0;
+    double res;
+    if ((n & 1) == 0) {  // +- sin(y0 + y1)
+        const double v = z * y0;
+        const double rr = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+        res = y0 - ((z * (0.5 * y1 - v * rr) - y1) - v * S1);
+    } else {  // +- cos(y0 + y1)
+        const double rr = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+        res = 1.0 - (0.5 * z - (z * rr - y0 * y1));
+    }
+    if (n & 2) res = -res;
+    return (x < 0.) ? -res : res;
+}
+
+static const uint64_t PERLIN_KEY = 0x243F6A8885A308D3ULL;  // stream (seed, PERLIN_KEY, 0) fills a noise texture's tables
+// perlin / noise_texture of the book: 256 random unit vectors, three permutations, trilinear interpolation with Hermite smoothing,
+// 7 octaves of turbulence, marble = 0.5 (1 + sin(scale z + 10 turb(p)))
+struct NoiseTexture : Texture {
+    double scale;
+    Vec3 ranvec[256];
+    int perm[3][256];
+    NoiseTexture(double scale_, uint64_t seed) : scale(scale_) {
+        Rng rng(seed, PERLIN_KEY, 0);
+        for (int i = 0; i < 256; i++) {
+            const double x = rng.gen_range(-1., 1.), y = rng.gen_range(-1., 1.), z = rng.gen_range(-1., 1.);
+            ranvec[i] = v_unit(Vec3(x, y, z));  // unit_vector(vec3::random(-1, 1))
+        }
+        for (int a = 0; a < 3; a++) {  // perlin_generate_perm: identity, then permute from the top
+            for (int i = 0; i < 256; i++) perm[a][i] = i;
+            for (int i = 255; i > 0; i--) {
+                const int target = (int)(((uint64_t)rng.next_u32() * (uint64_t)(i + 1)) >> 32);  // random_int(0, i)
+                std::swap(perm[a][i], perm[a][target]);
+            }
+        }
+    }
+    double noise(Vec3 p) const {
+        const double fx = std::floor(p.x), fy = std::floor(p.y), fz = std::floor(p.z);
+        const double u = p.x - fx, v = p.y - fy, w = p.z - fz;
+        const int i = (int)fx, j = (int)fy, k = (int)fz;
+        const double uu = u * u * (3. - 2. * u), vv = v * v * (3. - 2. * v), ww = w * w * (3. - 2. * w);
+        double accum = 0.;
+        for (int di = 0; di < 2; di++)
+            for (int dj = 0; dj < 2; dj++)
+                for (int dk = 0; dk < 2; dk++) {
+                    const Vec3 c = ranvec[perm[0][(i + di) & 255] ^ perm[1][(j + dj) & 255] ^ perm[2][(k + dk) & 255]];
+                    const Vec3 weight_v(u - di, v - dj, w - dk);
+                    accum += (di * uu + (1 - di) * (1. - uu)) * (dj * vv + (1 - dj) * (1. - vv)) * (dk * ww + (1 - dk) * (1. - ww)) * v_dot(c, weight_v);
+                }
+        return accum;
+    }
+    double turb(Vec3 p) const {
+        double accum = 0., weight = 1.;
+        Vec3 temp_p = p;
+        for (int i = 0; i < 7; i++) {
+            accum += weight * noise(temp_p);
+            weight *= 0.5;
+            temp_p = v_muls(temp_p, 2.);
+        }
+        return std::fabs(accum);
+    }
+    double value(Vec3 p) const { return 0.5 * (1. + det_sin(scale * p.z + 10. * turb(p))); }
+    Vec3 get_color(const HitRecord& rec) const override {
+        const double m = value(rec.p);
+        return Vec3(1. * m, 1. * m, 1. * m);  // color(1,1,1) * 0.5 * (1 + sin(..))
     }
 };
 
@@ -585,6 +680,39 @@ struct Sphere : Hitable {
     }
 };
 
+// D9: moving_sphere of the book: the centre moves linearly from center0 at time0 to center1 at time1; everything else is Sphere::hit
+struct MovingSphere : Hitable {
+    Vec3 center0, center1;
+    double time0, time1, radius;
+    const Material* material;
+    Vec3 center(double time) const { return v_add(center0, v_muls(v_sub(center1, center0), (time - time0) / (time1 - time0))); }
+    bool hit(const Ray& r, double t_min, double t_max, HitRecord& out, Ctx& cx) const override {
+        cx.cnt.n_sphere++;
+        const Vec3 c = center(r.time);
+        Vec3 oc = v_sub(r.orig, c);
+        double a = v_sqlen(r.dir);
+        double half_b = v_dot(oc, r.dir);
+        double cc = v_sqlen(oc) - radius * radius;
+        double discriminant = half_b * half_b - a * cc;
+        if (discriminant < 0.) return false;
+        double sqrt_d = std::sqrt(discriminant);
+        double root = (-half_b - sqrt_d) / a;
+        if (!(root >= t_min && root <= t_max)) root = (-half_b + sqrt_d) / a;
+        if (!(root >= t_min && root <= t_max)) return false;
+        Vec3 p = r.at(root);
+        Vec3 outward = v_divs(v_sub(p, c), radius);
+        double u, v;
+        Sphere::get_uv(outward, u, v);
+        out = HitRecord::make(root, outward, r, material, u, v, id);
+        return true;
+    }
+    bool bounding_box(AABB& out) const override {  // surrounding_box of the boxes at time0 and time1
+        const Vec3 rr(radius, radius, radius);
+        out = AABB::surrounding_box(AABB{v_sub(center0, rr), v_add(center0, rr)}, AABB{v_sub(center1, rr), v_add(center1, rr)});
+        return true;
+    }
+};
+
 // XY/XZ/YZ rectangles -- raytracer/src/objects/rectangle.rs:7-117.
 // axis = the constant axis (2: XY rect, 1: XZ rect, 0: YZ rect).
 // No guard on a zero direction component: t may be NaN/inf and every reject
@@ -710,7 +838,7 @@ struct Transform : Hitable {
     AABB box;
     bool hit(const Ray& r, double t_min, double t_max, HitRecord& out, Ctx& cx) const override {  // :152-165
         cx.cnt.n_xform++;
-        Ray trans_r{transform_point(r.orig, inverse_trans), transform_dir(r.dir, inverse_trans)};
+        Ray trans_r{transform_point(r.orig, inverse_trans), transform_dir(r.dir, inverse_trans), r.time};
         HitRecord rec;
         if (!obj->hit(trans_r, t_min, t_max, rec, cx)) return false;
         Vec3 outward_normal = transform_dir(rec.normal, trans);  // M, not inverse-transpose (Q7)
@@ -756,6 +884,7 @@ struct ConstantMedium : Hitable {
 struct Camera {
     Vec3 origin, lower_left_corner, horizontal, vertical, u, v, w;
     double lens_radius = 0;
+    double time0 = 0., time1 = 0.;  // D9: shutter open / close; time1 > time0 makes get_ray draw a time
     void init(Vec3 look_from, Vec3 look_at, Vec3 vup, double vfov, double aspect_ratio, double aperture, double focus_dist) {
         double theta = vfov * PI / 180.;  // degrees_to_radians, vec3.rs:10-12
         double h = std::tan(theta / 2.);
@@ -776,7 +905,10 @@ struct Camera {
         Vec3 offset = v_add(v_muls(u, rd.x), v_muls(v, rd.y));
         Vec3 o = v_add(origin, offset);
         Vec3 d = v_sub(v_sub(v_add(v_add(lower_left_corner, v_muls(horizontal, s)), v_muls(vertical, t)), origin), offset);
-        return Ray{o, d};
+        // D9 (book 2: ray(origin + offset, .., random_double(time0, time1))): one more draw, AFTER the lens sample, and only when the
+        // shutter is open for a while -- scenes without motion keep their streams
+        const double time = (time1 > time0) ? rng.gen_range(time0, time1) : time0;
+        return Ray{o, d, time};
     }
 };
 
@@ -813,7 +945,9 @@ static Vec3 sample_ray(const Scene& sc, Ray ray, int max_depth, double t_min, Ct
         if (sr.has_ray && sr.has_att) {
             // D2: Diffuse continues exactly like Specular/Reflect/Refract
             throughput = v_elemul(throughput, sr.att);
+            const double time = curr.time;  // D9: scattered = ray(rec.p, direction, r_in.time())
             curr = sr.ray;
+            curr.time = time;
         } else {
             break;  // Absorb
         }
@@ -911,10 +1045,12 @@ static Vec3 sample_ray_mixture(const Scene& sc, Ray ray, int max_depth, double t
             double wgt = scattering_pdf / pdf_val;
             if (!(wgt > 0.)) break;  // direction below the surface (or a NaN): the path carries nothing further
             throughput = v_muls(v_elemul(throughput, sr.att), wgt);
-            curr = Ray{rec.p, dir};
+            curr = Ray{rec.p, dir, curr.time};
         } else {
             throughput = v_elemul(throughput, sr.att);
+            const double time = curr.time;
             curr = sr.ray;
+            curr.time = time;
         }
     }
     return radiance;
@@ -1429,6 +1565,46 @@ int orc_mat_isotropic(void* s, int t) {
     return (int)sc.materials.size() - 1;
 }
 double orc_det_ln(double x) { return det_ln(x); }
+double orc_det_sin(double x) { return det_sin(x); }
+// D9
+int orc_tex_noise(void* s, double scale, uint64_t seed) {
+    Scene& sc = *(Scene*)s;
+    try {
+        sc.textures.emplace_back(new NoiseTexture(scale, seed));
+    } catch (const UnitZero&) {
+        return ORC_ERR_UNIT_ZERO;
+    }
+    return (int)sc.textures.size() - 1;
+}
+int orc_noise_value(void* s, int t, const double* p3, double* out3) {  // {noise(p), turb(p), the marble value}
+    Scene& sc = *(Scene*)s;
+    const NoiseTexture* n = dynamic_cast<const NoiseTexture*>(tex(sc, t));
+    if (!n) return ORC_ERR_ARG;
+    const Vec3 p(p3[0], p3[1], p3[2]);
+    out3[0] = n->noise(p);
+    out3[1] = n->turb(p);
+    out3[2] = n->value(p);
+    return ORC_OK;
+}
+int orc_moving_sphere(void* s, const double* c0, const double* c1, double time0, double time1, double r, int m) {
+    Scene& sc = *(Scene*)s;
+    if (!mat(sc, m) || !(time1 > time0)) return ORC_ERR_ARG;
+    auto o = std::make_unique<MovingSphere>();
+    o->center0 = Vec3(c0[0], c0[1], c0[2]);
+    o->center1 = Vec3(c1[0], c1[1], c1[2]);
+    o->time0 = time0;
+    o->time1 = time1;
+    o->radius = r;
+    o->material = mat(sc, m);
+    return push_obj(sc, std::move(o));
+}
+int orc_set_shutter(void* s, double time0, double time1) {
+    Scene& sc = *(Scene*)s;
+    if (!(time1 >= time0)) return ORC_ERR_ARG;
+    sc.cam.time0 = time0;
+    sc.cam.time1 = time1;
+    return ORC_OK;
+}
 
 int orc_sphere(void* s, double cx, double cy, double cz, double r, int m) {
     Scene& sc = *(Scene*)s;

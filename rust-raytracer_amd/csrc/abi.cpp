@@ -80,6 +80,8 @@ void rt_default_params(rt_params* p) {
     p->kernel = 0;
     p->device = -1;
     p->integrator = 0;
+    p->time0 = 0.;  // (book-2 extension: shutter closed = no time draw)
+    p->time1 = 0.;
 }
 int rt_device_count(void) { return device_count(); }
 int64_t rt_release_workspaces(void) {
@@ -149,6 +151,12 @@ int rt_texture_image(rt_scene* s, int width, int height, const uint8_t* rgb) {
         return add_texture_image(*s, width, height, rgb);
     });
 }
+int rt_texture_noise(rt_scene* s, double scale, uint64_t seed) {
+    return guard([&] {
+        not_committed_only(s);
+        return add_texture_noise(*s, scale, seed);
+    });
+}
 int rt_material_lambertian(rt_scene* s, int tex) {
     return guard([&] {
         not_committed_only(s);
@@ -191,6 +199,13 @@ int rt_object_sphere(rt_scene* s, const double center[3], double radius, int mat
         not_committed_only(s);
         REQUIRE(center, "null center");
         return add_sphere(*s, center, radius, material);
+    });
+}
+int rt_object_moving_sphere(rt_scene* s, const double center0[3], const double center1[3], double time0, double time1, double radius, int material) {
+    return guard([&] {
+        not_committed_only(s);
+        REQUIRE(center0 && center1, "null center");
+        return add_moving_sphere(*s, center0, center1, time0, time1, radius, material);
     });
 }
 int rt_object_rect_xy(rt_scene* s, double x0, double y0, double x1, double y1, double z, int material) {
@@ -330,13 +345,17 @@ int rt_object_describe(const rt_scene* s, int object, rt_object_desc* out) {
         const ObjectRec& o = s->objects[object];
         static_assert((int)OBJ_SPHERE == RT_OBJ_SPHERE && (int)OBJ_RECT == RT_OBJ_RECT && (int)OBJ_CUBE == RT_OBJ_CUBE &&
                       (int)OBJ_TRIANGLE == RT_OBJ_TRIANGLE && (int)OBJ_MESH == RT_OBJ_MESH && (int)OBJ_TRANSFORM == RT_OBJ_TRANSFORM &&
-                      (int)OBJ_LIST == RT_OBJ_LIST && (int)OBJ_BVH == RT_OBJ_BVH && (int)OBJ_MEDIUM == RT_OBJ_MEDIUM, "rt_object_type mirrors ObjType");
+                      (int)OBJ_LIST == RT_OBJ_LIST && (int)OBJ_BVH == RT_OBJ_BVH && (int)OBJ_MEDIUM == RT_OBJ_MEDIUM &&
+                      (int)OBJ_MOVING_SPHERE == RT_OBJ_MOVING_SPHERE, "rt_object_type mirrors ObjType");
         std::memset(out, 0, sizeof(*out));
         out->type = o.type;
-        out->material = (o.type == OBJ_SPHERE || o.type == OBJ_RECT || o.type == OBJ_TRIANGLE) ? o.material : -1;
+        out->material = (o.type == OBJ_SPHERE || o.type == OBJ_RECT || o.type == OBJ_TRIANGLE || o.type == OBJ_MOVING_SPHERE) ? o.material : -1;
         out->n_children = (int32_t)o.children.size();
         if (o.type == OBJ_SPHERE) {
             out->v[0] = o.c[0]; out->v[1] = o.c[1]; out->v[2] = o.c[2]; out->v[3] = o.r;
+        } else if (o.type == OBJ_MOVING_SPHERE) {
+            out->v[0] = o.c[0]; out->v[1] = o.c[1]; out->v[2] = o.c[2]; out->v[3] = o.r;
+            out->v[4] = o.c1[0]; out->v[5] = o.c1[1]; out->v[6] = o.c1[2];
         } else if (o.type == OBJ_RECT) {
             out->axis = o.axis;
             out->v[0] = o.a0; out->v[1] = o.b0; out->v[2] = o.a1; out->v[3] = o.b1; out->v[4] = o.k;
@@ -465,6 +484,7 @@ static RenderPlan make_plan(const rt_params* p) {
     REQUIRE(p->world >= 1 && p->rank >= 0 && p->rank < p->world, "bad rank/world");
     REQUIRE((p->kernel >= 0 && p->kernel <= 2) || p->kernel == 5 || p->kernel == 6, "unknown kernel id (0 auto, 1, 2, 5, 6)");
     REQUIRE(p->integrator >= 0 && p->integrator <= 2, "unknown integrator id");
+    REQUIRE(std::isfinite(p->time0) && std::isfinite(p->time1) && p->time1 >= p->time0, "shutter: time1 must be >= time0 and both finite");
     RenderPlan pl;
     pl.width = p->width; pl.height = p->height; pl.spp = p->spp; pl.max_depth = p->max_depth;
     pl.t_min = p->t_min; pl.seed = p->seed; pl.rank = p->rank; pl.world = p->world;
@@ -475,6 +495,8 @@ static RenderPlan make_plan(const rt_params* p) {
     if (pl.tiles_owned < 0) pl.tiles_owned = 0;
     pl.kernel = p->kernel;
     pl.integrator = p->integrator;
+    pl.time0 = p->time0;
+    pl.time1 = p->time1;
     // One launch renders all sample indices unless the caller splits them (rt_params.spp_chunk): samples are folded into the
     // accumulator inside the kernel, unit by unit, so no per-launch sample buffer bounds the launch size.
     int chunk = p->spp_chunk > 0 ? p->spp_chunk : p->spp;
@@ -962,7 +984,7 @@ int rt_debug_rng_floats(uint64_t seed, uint64_t pixel, uint64_t sample, int n, d
 }
 int rt_debug_math_device(int op, size_t n, const double* a_host, const double* b_host, double* out_host) {
     return guard([&] {
-        REQUIRE(n > 0 && a_host && out_host && (op == 0 || op == 2 || (op == 1 && b_host)), "bad argument");
+        REQUIRE(n > 0 && a_host && out_host && (op == 0 || op == 2 || op == 3 || (op == 1 && b_host)), "bad argument");
         if (device_count() < 1) throw RtError(RT_ERR_NO_DEVICE, "no HIP device");
         debug_math_device(op, n, a_host, b_host, out_host);
         return (int)RT_OK;

@@ -38,7 +38,10 @@ enum NodeKind : uint32_t {
     // in the program and in accel items; a Hit's kp carries the winning side (0 XY z=min, 1 XY z=max, 2 XZ y=min, 3 XZ y=max,
     // 4 YZ x=min, 5 YZ x=max).  The six sides are contiguous in the reference's visit order, so one program index per cube
     // resolves exact ties against other objects exactly as six would; ties among the sides are resolved inside the scan.
-    NK_CUBE = 13
+    NK_CUBE = 13,
+    // D9 (book-2 extension, no reference code): moving_sphere -- Sphere::hit around center0 + (center1 - center0) (ray.time - time0) / (time1 - time0);
+    // payload = index into the moving-sphere table (cold part: 10 f64 per record {center0, center1, time0, time1, radius, material})
+    NK_MSPHERE = 14
 };
 static const uint32_t NK_BITS = 4;
 static const uint32_t NK_MASK = 15;
@@ -65,11 +68,11 @@ struct MatDev {   // material.rs:88-212 (+ :213-231, the commented-out Isotropic
     double r0_back;     // ((1 - ir) / (1 + ir))^2
 };
 struct TexDev {   // material.rs:48-84
-    int32_t type;  // 0 Constant, 1 Checker, 2 Image
+    int32_t type;  // 0 Constant, 1 Checker, 2 Image, 3 Noise (D9: Perlin marble, book 2)
     int32_t t0, t1;        // Checker: constant-texture ids (.0 when sines < 0, .1 otherwise)
     int32_t w, h;          // Image
-    uint32_t texel_off;    // Image: byte offset into texels
-    double color[3];       // Constant
+    uint32_t texel_off;    // Image: byte offset into texels; Noise: byte offset (8-aligned) of its tables: 768 f64 gradient vectors, 768 permutation bytes
+    double color[3];       // Constant; Noise: color[0] = scale
 };
 
 // ---------------------------------------------------------------------------
@@ -116,6 +119,8 @@ struct FlatView {  // by-value kernel argument
     uint32_t off_mats, off_texs, off_vpos, off_vnrm, off_texels;
     uint32_t off_media;    // cold part: MediumDev per ConstantMedium, in the reference's visit order
     uint32_t n_media;
+    uint32_t off_msph;     // cold part: moving spheres (NK_MSPHERE), 10 f64 each
+    uint32_t n_msph;
     uint32_t n_nodes;
     uint32_t stage_bytes;  // kernel 1 stages bytes [0, stage_bytes) into LDS: [meta|boxes|spheres|rects|tris|xforms|vpos]
     uint32_t kinds_mask;   // bit k set if some node has kind k

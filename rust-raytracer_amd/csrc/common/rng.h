@@ -98,5 +98,7 @@ struct Rng {
 
 // key of the BVHNode::new split-axis stream: stream(bvh_seed, RT_BVH_STREAM_KEY, 0)
 static const uint64_t RT_BVH_STREAM_KEY = 0xB7E151628AED2A6AULL;
+// key of a noise texture's table stream: stream(texture seed, RT_PERLIN_STREAM_KEY, 0)  (D9)
+static const uint64_t RT_PERLIN_STREAM_KEY = 0x243F6A8885A308D3ULL;
 
 }  // namespace rtamd

@@ -21,6 +21,7 @@ struct RenderPlan {
     int sub_spp;    // samples per pixel per work unit (a wave's pool = 64 * sub_spp paths; at most 8)
     int kernel;
     int integrator;  // 0 BSDF sampling, 1 light/cosine mixture pdf, 2 SPPM final gather (needs sppm_est)
+    double time0 = 0., time1 = 0.;  // D9: the camera's shutter (time1 > time0: every sample draws a time)
     const double* sppm_est = nullptr;  // device: per pixel {caustic estimate[3], global estimate[3]}
 };
 

@@ -28,6 +28,8 @@ struct Builder {
     std::vector<uint32_t> tris;
     std::vector<double> tripre;  // per triangle: pa, e0 = pb - pa, e1 = pc - pa, pad (10 doubles = 80 B)
     std::vector<MediumDev> media;
+    std::vector<double> msph;  // moving spheres: {center0, center1, time0, time1, radius, material} (10 f64)
+    std::map<int, uint32_t> msph_of;
     double media_extent = 0.;  // largest |coordinate| of the media's bounding boxes: scatter points inside a medium are ray origins too
     std::map<int, uint32_t> medium_of;
     int medium_depth = 0;
@@ -91,6 +93,16 @@ struct Builder {
                 }
                 uint32_t n = node(NK_SPHERE, it->second);
                 accel_item(id, o, NK_SPHERE | (it->second << NK_BITS), n);
+                break;
+            }
+            case OBJ_MOVING_SPHERE: {  // D9
+                auto it = msph_of.find(id);
+                if (it == msph_of.end()) {
+                    it = msph_of.emplace(id, (uint32_t)(msph.size() / 10)).first;
+                    msph.insert(msph.end(), {o.c[0], o.c[1], o.c[2], o.c1[0], o.c1[1], o.c1[2], o.time0, o.time1, o.r, (double)o.material});
+                }
+                uint32_t n = node(NK_MSPHERE, it->second);
+                accel_item(id, o, NK_MSPHERE | (it->second << NK_BITS), n);
                 break;
             }
             case OBJ_RECT: {
@@ -311,6 +323,7 @@ void flatten(rt_scene& s) {
         d.t1 = t.t1;
         d.w = t.w;
         d.h = t.h;
+        if (t.type == TEX_NOISE) texels.resize((texels.size() + 7) & ~size_t(7));  // its f64 gradient vectors are read as doubles
         d.texel_off = (uint32_t)texels.size();
         for (int i = 0; i < 3; i++) d.color[i] = t.color[i];
         texels.insert(texels.end(), t.rgb.begin(), t.rgb.end());
@@ -680,6 +693,8 @@ void flatten(rt_scene& s) {
     v.off_texs = append(f.blob, texs);
     v.off_media = append(f.blob, b.media);
     v.n_media = (uint32_t)b.media.size();
+    v.off_msph = append(f.blob, b.msph);
+    v.n_msph = (uint32_t)(b.msph.size() / 10);
     v.off_lights = append(f.blob, lights);
     v.n_lights = (uint32_t)(lights.size() / 2);
     v.off_vpos = append(f.blob, b.vpos);  // kept for introspection; the kernels read tripre instead

@@ -54,6 +54,40 @@ int add_texture_image(rt_scene& s, int w, int h, const uint8_t* rgb) {
     s.textures.push_back(std::move(t));
     return (int)s.textures.size() - 1;
 }
+// D9 (book 2, no reference code): noise_texture(scale) = marble over Perlin noise.  The tables come from the stream
+// (seed, RT_PERLIN_STREAM_KEY, 0): 256 x unit_vector(random(-1, 1)), then perm_x, perm_y, perm_z (identity permuted from the top with
+// random_int(0, i) = (next_u32 * (i + 1)) >> 32).  Layout of the table blob: 768 f64, then 768 bytes.
+int add_texture_noise(rt_scene& s, double scale, uint64_t seed) {
+    if (!std::isfinite(scale)) throw RtError(RT_ERR_ARG, "noise scale must be finite");
+    TextureRec t;
+    t.type = TEX_NOISE;
+    t.color[0] = scale;
+    Rng rng;
+    rng.seed_stream(seed, RT_PERLIN_STREAM_KEY, 0);
+    std::vector<double> vec(768);
+    for (int i = 0; i < 256; i++) {
+        const double x = rng.gen_range(-1., 1.), y = rng.gen_range(-1., 1.), z = rng.gen_range(-1., 1.);
+        const double len = std::sqrt(x * x + y * y + z * z);  // Vec3::unit, vec3.rs:85-90
+        if (len == 0.) throw RtError(RT_ERR_UNIT_ZERO, "unitizing zero vector (noise table)");
+        vec[3 * i] = x / len;
+        vec[3 * i + 1] = y / len;
+        vec[3 * i + 2] = z / len;
+    }
+    std::vector<uint8_t> perm(768);
+    for (int a = 0; a < 3; a++) {
+        uint8_t* p = perm.data() + 256 * a;
+        for (int i = 0; i < 256; i++) p[i] = (uint8_t)i;
+        for (int i = 255; i > 0; i--) {
+            const int target = (int)(((uint64_t)rng.next_u32() * (uint64_t)(i + 1)) >> 32);
+            std::swap(p[i], p[target]);
+        }
+    }
+    t.rgb.resize(768 * sizeof(double) + 768);
+    std::memcpy(t.rgb.data(), vec.data(), 768 * sizeof(double));
+    std::memcpy(t.rgb.data() + 768 * sizeof(double), perm.data(), 768);
+    s.textures.push_back(std::move(t));
+    return (int)s.textures.size() - 1;
+}
 int add_material(rt_scene& s, int type, int tex, double param) {
     check_tex(s, tex);
     MaterialRec m;
@@ -89,6 +123,27 @@ int add_sphere(rt_scene& s, const double c[3], double r, int mat) {
     for (int i = 0; i < 3; i++) {
         o.box.mn[i] = c[i] - r;
         o.box.mx[i] = c[i] + r;
+    }
+    return push(s, std::move(o));
+}
+// D9 (book 2, no reference code): moving_sphere -- the centre moves linearly from c0 at time0 to c1 at time1; box = the union of the boxes at both ends
+int add_moving_sphere(rt_scene& s, const double c0[3], const double c1[3], double time0, double time1, double r, int mat) {
+    check_mat(s, mat);
+    require_finite(c0, 3, "sphere center");
+    require_finite(c1, 3, "sphere center");
+    require_finite(&r, 1, "sphere radius");
+    if (!std::isfinite(time0) || !std::isfinite(time1) || !(time1 > time0)) throw RtError(RT_ERR_ARG, "a moving sphere needs time1 > time0");
+    ObjectRec o;
+    o.type = OBJ_MOVING_SPHERE;
+    o.material = mat;
+    for (int i = 0; i < 3; i++) { o.c[i] = c0[i]; o.c1[i] = c1[i]; }
+    o.time0 = time0;
+    o.time1 = time1;
+    o.r = r;
+    o.has_box = true;
+    for (int i = 0; i < 3; i++) {
+        o.box.mn[i] = std::fmin(c0[i] - r, c1[i] - r);
+        o.box.mx[i] = std::fmax(c0[i] + r, c1[i] + r);
     }
     return push(s, std::move(o));
 }

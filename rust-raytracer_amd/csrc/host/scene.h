@@ -24,13 +24,13 @@ struct Box {  // objects/aabb.rs:6-9
     double mn[3], mx[3];
 };
 
-enum TexType { TEX_CONSTANT = 0, TEX_CHECKER = 1, TEX_IMAGE = 2 };
+enum TexType { TEX_CONSTANT = 0, TEX_CHECKER = 1, TEX_IMAGE = 2, TEX_NOISE = 3 };
 struct TextureRec {
     int type = TEX_CONSTANT;
-    double color[3] = {0, 0, 0};
+    double color[3] = {0, 0, 0};  // TEX_NOISE: color[0] = scale
     int t0 = -1, t1 = -1;
     int w = 0, h = 0;
-    std::vector<uint8_t> rgb;
+    std::vector<uint8_t> rgb;     // TEX_NOISE: the Perlin tables, 256 x 3 f64 unit vectors then 3 x 256 bytes of permutations (6 912 bytes)
 };
 enum MatType { MAT_LAMBERTIAN = 0, MAT_METAL = 1, MAT_DIELECTRIC = 2, MAT_DIFFUSE_LIGHT = 3, MAT_ISOTROPIC = 4 };
 struct MaterialRec {
@@ -39,14 +39,15 @@ struct MaterialRec {
     double param = 0;
 };
 
-enum ObjType { OBJ_SPHERE, OBJ_RECT, OBJ_CUBE, OBJ_TRIANGLE, OBJ_MESH, OBJ_TRANSFORM, OBJ_LIST, OBJ_BVH, OBJ_MEDIUM };
+enum ObjType { OBJ_SPHERE, OBJ_RECT, OBJ_CUBE, OBJ_TRIANGLE, OBJ_MESH, OBJ_TRANSFORM, OBJ_LIST, OBJ_BVH, OBJ_MEDIUM, OBJ_MOVING_SPHERE };
 struct MeshData {
     std::vector<double> pos, nrm;  // 3 per vertex
 };
 struct ObjectRec {
     int type = OBJ_SPHERE;
     int material = -1;
-    double c[3] = {0, 0, 0}, r = 0;             // sphere
+    double c[3] = {0, 0, 0}, r = 0;             // sphere; moving sphere: center0
+    double c1[3] = {0, 0, 0}, time0 = 0, time1 = 0;  // moving sphere (D9): center1, the times the centre is at center0 / center1
     int axis = 0;                               // rect: constant axis (0 YZ, 1 XZ, 2 XY)
     double a0 = 0, b0 = 0, a1 = 0, b1 = 0, k = 0;
     std::vector<int> children;                  // cube: 6 rects; list: items; bvh: {left,right}; mesh: {bvh}; transform: {obj}; medium: {boundary}
@@ -104,6 +105,8 @@ int add_texture_checker(rt_scene& s, int t0, int t1);
 int add_texture_image(rt_scene& s, int w, int h, const uint8_t* rgb);
 int add_material(rt_scene& s, int type, int tex, double param);
 int add_sphere(rt_scene& s, const double c[3], double r, int mat);
+int add_moving_sphere(rt_scene& s, const double c0[3], const double c1[3], double time0, double time1, double r, int mat);
+int add_texture_noise(rt_scene& s, double scale, uint64_t seed);
 int add_rect(rt_scene& s, int axis, double a0, double b0, double a1, double b1, double k, int mat);
 int add_cube(rt_scene& s, const double mn[3], const double mx[3], int mat);
 int add_mesh(rt_scene& s, int n_vert, const double* pos, const double* nrm, int n_tri, const uint32_t* idx, int mat,

@@ -43,7 +43,7 @@ class rt_camera_frame(C.Structure):
 class rt_params(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("spp", C.c_int32), ("max_depth", C.c_int32), ("t_min", C.c_double),
                 ("seed", C.c_uint64), ("rank", C.c_int32), ("world", C.c_int32), ("spp_chunk", C.c_int32), ("kernel", C.c_int32),
-                ("device", C.c_int32), ("integrator", C.c_int32)]
+                ("device", C.c_int32), ("integrator", C.c_int32), ("time0", C.c_double), ("time1", C.c_double)]
 
 
 class rt_stats(C.Structure):
@@ -72,7 +72,7 @@ class rt_object_desc(C.Structure):
     _fields_ = [("type", C.c_int32), ("material", C.c_int32), ("n_children", C.c_int32), ("axis", C.c_int32), ("v", C.c_double * 8)]
 
 
-OBJECT_TYPES = ("Sphere", "Rect", "Cube", "Triangle", "Mesh", "Transform", "HitableList", "BVHNode", "ConstantMedium")
+OBJECT_TYPES = ("Sphere", "Rect", "Cube", "Triangle", "Mesh", "Transform", "HitableList", "BVHNode", "ConstantMedium", "MovingSphere")
 
 
 class rt_scene_info(C.Structure):
@@ -102,6 +102,7 @@ _SIGS = [
     ("rt_texture_constant", C.c_int, [C.c_void_p, _d3]),
     ("rt_texture_checker", C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     ("rt_texture_image", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_uint8)]),
+    ("rt_texture_noise", C.c_int, [C.c_void_p, C.c_double, C.c_uint64]),
     ("rt_material_lambertian", C.c_int, [C.c_void_p, C.c_int]),
     ("rt_material_metal", C.c_int, [C.c_void_p, C.c_int, C.c_double]),
     ("rt_material_dielectric", C.c_int, [C.c_void_p, C.c_double, C.c_int]),
@@ -109,6 +110,7 @@ _SIGS = [
     ("rt_material_isotropic", C.c_int, [C.c_void_p, C.c_int]),
     ("rt_object_constant_medium", C.c_int, [C.c_void_p, C.c_double, C.c_int, C.c_int]),
     ("rt_object_sphere", C.c_int, [C.c_void_p, _d3, C.c_double, C.c_int]),
+    ("rt_object_moving_sphere", C.c_int, [C.c_void_p, _d3, _d3, C.c_double, C.c_double, C.c_double, C.c_int]),
     ("rt_object_rect_xy", C.c_int, [C.c_void_p] + [C.c_double] * 5 + [C.c_int]),
     ("rt_object_rect_xz", C.c_int, [C.c_void_p] + [C.c_double] * 5 + [C.c_int]),
     ("rt_object_rect_yz", C.c_int, [C.c_void_p] + [C.c_double] * 5 + [C.c_int]),
@@ -291,6 +293,10 @@ class World:
         a = np.ascontiguousarray(rgb_u8, dtype=np.uint8)
         return _chk(self.L.rt_texture_image(self.h, a.shape[1], a.shape[0], a.ctypes.data_as(C.POINTER(C.c_uint8))))
 
+    def NoiseTexture(self, scale, seed=1):
+        """book-2 extension (no reference code): Perlin marble texture 0.5 (1 + sin(scale z + 10 turb(p)))"""
+        return _chk(self.L.rt_texture_noise(self.h, float(scale), int(seed)))
+
     # --- materials (material.rs:88-212) ---
     def Lambertian(self, albedo):
         return _chk(self.L.rt_material_lambertian(self.h, albedo))
@@ -310,6 +316,10 @@ class World:
     # --- hitables (objects/*.rs, light.rs) ---
     def Sphere(self, center, radius, material):
         return _chk(self.L.rt_object_sphere(self.h, _arr3(center), float(radius), material))
+
+    def MovingSphere(self, center0, center1, time0, time1, radius, material):
+        """book-2 extension (no reference code): a sphere whose centre moves linearly from center0 at time0 to center1 at time1"""
+        return _chk(self.L.rt_object_moving_sphere(self.h, _arr3(center0), _arr3(center1), float(time0), float(time1), float(radius), material))
 
     def XYRectangle(self, xy0, xy1, z, material):
         return _chk(self.L.rt_object_rect_xy(self.h, float(xy0[0]), float(xy0[1]), float(xy1[0]), float(xy1[1]), float(z), material))
@@ -424,23 +434,23 @@ class World:
 
     # --- the hot path ---
     def render(self, camera, width=800, height=800, spp=256, max_depth=50, t_min=1e-3, seed=1, rank=0, world=1, spp_chunk=0,
-               kernel=0, device=-1, integrator=0):
-        """rt_render: linear radiance f64 [H,W,3] on the host + stats dict."""
+               kernel=0, device=-1, integrator=0, shutter=(0.0, 0.0)):
+        """rt_render: linear radiance f64 [H,W,3] on the host + stats dict.  shutter = (time0, time1): the book-2 camera shutter."""
         p = default_params(width=width, height=height, spp=spp, max_depth=max_depth, t_min=t_min, seed=seed, rank=rank, world=world,
-                           spp_chunk=spp_chunk, kernel=kernel, device=device, integrator=integrator)
+                           spp_chunk=spp_chunk, kernel=kernel, device=device, integrator=integrator, time0=float(shutter[0]), time1=float(shutter[1]))
         out = np.zeros((height, width, 3), dtype=np.float64)
         st = rt_stats()
         _chk(self.L.rt_render(self.h, C.byref(camera.c), C.byref(p), out.ctypes.data_as(_dp), C.byref(st)))
         return out, st.as_dict()
 
     def render_multi(self, camera, devices=None, gpus=0, width=800, height=800, spp=256, max_depth=50, t_min=1e-3, seed=1, spp_chunk=0,
-                     kernel=0, integrator=0):
+                     kernel=0, integrator=0, shutter=(0.0, 0.0)):
         """rt_render_multi: the frame across the GPUs of this node in ONE call (one host thread per rank inside the library, rows
         gathered on devices[0] through RCCL).  devices = HIP ordinals, one per rank (may repeat); or gpus = N for devices 0..N-1
         (0 = all visible).  Returns (radiance [H,W,3], [per-rank stats dicts]); stats[0] also carries 'exchange_seconds' and
         'rows_through_rccl'."""
         p = default_params(width=width, height=height, spp=spp, max_depth=max_depth, t_min=t_min, seed=seed, spp_chunk=spp_chunk,
-                           kernel=kernel, integrator=integrator)
+                           kernel=kernel, integrator=integrator, time0=float(shutter[0]), time1=float(shutter[1]))
         n = len(devices) if devices is not None else int(gpus)
         ids = (C.c_int * n)(*[int(d) for d in devices]) if devices is not None else None
         n_st = n if n > 0 else max(1, device_count())

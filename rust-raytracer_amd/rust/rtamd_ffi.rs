@@ -88,6 +88,8 @@ pub struct rt_params {
     pub kernel: i32,
     pub device: i32,
     pub integrator: i32,
+    pub time0: c_double,
+    pub time1: c_double,
 }
 
 #[repr(C)]
@@ -196,12 +198,14 @@ extern "C" {
     pub fn rt_texture_constant(s: *mut rt_scene, color: *const c_double) -> c_int;
     pub fn rt_texture_checker(s: *mut rt_scene, t0: c_int, t1: c_int) -> c_int;
     pub fn rt_texture_image(s: *mut rt_scene, width: c_int, height: c_int, rgb: *const u8) -> c_int;
+    pub fn rt_texture_noise(s: *mut rt_scene, scale: c_double, seed: u64) -> c_int;
     pub fn rt_material_lambertian(s: *mut rt_scene, albedo_tex: c_int) -> c_int;
     pub fn rt_material_metal(s: *mut rt_scene, albedo_tex: c_int, fuzz: c_double) -> c_int;
     pub fn rt_material_dielectric(s: *mut rt_scene, ir: c_double, albedo_tex: c_int) -> c_int;
     pub fn rt_material_diffuse_light(s: *mut rt_scene, emit_tex: c_int) -> c_int;
     pub fn rt_material_isotropic(s: *mut rt_scene, albedo_tex: c_int) -> c_int;
     pub fn rt_object_sphere(s: *mut rt_scene, center: *const c_double, radius: c_double, material: c_int) -> c_int;
+    pub fn rt_object_moving_sphere(s: *mut rt_scene, center0: *const c_double, center1: *const c_double, time0: c_double, time1: c_double, radius: c_double, material: c_int) -> c_int;
     pub fn rt_object_rect_xy(s: *mut rt_scene, x0: c_double, y0: c_double, x1: c_double, y1: c_double, z: c_double, material: c_int) -> c_int;
     pub fn rt_object_rect_xz(s: *mut rt_scene, x0: c_double, z0: c_double, x1: c_double, z1: c_double, y: c_double, material: c_int) -> c_int;
     pub fn rt_object_rect_yz(s: *mut rt_scene, y0: c_double, z0: c_double, y1: c_double, z1: c_double, x: c_double, material: c_int) -> c_int;
