@@ -31,6 +31,7 @@
 
 #include "../common/flat.h"
 #include "../common/detlog.h"
+#include "../common/detsin.h"
 #include "../common/rng.h"
 #include "../common/schedule.h"
 #include "device.h"
@@ -196,6 +197,8 @@ struct Acc {  // typed views into the blob (LDS or global; the address space is 
     const uint2* lights;     // {NK_SPHERE | NK_RECT_XZ, payload}
     uint32_t n_lights;
     const MediumDev* media;  // always global
+    const double* msph;      // moving spheres (D9), always global: 10 f64 each
+    uint32_t time_lds;       // LDS byte address of the per-lane ray times (D9; 0: the scene has no moving sphere, every time is 0)
     // kernel 5's serving waves: compact object-space data (flat.h "Compact instance data")
     const uint4* n2q;        // 2 x uint4 per NodeQ
     const uint4* n2q_top;    // LDS copy of the first n2q_top_count NodeQ
@@ -232,6 +235,8 @@ DEV Acc make_acc(P hot, const char* gbase, const FlatView& v) {  // hot: LDS cop
     a.lights = (const uint2*)(gbase + v.off_lights);
     a.n_lights = v.n_lights;
     a.media = (const MediumDev*)(gbase + v.off_media);
+    a.msph = (const double*)(gbase + v.off_msph);
+    a.time_lds = 0u;
     return a;
 }
 
@@ -258,6 +263,8 @@ struct RenderK {
     int n_topq;              // kernel 5: number of NodeQ cached in LDS for the serving waves
     int coop_pool;           // kernel 5: parked-path slots in use (<= COOP_POOL)
     int coop_stack;          // kernel 5: stack entries per lane
+    double time0, time1;     // D9: the camera's shutter; time1 > time0: every sample draws its time after the lens sample
+    int time_slots;          // D9: 1 = the scene has moving spheres: 8 bytes of LDS per lane (behind the launch constants) hold the paths' times
 };
 
 // ------------------------------------------------------ intersection ------
@@ -318,6 +325,61 @@ DEV bool rect_hit(const double2* r, int axis, D3 o, D3 d, double t_min, double t
     t_out = t;
     return true;
 }
+// D9 (book-2 extension, no reference code).  A path's time lives in LDS (one f64 per lane, written when the path is generated) so that
+// the one primitive that reads it costs the others no register; the scene's kinds_mask says whether the slots exist.
+DEV double ray_time(const Acc& A) { return A.time_lds ? *(const AS_L double*)(uintptr_t)(A.time_lds + 8u * threadIdx.x) : 0.; }
+// moving_sphere::center(time) = center0 + ((time - time0) / (time1 - time0)) (center1 - center0)
+DEV D3 msphere_center(const double* q, double time) {
+    const D3 c0 = mk(q[0], q[1], q[2]), c1 = mk(q[3], q[4], q[5]);
+    return add(c0, muls(sub(c1, c0), (time - q[6]) / (q[7] - q[6])));
+}
+// moving_sphere::hit = Sphere::hit (sphere.rs:24-43) around center(r.time); out of line: rare, and the sphere test's twin in the loops
+__device__ __attribute__((noinline)) bool msphere_hit(const double* q, double time, double ox, double oy, double oz, double dx, double dy, double dz, double a,
+                                                       double t_min, double t_max, double* t_out) {
+    const D3 c = msphere_center(q, time), o = mk(ox, oy, oz), d = mk(dx, dy, dz);
+    const D3 oc = sub(o, c);
+    const double radius = q[8];
+    const double half_b = dot(oc, d);
+    const double cc = sqlen(oc) - radius * radius;
+    const double disc = half_b * half_b - a * cc;
+    if (disc < 0.) return false;
+    const double sq = sqrt(disc);
+    double root = (-half_b - sq) / a;
+    if (!(root >= t_min && root <= t_max)) root = (-half_b + sq) / a;
+    if (!(root >= t_min && root <= t_max)) return false;
+    *t_out = root;
+    return true;
+}
+// perlin::noise / turb and noise_texture::value of the book over the texture's tables (768 f64 gradient vectors, 768 permutation bytes)
+__device__ __attribute__((noinline)) double noise_marble(const uint8_t* tab, double scale, double px, double py, double pz) {
+    const double* ranvec = (const double*)tab;
+    const uint8_t* perm = tab + 768 * sizeof(double);
+    double accum_t = 0., weight = 1.;
+    double x = px, y = py, z = pz;
+    for (int oct = 0; oct < 7; oct++) {
+        const double fx = floor(x), fy = floor(y), fz = floor(z);
+        const double u = x - fx, v = y - fy, w = z - fz;
+        const int i = (int)fx, j = (int)fy, k = (int)fz;
+        const double uu = u * u * (3. - 2. * u), vv = v * v * (3. - 2. * v), ww = w * w * (3. - 2. * w);
+        double accum = 0.;
+        for (int di = 0; di < 2; di++)
+            for (int dj = 0; dj < 2; dj++)
+                for (int dk = 0; dk < 2; dk++) {
+                    const int h = perm[(i + di) & 255] ^ perm[256 + ((j + dj) & 255)] ^ perm[512 + ((k + dk) & 255)];
+                    const double cx = ranvec[3 * h], cy = ranvec[3 * h + 1], cz = ranvec[3 * h + 2];
+                    const double wx = u - di, wy = v - dj, wz = w - dk;
+                    accum += (di * uu + (1 - di) * (1. - uu)) * (dj * vv + (1 - dj) * (1. - vv)) * (dk * ww + (1 - dk) * (1. - ww)) * (cx * wx + cy * wy + cz * wz);
+                }
+        accum_t += weight * accum;
+        weight *= 0.5;
+        x = x * 2.;
+        y = y * 2.;
+        z = z * 2.;
+    }
+    const double turb = fabs(accum_t);
+    return 0.5 * (1. + det_sin(scale * pz + 10. * turb));
+}
+
 // Cube::hit = self.sides.hit(r, t_min, t_max) (cube.rs:64-66): the list scan of hit.rs:56-67 over the six rectangles of Cube::new
 // (cube.rs:17-54) in their order -- XY z=min.z, XY z=max.z, XZ y=min.y, XZ y=max.y, YZ x=min.x, YZ x=max.x -- each one rectangle.rs's
 // test (:20-25, :58-63, :95-100: t = (k - o) / d; reject t < t_min || t > closest_so_far; then the two bounds) with the closest hit so
@@ -488,6 +550,14 @@ DEV Hit traverse(const Acc& A, D3 wo, D3 wd, double t_min, double t_max, Rng* rn
                     h.node = (int)n;
                     h.xf = cur_xf;
                     h.kp = m.x + (side << NK_BITS);
+                }
+            } else if (kind == NK_MSPHERE) {
+                double t;
+                if (msphere_hit(A.msph + 10 * pl, ray_time(A), o.x, o.y, o.z, d.x, d.y, d.z, a, t_min, h.t, &t)) {
+                    h.t = t;
+                    h.node = (int)n;
+                    h.xf = cur_xf;
+                    h.kp = m.x;
                 }
             } else if (kind == NK_TRI) {
                 double t, b1, b2;
@@ -799,6 +869,8 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
                 } else if (GENERAL) {
                     if (kind == NK_RECT_YZ || kind == NK_RECT_XZ || kind == NK_RECT_XY) {
                         got = rect_hit(A.rects + 3 * pl, (int)kind - (int)NK_RECT_YZ, o, d, t_min, t_far, t);
+                    } else if (kind == NK_MSPHERE) {
+                        got = msphere_hit(A.msph + 10 * pl, ray_time(A), o.x, o.y, o.z, d.x, d.y, d.z, a, t_min, t_far, &t);
                     } else if (kind == NK_CUBE) {
                         PH_EV(12);
                         got = cube_hit(A.rects + 3 * (pl >> 3), o, d, t_min, t_far, t, cube_side);
@@ -1048,6 +1120,10 @@ DEV D3 tex_color(const Acc& A, int tex, const Rec& rec) {  // material.rs:52-84
         type = 0;
     }
     if (type == 0) return mk(t->color[0], t->color[1], t->color[2]);
+    if (type == 3) {  // D9: noise_texture::value = color(1, 1, 1) * 0.5 * (1 + sin(scale p.z + 10 turb(p)))
+        const double m = noise_marble(A.texels + t->texel_off, t->color[0], rec.p.x, rec.p.y, rec.p.z);
+        return mk(1. * m, 1. * m, 1. * m);
+    }
     // ImageTexture: nearest texel, v flipped; x == w at u == 1 is clamped (Q11)
     double u = fmin(fmax(rec.u, 0.), 1.), v = 1. - fmin(fmax(rec.v, 0.), 1.);
     int x = (int)floor((double)t->w * u), y = (int)floor((double)t->h * v);
@@ -1086,6 +1162,13 @@ DEV Rec materialize(const Acc& A, const Hit& h, D3 wo, D3 wd, int* err) {
         outward = divs(sub(p, mk(c0.x, c0.y, c1.x)), c1.y);
         want_uv = A.texs[A.mats[rec.mat].tex].type == 2;
         if (want_uv) sphere_uv(outward, rec.u, rec.v);  // get_uv, sphere.rs:16-20 (only an ImageTexture reads it)
+    } else if (GENERAL && kind == NK_MSPHERE) {  // D9: outward_normal = (p - center(r.time)) / radius, get_uv as a sphere
+        const double* q = A.msph + 10 * pl;
+        rec.mat = (int)q[9];
+        D3 p = add(o, muls(d, h.t));
+        outward = divs(sub(p, msphere_center(q, ray_time(A))), q[8]);
+        want_uv = A.texs[A.mats[rec.mat].tex].type == 2;
+        if (want_uv) sphere_uv(outward, rec.u, rec.v);
     } else if (GENERAL && kind == NK_MEDIUM_END) {  // ConstantMedium: arbitrary normal (1,0,0), uv (0,0), phase function (medium.rs:43-49)
         rec.mat = A.media[pl].mat;
         outward = mk(1., 0., 0.);
@@ -1779,6 +1862,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
 #pragma unroll
         for (int i = 0; i < 25; i++) cfg[CFG_LVL + i] = rk.lvl[i / 5][i % 5];
     }
+    if (GENERAL && rk.time_slots) A.time_lds = (uint32_t)(uintptr_t)(AS_L char*)(cfg + CFG_WORDS);  // (8-aligned: every section before it is)
     __syncthreads();
     double* wring = ring + ((size_t)blockIdx.x * (PT_BLOCK / 64) + (size_t)wave) * RING_UNITS * UNIT_DOUBLES;
 
@@ -1860,6 +1944,12 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
                         double v = ((double)y + rng.gen_f64()) / (double)(rk.height - 1);
                         double st = 1.0 - v;
                         D3 rd = muls(random_in_unit_disk(rng), cam.lens_radius);  // drawn even for aperture 0 (Q4)
+                        if (GENERAL && rk.time1 > rk.time0) {  // D9: ray(origin + offset, .., random_double(time0, time1)), after the lens sample
+                            const double tm = rng.gen_range(rk.time0, rk.time1);
+                            if (A.time_lds) *(AS_L double*)(uintptr_t)(A.time_lds + 8u * threadIdx.x) = tm;
+                        } else if (GENERAL && A.time_lds) {
+                            *(AS_L double*)(uintptr_t)(A.time_lds + 8u * threadIdx.x) = rk.time0;
+                        }
                         D3 offset = add(muls(cam.u, rd.x), muls(cam.v, rd.y));
                         o = add(cam.origin, offset);
                         d = sub(sub(add(add(cam.llc, muls(cam.horizontal, u)), muls(cam.vertical, st)), cam.origin), offset);
@@ -2166,6 +2256,8 @@ DEV void blas_pass(const Acc& A, bool act, uint32_t* stk, const int stride, D3 o
                 got = rect_hit(A.rects + 3 * pl, (int)kind - (int)NK_RECT_YZ, o, d, t_min, ht, t);
             } else if (kind == NK_CUBE) {
                 got = cube_hit(A.rects + 3 * (pl >> 3), o, d, t_min, ht, t, cube_side);
+            } else if (kind == NK_MSPHERE) {
+                got = msphere_hit(A.msph + 10 * pl, ray_time(A), o.x, o.y, o.z, d.x, d.y, d.z, a, t_min, ht, &t);
             } else if (kind == NK_TRI) {
                 double b1, b2;
                 got = tri_hit(A.tripre2 + 5 * (first + i), o, d, t_min, ht, t, b1, b2);
@@ -2668,6 +2760,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
                     double v = ((double)y + rng.gen_f64()) / (double)(rk.height - 1);
                     double stt = 1.0 - v;
                     D3 rd = muls(random_in_unit_disk(rng), cam.lens_radius);
+                    if (rk.time1 > rk.time0) (void)rng.gen_range(rk.time0, rk.time1);  // D9: the sample's time (nothing here moves: scenes with moving spheres take kernel 2)
                     D3 offset = add(muls(cam.u, rd.x), muls(cam.v, rd.y));
                     o = add(cam.origin, offset);
                     d = sub(sub(add(add(cam.llc, muls(cam.horizontal, u)), muls(cam.vertical, stt)), cam.origin), offset);
@@ -2989,7 +3082,7 @@ __global__ void rng_floats_kernel(uint64_t seed, uint64_t pixel, uint64_t sample
 __global__ void math_kernel(int op, size_t n, const double* a, const double* b, double* out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    out[i] = (op == 0) ? sqrt(a[i]) : (op == 2) ? det_ln(a[i]) : a[i] / b[i];
+    out[i] = (op == 0) ? sqrt(a[i]) : (op == 2) ? det_ln(a[i]) : (op == 3) ? det_sin(a[i]) : a[i] / b[i];
 }
 __global__ void hit_kernel(FlatView sv, int accel, size_t n, const double* rays, double t_min, double t_max, double* out, int* err) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -3243,8 +3336,10 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
 
     FlatView view = s.flat.view;
     view.base = device_blob(s, dev);
-    const bool general = (view.kinds_mask & ~((1u << NK_BOX) | (1u << NK_SPHERE))) != 0;
-    const size_t lds_max = di.lds_max;
+    // (an open shutter makes every sample draw a time: that lives in the GENERAL variants only, the sphere-only ones stay as they are)
+    const bool general = (view.kinds_mask & ~((1u << NK_BOX) | (1u << NK_SPHERE))) != 0 || plan.time1 > plan.time0;
+    const bool moving = (view.kinds_mask & (1u << NK_MSPHERE)) != 0;  // D9: the paths' times live in LDS, 8 bytes per lane
+    const size_t lds_max = di.lds_max - (moving ? (size_t)PT_BLOCK * sizeof(double) : 0);
     // The accel kernels need the camera inside the region the f32 boxes were padded for (flatten.cpp: origin_limit2) and
     // t_min >= 0 (box32's proof); otherwise kernel 1 (reference order) renders.
     double cam_abs = std::fmax(std::fmax(std::fabs(cam.origin[0]), std::fabs(cam.origin[1])), std::fabs(cam.origin[2])) + std::fabs(cam.lens_radius);
@@ -3259,7 +3354,7 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
     const size_t stack5_bytes = (size_t)stack5 * PT_BLOCK * sizeof(uint32_t);
     const size_t coop_world = coop_world_bytes(view);  // world-level tables, always in LDS for this kernel
     const size_t coop_lds = (size_t)3 * COOP_RING * sizeof(uint16_t) + 8 * sizeof(uint32_t) + ((sizeof(CoopArgs) + 15) & ~size_t(15)) + coop_world;  // + three rings of pool-slot ids, counters, argument block
-    const bool coop_usable = accel2_usable && general && !media && view.coop_data_ok != 0 && view.n_inst2 >= 1 && view.n_inst2 <= (uint32_t)COOP_MAX_INST &&
+    const bool coop_usable = accel2_usable && general && !media && !moving && view.coop_data_ok != 0 && view.n_inst2 >= 1 && view.n_inst2 <= (uint32_t)COOP_MAX_INST &&
                              view.inst_depth2 <= (uint32_t)COOP_STACK_MAX && coop_world <= 32768 && stack5_bytes + coop_lds <= lds_max && plan.max_depth < (1 << 24);
     // kernel 6 = the same instance service across the whole GPU and across launches (wavefront.inc)
     const uint32_t stack6 = std::max<uint32_t>(std::max(view.world_depth2 + 2u, view.stack2_inline), (uint32_t)WF_ENTRY_STACK + 1u);
@@ -3269,7 +3364,7 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
     const uint32_t stack6w = view.inst_depth2 + 2u;
     const size_t wf_tables_w = coop_a16(view.stage_bytes - view.off_xforms) + coop_a16(8u * view.n_inst2) + coop_a16((uint32_t)sizeof(QGrid) * view.n_inst2);
     const size_t wf_lds_walk_min = wf_tables_w + (size_t)stack6w * WF_WALK_BLOCK * sizeof(uint32_t);
-    const bool wf_usable = accel2_usable && general && !media && view.coop_data_ok != 0 && view.n_inst2 >= 1 && view.n_inst2 <= (uint32_t)WF_MAX_INST &&
+    const bool wf_usable = accel2_usable && general && !media && !moving && view.coop_data_ok != 0 && view.n_inst2 >= 1 && view.n_inst2 <= (uint32_t)WF_MAX_INST &&
                            coop_world <= 32768 && wf_lds_pt <= lds_max && wf_lds_walk_min <= lds_max && plan.max_depth < (1 << 24);
     int kernel = plan.kernel;
     // auto: the cooperative kernel as soon as an instance is more than a handful of triangles (Cornell box + torus instance, 64 spp,
@@ -3299,6 +3394,8 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
     const int integ = plan.integrator;
     if (integ == 1 && view.n_lights == 0) throw RtError(RT_ERR_ARG, "integrator 1 (light importance sampling) needs rt_scene_set_lights");
     if (integ == 2 && !plan.sppm_est) throw RtError(RT_ERR_ARG, "integrator 2 (SPPM) is reached through rt_render_sppm");
+    if (integ == 2 && (moving || plan.time1 > plan.time0))
+        throw RtError(RT_ERR_UNSUPPORTED, "the SPPM integrator has no notion of time: moving spheres / an open shutter render with integrators 0 and 1");
     if (media && integ != 0)
         throw RtError(RT_ERR_UNSUPPORTED, "scenes with a ConstantMedium render with integrator 0 only (the medium's random draw is part of the "
                                           "reference-order walk; light sampling and SPPM have no volume events)");
@@ -3332,7 +3429,7 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
         n_topq = (int)std::min<size_t>(room / sizeof(NodeQ), view.n_nodes2);
         if (tun.n_top >= 0) n_topq = std::min(n_topq, tun.n_top);
     }
-    const size_t smem = (lds ? hot_bytes : (size_t)n_top * sizeof(Node2) + (size_t)n_topq * sizeof(NodeQ)) + stack_bytes;
+    const size_t smem = (lds ? hot_bytes : (size_t)n_top * sizeof(Node2) + (size_t)n_topq * sizeof(NodeQ)) + stack_bytes + (moving ? (size_t)PT_BLOCK * sizeof(double) : 0);
     if (kernel == 5 && COOP_EARLY_FOLD && plan.tiles_owned < (int64_t)2 * di.cus * (PT_BLOCK / 64)) fn_coop = fn_coop_early;  // (one workgroup per CU)
     const void* fptr = (kernel == 5) ? (const void*)fn_coop : (const void*)fn;
     if (smem > 48 * 1024) HIP_CHECK(hipFuncSetAttribute(fptr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -3391,6 +3488,9 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
         rk.n_units = (int)units;
         rk.tiles_x = plan.tiles_x; rk.rank = plan.rank; rk.world = plan.world;
         rk.sppm_est = plan.sppm_est;
+        rk.time0 = plan.time0;
+        rk.time1 = plan.time1;
+        rk.time_slots = moving ? 1 : 0;
         rk.n_top = n_top;
         rk.n_topq = n_topq;
         rk.coop_stack = (int)stack5;
@@ -3608,6 +3708,8 @@ static void render_tiles_wf(const rt_scene& s, const FlatView& view, const Camer
         rk.tiles_x = plan.tiles_x; rk.rank = plan.rank; rk.world = plan.world;
         rk.tiles_owned = (int)std::max<int64_t>(1, plan.tiles_owned);
         rk.sppm_est = plan.sppm_est;
+        rk.time0 = plan.time0;
+        rk.time1 = plan.time1;
         rk.n_top = (int)std::min<uint32_t>(128u, view.world_top2);
         rk.n_topq = (int)n_entry6;
         rk.coop_stack = (int)stack6;

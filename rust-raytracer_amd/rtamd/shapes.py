@@ -65,7 +65,17 @@ CORNELL_CAMERA = dict(look_from=(278.0, 278.0, -800.0), look_at=(278.0, 278.0, 2
                       focus_dist=10.0)
 
 
-def final_scene_reduced(B, n_boxes=20, n_cluster=1000, seed=2):
+def final_scene(B, n_boxes=20, n_cluster=1000, seed=2):
+    """BASELINE config C5 AS NAMED: book 2's final scene with its moving sphere (centre (400,400,200) -> (430,400,200) while the shutter
+    [0, 1) is open: FINAL_SCENE_SHUTTER) and its Perlin marble sphere (noise_texture(0.1)).  The reference has code for neither (ray.rs:3-6
+    has no time; no noise texture): both are book-2 extensions of this build, parity exists against the own restatement only."""
+    return final_scene_reduced(B, n_boxes, n_cluster, seed, full=True)
+
+
+FINAL_SCENE_SHUTTER = (0.0, 1.0)
+
+
+def final_scene_reduced(B, n_boxes=20, n_cluster=1000, seed=2, full=False):
     """BASELINE config C5 ("motion-blur + Perlin-noise volumetric final scene", book 2) reduced to what the reference has code for:
     no motion blur (ray.rs:3-6 has no time: the moving sphere stands still) and no Perlin noise (no noise texture: that sphere gets a
     checker).  Everything else is the book's scene: a ground of n_boxes^2 boxes of random height, a rectangle light, glass and metal
@@ -83,7 +93,10 @@ def final_scene_reduced(B, n_boxes=20, n_cluster=1000, seed=2):
             boxes.append(B.Cube((x0, 0.0, z0), (x0 + w, float(rng.uniform(1.0, 101.0)), z0 + w), ground))
     items.append(B.BVHNode_new(boxes, 11))
     items.append(B.XZRectangle((123.0, 147.0), (423.0, 412.0), 554.0, B.DiffuseLight(B.ConstantTexture((7.0, 7.0, 7.0)))))
-    items.append(B.Sphere((400.0, 400.0, 200.0), 50.0, B.Lambertian(B.ConstantTexture((0.7, 0.3, 0.1)))))          # the "moving" sphere
+    if full:
+        items.append(B.MovingSphere((400.0, 400.0, 200.0), (430.0, 400.0, 200.0), 0.0, 1.0, 50.0, B.Lambertian(B.ConstantTexture((0.7, 0.3, 0.1)))))
+    else:
+        items.append(B.Sphere((400.0, 400.0, 200.0), 50.0, B.Lambertian(B.ConstantTexture((0.7, 0.3, 0.1)))))          # the "moving" sphere
     items.append(B.Sphere((260.0, 150.0, 45.0), 50.0, B.Dielectric(1.5, B.ConstantTexture((1.0, 1.0, 1.0)))))
     items.append(B.Sphere((0.0, 150.0, 145.0), 50.0, B.Metal(B.ConstantTexture((0.8, 0.8, 0.9)), 1.0)))
     glass = B.Dielectric(1.5, B.ConstantTexture((1.0, 1.0, 1.0)))
@@ -93,7 +106,10 @@ def final_scene_reduced(B, n_boxes=20, n_cluster=1000, seed=2):
     yy, xx = np.mgrid[0:64, 0:128]
     earth = np.stack([(40 + 150 * (np.sin(xx / 9.0) * np.cos(yy / 7.0) > 0.2)), 90 + (xx * 3 + yy * 5) % 120, 160 + (yy * 11) % 90], axis=-1).astype(np.uint8)
     items.append(B.Sphere((400.0, 200.0, 400.0), 100.0, B.Lambertian(B.ImageTexture(earth))))
-    items.append(B.Sphere((220.0, 280.0, 300.0), 80.0, B.Lambertian(B.CheckerTexture(B.ConstantTexture((0.2, 0.2, 0.2)), B.ConstantTexture((0.9, 0.9, 0.9))))))  # (Perlin in the book)
+    if full:
+        items.append(B.Sphere((220.0, 280.0, 300.0), 80.0, B.Lambertian(B.NoiseTexture(0.1, 5))))
+    else:
+        items.append(B.Sphere((220.0, 280.0, 300.0), 80.0, B.Lambertian(B.CheckerTexture(B.ConstantTexture((0.2, 0.2, 0.2)), B.ConstantTexture((0.9, 0.9, 0.9))))))  # (Perlin in the book)
     white = B.Lambertian(B.ConstantTexture((0.73, 0.73, 0.73)))
     cluster = [B.Sphere(tuple(float(c) for c in rng.uniform(0.0, 165.0, 3)), 10.0, white) for _ in range(n_cluster)]
     items.append(B.Transform((0.0, 15.0, 0.0), (1.0, 1.0, 1.0), (-100.0, 270.0, 395.0), B.BVHNode_new(cluster, 12)))

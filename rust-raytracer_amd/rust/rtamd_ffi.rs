@@ -326,6 +326,10 @@ impl SceneBuilder {
         assert_eq!(rgb8.len(), (width * height * 3) as usize);
         check(unsafe { rt_texture_image(self.raw, width as c_int, height as c_int, rgb8.as_ptr()) })
     }
+    /// book-2 extension (the reference has no noise texture): Perlin marble, tables from the stream (seed, "perlin" key, 0)
+    pub fn noise_texture(&mut self, scale: f64, seed: u64) -> Result<Id, RtError> {
+        check(unsafe { rt_texture_noise(self.raw, scale, seed) })
+    }
     pub fn lambertian(&mut self, albedo: Id) -> Result<Id, RtError> {
         check(unsafe { rt_material_lambertian(self.raw, albedo) })
     }
@@ -343,6 +347,10 @@ impl SceneBuilder {
     }
     pub fn sphere(&mut self, center: &Vec3, radius: f64, material: Id) -> Result<Id, RtError> {
         check(unsafe { rt_object_sphere(self.raw, v3(center).as_ptr(), radius, material) })
+    }
+    /// book-2 extension (the reference's Ray has no time): a sphere whose centre moves linearly during the shutter
+    pub fn moving_sphere(&mut self, center0: &Vec3, center1: &Vec3, time0: f64, time1: f64, radius: f64, material: Id) -> Result<Id, RtError> {
+        check(unsafe { rt_object_moving_sphere(self.raw, v3(center0).as_ptr(), v3(center1).as_ptr(), time0, time1, radius, material) })
     }
     pub fn rect_xy(&mut self, xy0: (f64, f64), xy1: (f64, f64), z: f64, material: Id) -> Result<Id, RtError> {
         check(unsafe { rt_object_rect_xy(self.raw, xy0.0, xy0.1, xy1.0, xy1.1, z, material) })

@@ -15,7 +15,7 @@ import oracle
 
 for key in (sys.argv[1:] or list(configs.CONFIGS)):
     label, W, H, spp_cfg, spp = configs.CONFIGS[key]
-    w, h = (300, 300) if key == "c4" else (400, 400) if key == "c5r" else (W, H)
+    w, h = (300, 300) if key == "c4" else (400, 400) if key in ("c5r", "c5") else (W, H)
     sc = configs.oracle_scene(key)
     t0 = time.time()
     _, cnt = sc.render(w, h, spp, max_depth=50, seed=1, integrator=configs.INTEGRATOR.get(key, 0))

@@ -79,7 +79,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header_sizes():
     import rtamd
     assert ctypes.sizeof(rtamd.rt_camera) == 13 * 8
-    assert ctypes.sizeof(rtamd.rt_params) == 4 * 4 + 8 + 8 + 6 * 4
+    assert ctypes.sizeof(rtamd.rt_params) == 4 * 4 + 8 + 8 + 6 * 4 + 2 * 8
     assert ctypes.sizeof(rtamd.rt_stats) == 3 * 8 + 8 + 6 * 4 + 8 + 4 * 8
     p = rtamd.default_params()
     assert (p.width, p.height, p.spp, p.max_depth, p.t_min, p.world) == (800, 800, 256, 50, 0.001, 1)   # main.rs:34-45, camera.rs:73

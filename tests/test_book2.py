@@ -1,0 +1,228 @@
+"""The two book-2 ("Ray Tracing: The Next Week") features BASELINE's config C5 names -- motion blur and a Perlin-noise texture.
+The reference has code for NEITHER (its Ray has no time, ray.rs:3-6; there is no noise texture), so both are extensions of this build
+ and parity exists only against the build's own CPU restatement: the oracle restates the book's
+published algorithms independently of the product's device code, the tests below pin
+  * rtamd-sin-1 (the deterministic sine of the marble texture) against libm to 1 ulp and product == oracle bit for bit,
+  * the Perlin tables and noise values (range, continuity, gradient-noise zero at lattice points, turbulence bounds),
+  * moving-sphere hits at the ends and the middle of the shutter, its box, the time draw's place in the RNG stream,
+and the -m gpu tests compare rendered frames of kernels 1 and 2 with the oracle bit for bit (incl. C5 as named at reduced size)."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, scene_path
+
+
+# ---- CPU: the restatement itself -----------------------------------------------------------------------------------------------------
+def test_det_sin_is_within_one_ulp_of_libm_and_odd():
+    import oracle
+    L = oracle.lib()
+    rng = np.random.default_rng(3)
+    xs = np.concatenate([np.linspace(-700.0, 700.0, 50001), rng.uniform(-8e5, 8e5, 50000), [0.0, -0.0, 1e-300, math.pi, 0.5 * math.pi, 1e5]])
+    worst = 0.0
+    for x in xs:
+        x = float(x)
+        got, ref = L.orc_det_sin(x), math.sin(x)
+        worst = max(worst, abs(got - ref) / max(np.spacing(abs(ref)), 1e-300) if ref != 0.0 else abs(got))
+        assert L.orc_det_sin(-x) == -got
+    assert worst <= 1.0 + 1e-9, worst                       # |error| <= 1 ulp of the result
+    assert L.orc_det_sin(1e7) == 0.0 and L.orc_det_sin(float("nan")) == 0.0 and L.orc_det_sin(float("inf")) == 0.0   # outside the range: 0
+
+
+def test_perlin_noise_of_the_oracle_behaves_like_gradient_noise():
+    import oracle
+    o = oracle.Scene()
+    t = o.NoiseTexture(0.1, 5)
+    rng = np.random.default_rng(1)
+    vals = np.array([o.noise_value(t, p) for p in rng.uniform(-50.0, 50.0, (4000, 3))])
+    noise, turb, marble = vals[:, 0], vals[:, 1], vals[:, 2]
+    assert -1.0 < noise.min() < -0.3 and 0.3 < noise.max() < 1.0 and abs(noise.mean()) < 0.03       # gradient noise: zero mean, inside (-1, 1)
+    assert (turb >= 0.0).all() and turb.max() < 2.0 and (marble >= 0.0).all() and (marble <= 1.0).all()
+    for p in [(0.0, 0.0, 0.0), (3.0, -7.0, 12.0), (255.0, 256.0, -1.0)]:                             # a lattice point: every corner weight multiplies a zero offset
+        assert o.noise_value(t, p)[0] == 0.0
+    a, b = o.noise_value(t, (1.25, 2.5, 3.75))[0], o.noise_value(t, (1.25 + 1e-9, 2.5, 3.75))[0]      # continuous
+    assert abs(a - b) < 1e-7
+    assert o.noise_value(t, (1.25, 2.5, 3.75)) == o.noise_value(o.NoiseTexture(0.1, 5), (1.25, 2.5, 3.75))   # the tables are a function of the seed
+    assert o.noise_value(t, (1.25, 2.5, 3.75)) != o.noise_value(o.NoiseTexture(0.1, 6), (1.25, 2.5, 3.75))
+    assert o.noise_value(t, (1.25, 2.5, 3.75))[0] == o.noise_value(t, (1.25 + 256.0, 2.5 - 512.0, 3.75))[0]  # period 256 (the & 255 of the book)
+
+
+def test_moving_sphere_of_the_oracle():
+    import oracle
+    o = oracle.Scene()
+    m = o.Lambertian(o.ConstantTexture((0.5, 0.5, 0.5)))
+    s = o.MovingSphere((0.0, 0.0, 0.0), (4.0, 0.0, 0.0), 0.0, 1.0, 1.0, m)
+    assert np.array_equal(o.bounding_box(s), [-1.0, -1.0, -1.0, 5.0, 1.0, 1.0])      # the union of the boxes at both ends
+    o.set_root(s)
+    # orc_hit traces at time 0 (a Ray's default): the sphere is at center0
+    h = o.hit((0.0, 0.0, -5.0), (0.0, 0.0, 1.0))
+    assert h is not None and h["t"] == 4.0 and np.array_equal(h["normal"], [0.0, 0.0, -1.0])
+    assert o.hit((4.0, 0.0, -5.0), (0.0, 0.0, 1.0)) is None
+    # a render with the shutter open sees it smeared: the column above centre 0 and the one above centre 4 are both partly covered
+    li = o.DiffuseLight(o.ConstantTexture((1.0, 1.0, 1.0)))
+    o2 = oracle.Scene()
+    items = [o2.MovingSphere((0.0, 0.0, 0.0), (4.0, 0.0, 0.0), 0.0, 1.0, 1.0, o2.DiffuseLight(o2.ConstantTexture((1.0, 1.0, 1.0))))]
+    o2.World(items, 1)
+    o2.Camera((2.0, 0.0, -12.0), (2.0, 0.0, 0.0), (0.0, 1.0, 0.0), 40.0, 2.0, 0.0, 12.0)
+    still, _ = o2.render(64, 32, 32, seed=1)
+    o2.set_shutter(0.0, 1.0)
+    blur, _ = o2.render(64, 32, 32, seed=1)
+    row_s, row_b = still[16, :, 0], blur[16, :, 0]
+    assert (row_s > 0).sum() < (row_b > 0).sum()                                    # wider
+    assert row_s.max() == 1.0 and 0.0 < row_b[(row_b > 0)].min() < 0.9               # ... and partly transparent at its ends
+
+
+def test_the_time_draw_follows_the_lens_sample_and_only_an_open_shutter_draws():
+    """the RNG stream of a scene without motion does not change: frames with a closed shutter equal the frames of the rounds before"""
+    import oracle
+    o = oracle.load_scene_file(scene_path("scene_10.json"), aspect=16.0 / 9.0)
+    a, _ = o.render(32, 18, 4, seed=1)
+    o.set_shutter(0.5, 0.5)                                                          # closed: time1 == time0
+    b, _ = o.render(32, 18, 4, seed=1)
+    assert np.array_equal(a, b)
+    o.set_shutter(0.0, 1.0)                                                          # open: one more draw per sample shifts every later draw
+    c, _ = o.render(32, 18, 4, seed=1)
+    assert not np.array_equal(a, c)
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "scene_10_64x36_16spp_seed1.npy"))
+    o.set_shutter(0.0, 0.0)
+    g, _ = o.render(64, 36, 16, seed=1)
+    assert np.array_equal(g, gold)
+
+
+def test_product_tables_equal_the_oracles():
+    """the host builder fills a noise texture's tables from the same stream: spot-checked through the committed blob's texture count and,
+    on a GPU, through the rendered marble (below); here: the builder accepts / rejects what it should"""
+    import rtamd
+    w = rtamd.World()
+    t = w.NoiseTexture(0.1, 5)
+    m = w.Lambertian(t)
+    s = w.MovingSphere((0.0, 0.0, 0.0), (4.0, 0.0, 0.0), 0.0, 1.0, 1.0, m)
+    assert np.array_equal(w.bounding_box(s), [-1.0, -1.0, -1.0, 5.0, 1.0, 1.0])
+    kind, d = w.describe(s)
+    assert kind == "MovingSphere" and d["v"][:7] == [0.0, 0.0, 0.0, 1.0, 4.0, 0.0, 0.0] and d["material"] == m
+    with pytest.raises(rtamd.RtError):
+        w.MovingSphere((0.0, 0.0, 0.0), (4.0, 0.0, 0.0), 1.0, 1.0, 1.0, m)           # time1 must be > time0
+    with pytest.raises(rtamd.RtError):
+        w.NoiseTexture(float("nan"))
+    w.set_root(w.HitableList([s]))
+    assert w.info()["n_textures"] == 1
+    with pytest.raises(rtamd.RtError):
+        rtamd.default_params(time0=1.0, time1=0.5) and w.render(rtamd.Camera(((0, 0, -5), (0, 0, 0)), (0, 1, 0), 40, 1, 0, 5), width=8, height=8, spp=1, shutter=(1.0, 0.5))
+
+
+# ---- GPU: product == oracle ----------------------------------------------------------------------------------------------------------
+def _scene(B):
+    white = B.Lambertian(B.ConstantTexture((0.73, 0.73, 0.73)))
+    marble = B.Lambertian(B.NoiseTexture(4.0, 11))
+    glass = B.Dielectric(1.5, B.ConstantTexture((1.0, 1.0, 1.0)))
+    return [
+        B.XZRectangle((-20.0, -20.0), (20.0, 20.0), 0.0, marble),                                   # a marble floor
+        B.Sphere((0.0, 1.0, 0.0), 1.0, marble),
+        B.MovingSphere((-3.0, 0.7, -1.0), (-1.5, 1.4, -1.0), 0.0, 1.0, 0.7, B.Lambertian(B.ConstantTexture((0.7, 0.3, 0.1)))),
+        B.MovingSphere((2.0, 0.5, -2.0), (2.0, 2.5, -2.0), 0.25, 0.75, 0.5, glass),                 # moves during the middle half of the shutter (extrapolated outside)
+        B.Transform((0.0, 25.0, 0.0), (1.0, 1.5, 1.0), (3.0, 1.0, 1.5), B.MovingSphere((0.0, 0.0, 0.0), (0.0, 0.0, 1.0), 0.0, 1.0, 0.6, B.Metal(B.ConstantTexture((0.8, 0.8, 0.9)), 0.05))),
+        B.Cube((-4.0, 0.0, 1.0), (-2.5, 1.5, 2.5), white),
+        B.XZRectangle((-3.0, -3.0), (3.0, 3.0), 7.0, B.DiffuseLight(B.ConstantTexture((5.0, 5.0, 5.0)))),
+        B.Sphere((0.0, 0.0, 0.0), 60.0, B.DiffuseLight(B.ConstantTexture((0.15, 0.18, 0.25)))),     # a dim sky
+    ]
+
+
+def _pair():
+    import oracle
+    import rtamd
+    w = rtamd.World()
+    w.new(_scene(w), bvh_seed=4)
+    o = oracle.Scene()
+    o.World(_scene(o), 4)
+    cam = ((0.0, 3.0, -9.0), (0.0, 1.0, 0.0), (0.0, 1.0, 0.0), 40.0, 4.0 / 3.0, 0.1, 9.0)
+    o.Camera(*cam)
+    f, t, up, vfov, asp, ap, fd = cam
+    return w, rtamd.Camera((f, t), up, vfov, asp, ap, fd), o
+
+
+@pytest.mark.gpu
+def test_device_det_sin_equals_the_oracles():
+    import oracle
+    import rtamd
+    rng = np.random.default_rng(5)
+    x = np.concatenate([np.linspace(-700.0, 700.0, 100001), rng.uniform(-8e5, 8e5, 100000), [0.0, 1e7, np.inf, np.nan]])
+    dev = rtamd.debug_math(3, x)
+    L = oracle.lib()
+    ref = np.array([L.orc_det_sin(float(v)) for v in x])
+    assert np.array_equal(dev, ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kernel", [0, 1, 2])
+@pytest.mark.parametrize("shutter", [(0.0, 1.0), (0.0, 0.0), (0.3, 0.3)])
+def test_motion_blur_and_marble_render_bit_exact(kernel, shutter):
+    w, cam, o = _pair()
+    o.set_shutter(*shutter)
+    img, st = w.render(cam, width=96, height=72, spp=12, seed=2, kernel=kernel, shutter=shutter)
+    exp, _ = o.render(96, 72, 12, seed=2)
+    assert np.array_equal(img, exp, equal_nan=True), "%d pixels differ" % int((img != exp).any(axis=2).sum())
+    assert img.max() > 0 and (kernel == 0 or st["kernel_used"] == kernel) and st["kernel_used"] in (1, 2)   # moving spheres keep kernels 1 / 2
+    if shutter[1] > shutter[0]:
+        mix, _ = w.render(cam, width=48, height=36, spp=6, seed=2, kernel=kernel, shutter=shutter, integrator=0)
+        still, _ = w.render(cam, width=48, height=36, spp=6, seed=2, kernel=kernel)
+        assert not np.array_equal(mix, still)
+
+
+@pytest.mark.gpu
+def test_an_open_shutter_shifts_the_stream_of_every_scene_alike():
+    """scene_500 (spheres only: the sphere-only kernel variants) with an open shutter: the time draw is made although nothing moves"""
+    import oracle
+    import rtamd
+    w, cam = rtamd.load_scene_file(scene_path("scene_500.json"))
+    o = oracle.load_scene_file(scene_path("scene_500.json"))
+    o.set_shutter(0.0, 1.0)
+    for kernel in (1, 2):
+        img, _ = w.render(cam, width=64, height=64, spp=6, seed=3, kernel=kernel, shutter=(0.0, 1.0))
+        exp, _ = o.render(64, 64, 6, seed=3)
+        assert np.array_equal(img, exp)
+    c4ish, camc = rtamd.select_scene(scene_path("cube.obj"), 1.0, 1)          # the Cornell box: kernel 2 (its cube.obj instance is small)
+    oc = oracle.cornell_box_scene(scene_path("cube.obj"), 1.0, seed=1)
+    oc.set_shutter(0.0, 2.0)
+    img, _ = c4ish.render(camc, width=48, height=48, spp=6, seed=1, shutter=(0.0, 2.0))
+    exp, _ = oc.render(48, 48, 6, seed=1)
+    assert np.array_equal(img, exp)
+
+
+@pytest.mark.gpu
+def test_sppm_refuses_time():
+    import rtamd
+    w, cam = rtamd.select_scene(scene_path("cube.obj"), 1.0, 1)
+    p = rtamd.default_params(width=16, height=16, spp=1, time0=0.0, time1=1.0)
+    import ctypes as C
+    cfg = rtamd.rt_sppm_config()
+    w.L.rt_default_sppm_config(C.byref(cfg))
+    cfg.iterations, cfg.photons_per_iter = 1, 1000
+    out = np.zeros((16, 16, 3))
+    rc = w.L.rt_render_sppm(w.h, C.byref(cam.c), C.byref(p), C.byref(cfg), out.ctypes.data_as(C.POINTER(C.c_double)), None, None, None)
+    assert rc == -10 and b"no notion of time" in w.L.rt_last_error()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kernel", [0, 1, 2])
+def test_final_scene_as_named_bit_exact(kernel):
+    """BASELINE config C5 as it is worded: book 2's final scene WITH its moving sphere and its Perlin marble sphere, shutter [0, 1), at a reduced
+    frame; kernels 1 and 2 (MEDIA variants: it has two participating media) against the oracle."""
+    import oracle
+    import rtamd
+    from rtamd import shapes
+    w = rtamd.World()
+    w.new(shapes.final_scene(w), bvh_seed=3)
+    o = oracle.Scene()
+    o.World(shapes.final_scene(o), 3)
+    o.Camera(*shapes.FINAL_SCENE_CAMERA)
+    o.set_shutter(*shapes.FINAL_SCENE_SHUTTER)
+    f, t, up, vfov, asp, ap, fd = shapes.FINAL_SCENE_CAMERA
+    cam = rtamd.Camera((f, t), up, vfov, asp, ap, fd)
+    img, st = w.render(cam, width=80, height=80, spp=6, seed=1, kernel=kernel, shutter=shapes.FINAL_SCENE_SHUTTER)
+    exp, _ = o.render(80, 80, 6, seed=1)
+    assert np.array_equal(img, exp, equal_nan=True), "%d pixels differ" % int((img != exp).any(axis=2).sum())
+    assert st["kernel_used"] == (2 if kernel == 0 else kernel)
+    red, _ = w.render(cam, width=80, height=80, spp=6, seed=1, kernel=kernel)          # shutter closed: the sphere stands at center0, but the marble stays
+    assert not np.array_equal(red, img)

@@ -12,15 +12,15 @@ import bench
 
 scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
 rows = []
-for key in ("scene_10", "scene_500_c2", "scene_500", "cornell", "cornell_mix", "c4", "c5r"):
+for key in ("scene_10", "scene_500_c2", "scene_500", "cornell", "cornell_mix", "c4", "c5r", "c5"):
     label, W, H, spp_cfg, _ = configs.CONFIGS[key]
     spp = max(1, int(spp_cfg * scale))
-    if key == "c5r":
+    if key in ("c5r", "c5"):
         spp = max(1, spp // 8)  # 1600x1600x4000 = 10.2 G samples is the 8-GPU configuration: one GPU measures 500 spp of it
     world, cam = configs.product(key)
     integ = configs.INTEGRATOR.get(key, 0)
-    world.render(cam, width=W, height=H, spp=min(spp, 4), seed=1, integrator=integ)  # warm-up (workspace, code load)
-    _, st = world.render(cam, width=W, height=H, spp=spp, seed=1, integrator=integ)
+    world.render(cam, width=W, height=H, spp=min(spp, 4), seed=1, integrator=integ, shutter=configs.SHUTTER.get(key, (0.0, 0.0)))  # warm-up (workspace, code load)
+    _, st = world.render(cam, width=W, height=H, spp=spp, seed=1, integrator=integ, shutter=configs.SHUTTER.get(key, (0.0, 0.0)))
     acc = {"kernel_ms": st["kernel_ms"], "launches": st["launches"], "samples": st["samples"]}
     model = os.path.join(ROOT, "profiles", "pt_kernel_model.json") if key == "scene_500" else os.path.join(ROOT, "profiles", "r04", "model_%s.json" % key)
     roof, contract, hbm = bench.roofline_objects(acc, st["kernel_ms"] * 1e-3, model_path=model,

@@ -9,8 +9,8 @@ spp = int(sys.argv[2]) if len(sys.argv) > 2 else spp_cfg
 kernel = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 world, cam = configs.product(key)
 integ = configs.INTEGRATOR.get(key, 0)
-world.render(cam, width=W, height=H, spp=min(spp, 2), seed=1, kernel=kernel, integrator=integ)
-_, st = world.render(cam, width=W, height=H, spp=spp, seed=1, kernel=kernel, integrator=integ)
+world.render(cam, width=W, height=H, spp=min(spp, 2), seed=1, kernel=kernel, integrator=integ, shutter=configs.SHUTTER.get(key, (0.0, 0.0)))
+_, st = world.render(cam, width=W, height=H, spp=spp, seed=1, kernel=kernel, integrator=integ, shutter=configs.SHUTTER.get(key, (0.0, 0.0)))
 print(json.dumps(dict(config=label, key=key, width=W, height=H, spp=spp, kernel=st["kernel_used"], lds=st["scene_in_lds"], samples=st["samples"],
                       kernel_ms=st["kernel_ms"], launches=st["launches"], msamples_per_s_kernel=st["samples"] / (st["kernel_ms"] * 1e-3) / 1e6,
                       msamples_per_s_wall=st["samples"] / st["seconds"] / 1e6)))

@@ -18,9 +18,11 @@ CONFIGS = {
     "cornell": ("C3 cornell 800x800x2000 (BSDF sampling, integrator 0)", 800, 800, 2000, 4),
     "cornell_mix": ("C3 cornell 800x800x2000 (light / cosine mixture pdf, integrator 1)", 800, 800, 2000, 4),
     "c4": ("C4 cornell + 102,400-triangle torus 1200x1200x1000", 1200, 1200, 1000, 1),
+    "c5": ("C5 book-2 final scene AS NAMED (motion blur + Perlin marble; book-2 extensions, the reference has no code for either) 1600x1600x4000", 1600, 1600, 4000, 1),
     "c5r": ("C5 reduced (book-2 final scene without motion blur / Perlin: 400 boxes, 2 media, image texture, 1000-sphere instance) 1600x1600x4000", 1600, 1600, 4000, 1),
 }
 INTEGRATOR = {"cornell_mix": 1}  # rt_params.integrator of a configuration (default 0)
+SHUTTER = {"c5": (0.0, 1.0)}      # rt_params.time0 / time1 of a configuration (default: closed)
 CORNELL_CAM = ((278, 278, -800), (278, 278, 278), (0, 1, 0), 50, 1.0, 0.0, 10.0)
 
 
@@ -43,6 +45,11 @@ def product(key):
         w = rtamd.World()
         w.new(shapes.cornell_with_mesh(w, P, N, I), bvh_seed=1)
         f, t, up, vfov, asp, ap, fd = CORNELL_CAM
+        return w, rtamd.Camera((f, t), up, vfov, asp, ap, fd)
+    if key == "c5":
+        w = rtamd.World()
+        w.new(shapes.final_scene(w), bvh_seed=3)
+        f, t, up, vfov, asp, ap, fd = shapes.FINAL_SCENE_CAMERA
         return w, rtamd.Camera((f, t), up, vfov, asp, ap, fd)
     if key == "c5r":
         w = rtamd.World()
@@ -70,6 +77,12 @@ def oracle_scene(key):
         o = oracle.Scene()
         o.World(shapes.cornell_with_mesh(o, P, N, I), 1)
         o.Camera(*CORNELL_CAM)
+        return o
+    if key == "c5":
+        o = oracle.Scene()
+        o.World(shapes.final_scene(o), 3)
+        o.Camera(*shapes.FINAL_SCENE_CAMERA)
+        o.set_shutter(*shapes.FINAL_SCENE_SHUTTER)
         return o
     if key == "c5r":
         o = oracle.Scene()
