@@ -121,6 +121,11 @@ struct FlatView {  // by-value kernel argument
     uint32_t n_media;
     uint32_t off_msph;     // cold part: moving spheres (NK_MSPHERE), 10 f64 each
     uint32_t n_msph;
+    // cold part, one word per program node: for a leaf, the box (index into `boxes`) of the innermost BVHNode that encloses it in the
+    // reference's tree -- what BVHNode::hit tests, with t_max = closest hit so far, before it visits the leaf (bvh.rs:88).  Bit 31: that
+    // box lies in world space although the leaf sits under a Transform (no BVHNode between the Transform and the leaf);
+    // 0xFFFFFFFF: no enclosing BVHNode (lists).  Read by the accel kernels on EXACT ties only (tie_later_wins, kernels.hip).
+    uint32_t off_parent_box;
     uint32_t n_nodes;
     uint32_t stage_bytes;  // kernel 1 stages bytes [0, stage_bytes) into LDS: [meta|boxes|spheres|rects|tris|xforms|vpos]
     uint32_t kinds_mask;   // bit k set if some node has kind k

@@ -198,6 +198,8 @@ struct Acc {  // typed views into the blob (LDS or global; the address space is 
     uint32_t n_lights;
     const MediumDev* media;  // always global
     const double* msph;      // moving spheres (D9), always global: 10 f64 each
+    const double2* gboxes;   // the reference's BVHNode boxes, always global (kernel 2 does not stage them) ...
+    const uint32_t* parent_box;  // ... and per program node the innermost one around a leaf (FlatView::off_parent_box): read on exact ties only
     uint32_t time_lds;       // LDS byte address of the per-lane ray times (D9; 0: the scene has no moving sphere, every time is 0)
     // kernel 5's serving waves: compact object-space data (flat.h "Compact instance data")
     const uint4* n2q;        // 2 x uint4 per NodeQ
@@ -236,6 +238,8 @@ DEV Acc make_acc(P hot, const char* gbase, const FlatView& v) {  // hot: LDS cop
     a.n_lights = v.n_lights;
     a.media = (const MediumDev*)(gbase + v.off_media);
     a.msph = (const double*)(gbase + v.off_msph);
+    a.gboxes = (const double2*)(gbase + v.off_boxes);
+    a.parent_box = (const uint32_t*)(gbase + v.off_parent_box);
     a.time_lds = 0u;
     return a;
 }
@@ -457,6 +461,35 @@ struct Hit {
     int xf;       // enclosing Transform (xform index) or -1
     uint32_t kp;  // kind | payload << 4 of the winning leaf
 };
+
+// An EXACT tie between the best hit so far (program index best_order, under Transform best_xf or -1) and a candidate (cand_order,
+// cand_xf), both at parameter t, in a walk that meets objects in another order than the reference.  The reference gives a tie to the
+// object it visits LATER (inclusive ranges, Q5) -- if it visits it: BVHNode::hit first tests the enclosing node's box with t_max =
+// closest so far = t (bvh.rs:88), and AABB::hit rejects an interval that has shrunk to a point (aabb.rs:28-30).  A later object whose
+// innermost BVHNode box BEGINS at t (a Cube's exact box, cube.rs:67-69, entered through a face that is coplanar with what was hit
+// before) is therefore never visited and the earlier object keeps the hit.  Boxes nest, so the innermost enclosing one decides: an
+// outer box with an empty clipped interval implies an empty one for everything inside it.  Returns whether the candidate wins.
+// Out of line: ties are rare and the test needs the three divisions of AABB::hit.
+__device__ __attribute__((noinline)) bool tie_candidate_wins(const Acc* A, int cand_order, int cand_xf, int best_order, int best_xf, double wox, double woy,
+                                                             double woz, double wdx, double wdy, double wdz, double t_min, double t) {
+    if (cand_order == best_order) return false;  // the same object met twice (Q14): nothing changes
+    const bool cand_later = cand_order > best_order;
+    const int later = cand_later ? cand_order : best_order, later_xf = cand_later ? cand_xf : best_xf;
+    const uint32_t pb = A->parent_box[later];
+    bool visited = true;
+    if (pb != 0xFFFFFFFFu) {
+        D3 o = mk(wox, woy, woz), d = mk(wdx, wdy, wdz);
+        if (later_xf >= 0 && (pb >> 31) == 0u) {  // the box is in the object space of the leaf's Transform (transform.rs:153-156)
+            const double* Minv = A->xforms + 32 * later_xf;
+            const D3 oo = xf_point(Minv, o), dd = xf_dir(Minv, d);
+            o = oo;
+            d = dd;
+        }
+        const D3 inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+        visited = aabb_hit(A->gboxes + 3 * (pb & 0x7FFFFFFFu), o, inv, t_min, t);
+    }
+    return cand_later ? visited : !visited;
+}
 
 // World::hit -> BVHNode::hit / Vec::hit / Transform::hit, flattened (common/flat.h).
 // Visits nodes in the reference's own order; a leaf is accepted when t_min <= t <= best
@@ -887,7 +920,7 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
                     if (got) {
                         if (it.y < track->lim[0] && t < track->T[0]) track->T[0] = t;
                         if (it.y < track->lim[1] && t < track->T[1]) track->T[1] = t;
-                        if (t < h.t || (t == h.t && (int)it.y > h.node) || !(t == t)) {  // (a candidate may lie beyond the best hit here)
+                        if (t < h.t || !(t == t) || (t == h.t && (h.node < 0 || tie_candidate_wins(&A, (int)it.y, cur_xf, h.node, h.xf, wo.x, wo.y, wo.z, wd.x, wd.y, wd.z, t_min, t)))) {  // (a candidate may lie beyond the best hit here)
                             h.t = t;
                             h.node = (int)it.y;
                             h.xf = cur_xf;
@@ -896,8 +929,8 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
                         }
                         r.best = ray32_best(track_bound(*track, h.t));
                     }
-                } else if (got && (t < h.t || (int)it.y > h.node || !(t == t))) {
-                    // accepted candidates satisfy t <= h.t; an exact tie goes to the later one in reference order
+                } else if (got && (t < h.t || !(t == t) || h.node < 0 || tie_candidate_wins(&A, (int)it.y, cur_xf, h.node, h.xf, wo.x, wo.y, wo.z, wd.x, wd.y, wd.z, t_min, t))) {
+                    // accepted candidates satisfy t <= h.t; an exact tie goes to the later one in reference order -- if the reference visits it
                     h.t = t;
                     h.node = (int)it.y;
                     h.xf = cur_xf;
