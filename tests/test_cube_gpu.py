@@ -128,7 +128,12 @@ def test_cube_hit_records_match_the_six_rectangle_scan(variant, as_list):
     # incl. the winning node's reference-order index: on an EXACT tie (a rectangle lying on a cube's face, the face two stacked cubes share) the
     # accel kernels ask whether the reference would have visited the later object at all -- its BVHNode::hit culls a box that BEGINS at the tied t
     # (bvh.rs:88, aabb.rs:28-30) -- and so agree with the reference-order kernel and the oracle (tie_candidate_wins, kernels.hip)
-    assert np.array_equal(outs[1][finite], outs[2][finite]) and np.array_equal(outs[2][finite], outs[3][finite])
+    # (the index itself may name the other of two emissions of ONE object -- BVHNode::new puts a single object into both children, Q14: the
+    # reference's second visit is culled by the same rule once the first has set closest-so-far to the box's entry, the accel keeps one
+    # item with the later index -- so the records are compared without it, and the indices where no object is emitted twice)
+    assert np.array_equal(outs[1][finite][:, :11], outs[2][finite][:, :11]) and np.array_equal(outs[2][finite], outs[3][finite])
+    if variant == 0:
+        assert np.array_equal(outs[1][finite], outs[2][finite])
 
 
 @pytest.mark.parametrize("kernel", [0, 1, 2])
