@@ -121,7 +121,8 @@ def _scene(B):
         B.XZRectangle((-20.0, -20.0), (20.0, 20.0), 0.0, marble),                                   # a marble floor
         B.Sphere((0.0, 1.0, 0.0), 1.0, marble),
         B.MovingSphere((-3.0, 0.7, -1.0), (-1.5, 1.4, -1.0), 0.0, 1.0, 0.7, B.Lambertian(B.ConstantTexture((0.7, 0.3, 0.1)))),
-        B.MovingSphere((2.0, 0.5, -2.0), (2.0, 2.5, -2.0), 0.25, 0.75, 0.5, glass),                 # moves during the middle half of the shutter (extrapolated outside)
+        B.MovingSphere((2.0, -0.5, -2.0), (2.0, 3.5, -2.0), -0.5, 1.5, 0.5, glass),                 # its own clock: at (2, 0.5, -2) when the shutter opens, at (2, 2.5, -2) when it closes
+                                                                                                    # (a moving sphere's box covers [time0, time1]: the shutter must lie within, as in the book)
         B.Transform((0.0, 25.0, 0.0), (1.0, 1.5, 1.0), (3.0, 1.0, 1.5), B.MovingSphere((0.0, 0.0, 0.0), (0.0, 0.0, 1.0), 0.0, 1.0, 0.6, B.Metal(B.ConstantTexture((0.8, 0.8, 0.9)), 0.05))),
         B.Cube((-4.0, 0.0, 1.0), (-2.5, 1.5, 2.5), white),
         B.XZRectangle((-3.0, -3.0), (3.0, 3.0), 7.0, B.DiffuseLight(B.ConstantTexture((5.0, 5.0, 5.0)))),
