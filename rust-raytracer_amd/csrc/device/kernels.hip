@@ -470,23 +470,25 @@ struct Hit {
 // before) is therefore never visited and the earlier object keeps the hit.  Boxes nest, so the innermost enclosing one decides: an
 // outer box with an empty clipped interval implies an empty one for everything inside it.  Returns whether the candidate wins.
 // Out of line: ties are rare and the test needs the three divisions of AABB::hit.
-__device__ __attribute__((noinline)) bool tie_candidate_wins(const Acc* A, int cand_order, int cand_xf, int best_order, int best_xf, double wox, double woy,
-                                                             double woz, double wdx, double wdy, double wdz, double t_min, double t) {
+// (the three tables by value: taking the address of the Acc would pin the whole struct in scratch memory for the callers' loops)
+__device__ __attribute__((noinline)) bool tie_candidate_wins(const uint32_t* parent_box, const double2* gboxes, const double* xforms, int cand_order, int cand_xf,
+                                                             int best_order, int best_xf, double wox, double woy, double woz, double wdx, double wdy, double wdz,
+                                                             double t_min, double t) {
     if (cand_order == best_order) return false;  // the same object met twice (Q14): nothing changes
     const bool cand_later = cand_order > best_order;
     const int later = cand_later ? cand_order : best_order, later_xf = cand_later ? cand_xf : best_xf;
-    const uint32_t pb = A->parent_box[later];
+    const uint32_t pb = parent_box[later];
     bool visited = true;
     if (pb != 0xFFFFFFFFu) {
         D3 o = mk(wox, woy, woz), d = mk(wdx, wdy, wdz);
         if (later_xf >= 0 && (pb >> 31) == 0u) {  // the box is in the object space of the leaf's Transform (transform.rs:153-156)
-            const double* Minv = A->xforms + 32 * later_xf;
+            const double* Minv = xforms + 32 * later_xf;
             const D3 oo = xf_point(Minv, o), dd = xf_dir(Minv, d);
             o = oo;
             d = dd;
         }
         const D3 inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
-        visited = aabb_hit(A->gboxes + 3 * (pb & 0x7FFFFFFFu), o, inv, t_min, t);
+        visited = aabb_hit(gboxes + 3 * (pb & 0x7FFFFFFFu), o, inv, t_min, t);
     }
     return cand_later ? visited : !visited;
 }
@@ -920,7 +922,7 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
                     if (got) {
                         if (it.y < track->lim[0] && t < track->T[0]) track->T[0] = t;
                         if (it.y < track->lim[1] && t < track->T[1]) track->T[1] = t;
-                        if (t < h.t || !(t == t) || (t == h.t && (h.node < 0 || tie_candidate_wins(&A, (int)it.y, cur_xf, h.node, h.xf, wo.x, wo.y, wo.z, wd.x, wd.y, wd.z, t_min, t)))) {  // (a candidate may lie beyond the best hit here)
+                        if (t < h.t || !(t == t) || (t == h.t && (h.node < 0 || tie_candidate_wins(A.parent_box, A.gboxes, A.xforms, (int)it.y, cur_xf, h.node, h.xf, wo.x, wo.y, wo.z, wd.x, wd.y, wd.z, t_min, t)))) {  // (a candidate may lie beyond the best hit here)
                             h.t = t;
                             h.node = (int)it.y;
                             h.xf = cur_xf;
@@ -929,7 +931,7 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
                         }
                         r.best = ray32_best(track_bound(*track, h.t));
                     }
-                } else if (got && (t < h.t || !(t == t) || h.node < 0 || tie_candidate_wins(&A, (int)it.y, cur_xf, h.node, h.xf, wo.x, wo.y, wo.z, wd.x, wd.y, wd.z, t_min, t))) {
+                } else if (got && (t < h.t || !(t == t) || h.node < 0 || tie_candidate_wins(A.parent_box, A.gboxes, A.xforms, (int)it.y, cur_xf, h.node, h.xf, wo.x, wo.y, wo.z, wd.x, wd.y, wd.z, t_min, t))) {
                     // accepted candidates satisfy t <= h.t; an exact tie goes to the later one in reference order -- if the reference visits it
                     h.t = t;
                     h.node = (int)it.y;
