@@ -121,6 +121,7 @@ struct FlatView {  // by-value kernel argument
     uint32_t n_media;
     uint32_t off_msph;     // cold part: moving spheres (NK_MSPHERE), 10 f64 each
     uint32_t n_msph;
+    uint32_t has_noise;    // 1 if some texture is a noise texture (D9): such scenes take the book-2 kernel variants
     // cold part, one word per program node: for a leaf, the box (index into `boxes`) of the innermost BVHNode that encloses it in the
     // reference's tree -- what BVHNode::hit tests, with t_max = closest hit so far, before it visits the leaf (bvh.rs:88).  Bit 31: that
     // box lies in world space although the leaf sits under a Transform (no BVHNode between the Transform and the leaf);

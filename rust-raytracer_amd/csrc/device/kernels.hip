@@ -462,35 +462,38 @@ struct Hit {
     uint32_t kp;  // kind | payload << 4 of the winning leaf
 };
 
-// An EXACT tie between the best hit so far (program index best_order, under Transform best_xf or -1) and a candidate (cand_order,
-// cand_xf), both at parameter t, in a walk that meets objects in another order than the reference.  The reference gives a tie to the
-// object it visits LATER (inclusive ranges, Q5) -- if it visits it: BVHNode::hit first tests the enclosing node's box with t_max =
-// closest so far = t (bvh.rs:88), and AABB::hit rejects an interval that has shrunk to a point (aabb.rs:28-30).  A later object whose
-// innermost BVHNode box BEGINS at t (a Cube's exact box, cube.rs:67-69, entered through a face that is coplanar with what was hit
-// before) is therefore never visited and the earlier object keeps the hit.  Boxes nest, so the innermost enclosing one decides: an
-// outer box with an empty clipped interval implies an empty one for everything inside it.  Returns whether the candidate wins.
-// Out of line: ties are rare and the test needs the three divisions of AABB::hit.
-// (the three tables by value: taking the address of the Acc would pin the whole struct in scratch memory for the callers' loops)
-__device__ __attribute__((noinline)) bool tie_candidate_wins(const uint32_t* parent_box, const double2* gboxes, const double* xforms, int cand_order, int cand_xf,
-                                                             int best_order, int best_xf, double wox, double woy, double woz, double wdx, double wdy, double wdz,
-                                                             double t_min, double t) {
-    if (cand_order == best_order) return false;  // the same object met twice (Q14): nothing changes
-    const bool cand_later = cand_order > best_order;
-    const int later = cand_later ? cand_order : best_order, later_xf = cand_later ? cand_xf : best_xf;
-    const uint32_t pb = parent_box[later];
-    bool visited = true;
-    if (pb != 0xFFFFFFFFu) {
-        D3 o = mk(wox, woy, woz), d = mk(wdx, wdy, wdz);
-        if (later_xf >= 0 && (pb >> 31) == 0u) {  // the box is in the object space of the leaf's Transform (transform.rs:153-156)
-            const double* Minv = xforms + 32 * later_xf;
-            const D3 oo = xf_point(Minv, o), dd = xf_dir(Minv, d);
-            o = oo;
-            d = dd;
-        }
-        const D3 inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
-        visited = aabb_hit(gboxes + 3 * (pb & 0x7FFFFFFFu), o, inv, t_min, t);
+// EXACT ties in the accel walks.  The reference gives a tie to the object it visits LATER (inclusive ranges, Q5) -- if it visits it:
+// BVHNode::hit first tests the enclosing node's box with t_max = closest so far = the tied t (bvh.rs:88), and AABB::hit rejects an
+// interval that has shrunk to a point (aabb.rs:28-30).  A later object whose innermost BVHNode box BEGINS at t (a Cube's exact box,
+// cube.rs:67-69, entered through a face that is coplanar with what was hit before: a rectangle lying on the face, the face it shares
+// with the cube the ray is leaving, a floor under a box lit from below) is therefore never visited and the earlier object keeps the
+// hit.  Boxes nest, so the innermost enclosing one decides.  The walk itself keeps the round-3 rule (the later object wins: nothing in
+// the leaf loops but a compare) and NOTES the tie -- the earlier party goes to a record in private memory; when the walk is over and the
+// noted later party is still the best hit, its innermost reference box is tested once (tie_resolve, three divisions) and the hit goes
+// back to the earlier party if the reference would have culled it.  (A call in the leaf loop instead cost every kernel 6-18 %: the
+// register allocator pays for a call site whether it is taken or not.)  Three-way exact ties keep the last note only.
+struct TieNote {  // written through a volatile pointer: stays in scratch, costs the loops no register
+    int later, earlier, earlier_xf;
+    uint32_t earlier_kp;
+};
+DEV void tie_note(volatile TieNote* n, int cand_order, int cand_xf, uint32_t cand_kp, const Hit& h) {  // cand and h.node tie at h.t; orders differ
+    const bool cand_later = cand_order > h.node;
+    n->later = cand_later ? cand_order : h.node;
+    n->earlier = cand_later ? h.node : cand_order;
+    n->earlier_xf = cand_later ? h.xf : cand_xf;
+    n->earlier_kp = cand_later ? h.kp : cand_kp;
+}
+DEV bool ref_box_visited(const uint32_t* parent_box, const double2* gboxes, const double* xforms, int order, int xf, D3 wo, D3 wd, double t_min, double t) {
+    const uint32_t pb = parent_box[order];
+    if (pb == 0xFFFFFFFFu) return true;  // no enclosing BVHNode (a list)
+    D3 o = wo, d = wd;
+    if (xf >= 0 && (pb >> 31) == 0u) {  // the box is in the object space of the leaf's Transform (transform.rs:153-156)
+        const double* Minv = xforms + 32 * xf;
+        o = xf_point(Minv, wo);
+        d = xf_dir(Minv, wd);
     }
-    return cand_later ? visited : !visited;
+    const D3 inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+    return aabb_hit(gboxes + 3 * (pb & 0x7FFFFFFFu), o, inv, t_min, t);
 }
 
 // World::hit -> BVHNode::hit / Vec::hit / Transform::hit, flattened (common/flat.h).
@@ -500,7 +503,7 @@ __device__ __attribute__((noinline)) bool tie_candidate_wins(const uint32_t* par
 // two boundary queries of ConstantMedium::hit (medium.rs:26-27) in a scratch hit with its own range [lo, +inf), then END
 // restores the outer best hit and makes the medium's one random draw from the path's stream.
 // [n0, n1): the part of the program to walk (default: all of it; traverse2_media walks a medium's boundary subtree).
-template <bool GENERAL, bool MEDIA = false>
+template <int GENERAL, bool MEDIA = false>
 DEV Hit traverse(const Acc& A, D3 wo, D3 wd, double t_min, double t_max, Rng* rng = nullptr, uint32_t n0 = 0u, uint32_t n1 = 0xFFFFFFFFu) {
     D3 o = wo, d = wd;
     D3 inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
@@ -586,7 +589,7 @@ DEV Hit traverse(const Acc& A, D3 wo, D3 wd, double t_min, double t_max, Rng* rn
                     h.xf = cur_xf;
                     h.kp = m.x + (side << NK_BITS);
                 }
-            } else if (kind == NK_MSPHERE) {
+            } else if (GENERAL == 2 && kind == NK_MSPHERE) {
                 double t;
                 if (msphere_hit(A.msph + 10 * pl, ray_time(A), o.x, o.y, o.z, d.x, d.y, d.z, a, t_min, h.t, &t)) {
                     h.t = t;
@@ -780,7 +783,7 @@ DEV double track_bound(const MediaTrack& K, double best) {
 }
 // ENTER: instance items may be entered in the lane (always, unless DEFER; with DEFER only in the MIXED variants of kernels 5 / 6,
 // for the NK_INSTANCE_INLINE items of scenes that have any: compiling the enter path into their world-space walk costs C4 6 %).
-template <bool GENERAL, bool DEFER = false, bool TOP = true, bool WIDE = false, class PEND = uint32_t, bool LIMIT = false, bool ENTER = !DEFER, bool TRACK = false>
+template <int GENERAL, bool DEFER = false, bool TOP = true, bool WIDE = false, class PEND = uint32_t, bool LIMIT = false, bool ENTER = !DEFER, bool TRACK = false>
 DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, double t_min, double t_max, PEND* pend = nullptr, uint32_t order_limit = 0xFFFFFFFFu,
                   MediaTrack* track = nullptr) {
     D3 o = wo, d = wd;
@@ -791,6 +794,8 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
     h.xf = -1;
     h.kp = 0;
     int cur_xf = -1;
+    volatile TieNote tie;  // (see "EXACT ties" above)
+    tie.later = -2;
     Ray32 r = make_ray32(o, d, t_min, t_max);
     float best_all32 = r.best;  // TRACK: the best hit's own (outward-rounded) t, beside r.best = the track bound
     if (WIDE) ray32_wide_addr(r, A.n2w_lds);
@@ -904,7 +909,7 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
                 } else if (GENERAL) {
                     if (kind == NK_RECT_YZ || kind == NK_RECT_XZ || kind == NK_RECT_XY) {
                         got = rect_hit(A.rects + 3 * pl, (int)kind - (int)NK_RECT_YZ, o, d, t_min, t_far, t);
-                    } else if (kind == NK_MSPHERE) {
+                    } else if (GENERAL == 2 && kind == NK_MSPHERE) {
                         got = msphere_hit(A.msph + 10 * pl, ray_time(A), o.x, o.y, o.z, d.x, d.y, d.z, a, t_min, t_far, &t);
                     } else if (kind == NK_CUBE) {
                         PH_EV(12);
@@ -922,7 +927,8 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
                     if (got) {
                         if (it.y < track->lim[0] && t < track->T[0]) track->T[0] = t;
                         if (it.y < track->lim[1] && t < track->T[1]) track->T[1] = t;
-                        if (t < h.t || !(t == t) || (t == h.t && (h.node < 0 || tie_candidate_wins(A.parent_box, A.gboxes, A.xforms, (int)it.y, cur_xf, h.node, h.xf, wo.x, wo.y, wo.z, wd.x, wd.y, wd.z, t_min, t)))) {  // (a candidate may lie beyond the best hit here)
+                        if (t == h.t && h.node >= 0 && (int)it.y != h.node) tie_note(&tie, (int)it.y, cur_xf, it.x + (cube_side << NK_BITS), h);
+                        if (t < h.t || (t == h.t && (int)it.y > h.node) || !(t == t)) {  // (a candidate may lie beyond the best hit here)
                             h.t = t;
                             h.node = (int)it.y;
                             h.xf = cur_xf;
@@ -931,8 +937,10 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
                         }
                         r.best = ray32_best(track_bound(*track, h.t));
                     }
-                } else if (got && (t < h.t || !(t == t) || h.node < 0 || tie_candidate_wins(A.parent_box, A.gboxes, A.xforms, (int)it.y, cur_xf, h.node, h.xf, wo.x, wo.y, wo.z, wd.x, wd.y, wd.z, t_min, t))) {
-                    // accepted candidates satisfy t <= h.t; an exact tie goes to the later one in reference order -- if the reference visits it
+                } else if (got) {
+                    // accepted candidates satisfy t <= h.t; an exact tie goes to the later one in reference order (and is noted: tie_resolve)
+                    if (t == h.t && h.node >= 0 && (int)it.y != h.node) tie_note(&tie, (int)it.y, cur_xf, it.x + (cube_side << NK_BITS), h);
+                    if (!(t < h.t || (int)it.y > h.node || !(t == t))) continue;
                     h.t = t;
                     h.node = (int)it.y;
                     h.xf = cur_xf;
@@ -982,6 +990,14 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
             cur = REF_DONE;
         }
         PH_END(9, ph_leaf0);
+    }
+    // the last exact tie noted, if its later party is still the hit: would the reference have visited that object at all?
+    if (GENERAL && h.node >= 0 && tie.later == h.node) {
+        if (!ref_box_visited(A.parent_box, A.gboxes, A.xforms, h.node, h.xf, wo, wd, t_min, h.t)) {
+            h.node = tie.earlier;
+            h.xf = tie.earlier_xf;
+            h.kp = tie.earlier_kp;
+        }
     }
     return h;
 }
@@ -1040,7 +1056,7 @@ DEV bool medium_boundary(const Acc& A, const MediumDev& M, D3 o, D3 d, double& t
     t_b = r2h.t;
     return true;
 }
-template <bool GENERAL, bool TOP, bool WIDE>
+template <int GENERAL, bool TOP, bool WIDE>
 DEV Hit traverse2_media(const Acc& A, uint32_t n_media, uint32_t* stk, const int stride, D3 o, D3 d, double t_min, Rng& rng) {
     // 1. the boundary queries of the media (no random number is drawn here); the first two media the ray crosses are TRACKED by the
     //    accel walk (MediaTrack), so that one walk yields the closest surface S and, for each of the two, the closest surface the
@@ -1139,6 +1155,7 @@ __device__ __attribute__((noinline)) bool checker_sines_negative(D3 p) {  // the
     double sines = sin(10. * p.x) * sin(10. * p.y) * sin(10. * p.z);
     return sines < 0.;
 }
+template <int GENERAL = 1>
 DEV D3 tex_color(const Acc& A, int tex, const Rec& rec) {  // material.rs:52-84
     const TexDev* t = &A.texs[tex];
     int type = t->type;
@@ -1155,7 +1172,7 @@ DEV D3 tex_color(const Acc& A, int tex, const Rec& rec) {  // material.rs:52-84
         type = 0;
     }
     if (type == 0) return mk(t->color[0], t->color[1], t->color[2]);
-    if (type == 3) {  // D9: noise_texture::value = color(1, 1, 1) * 0.5 * (1 + sin(scale p.z + 10 turb(p)))
+    if (GENERAL == 2 && type == 3) {  // D9: noise_texture::value = color(1, 1, 1) * 0.5 * (1 + sin(scale p.z + 10 turb(p)))
         const double m = noise_marble(A.texels + t->texel_off, t->color[0], rec.p.x, rec.p.y, rec.p.z);
         return mk(1. * m, 1. * m, 1. * m);
     }
@@ -1176,7 +1193,7 @@ DEV void sphere_uv(D3 outward, double& u, double& v) {  // get_uv, sphere.rs:16-
     v = theta * FRAC_1_PI;
 }
 // Build the HitRecord of the winning leaf only (the reference builds one per candidate).
-template <bool GENERAL>
+template <int GENERAL>
 DEV Rec materialize(const Acc& A, const Hit& h, D3 wo, D3 wd, int* err) {
     Rec rec;
     uint32_t kind = h.kp & NK_MASK, pl = h.kp >> NK_BITS;
@@ -1197,7 +1214,7 @@ DEV Rec materialize(const Acc& A, const Hit& h, D3 wo, D3 wd, int* err) {
         outward = divs(sub(p, mk(c0.x, c0.y, c1.x)), c1.y);
         want_uv = A.texs[A.mats[rec.mat].tex].type == 2;
         if (want_uv) sphere_uv(outward, rec.u, rec.v);  // get_uv, sphere.rs:16-20 (only an ImageTexture reads it)
-    } else if (GENERAL && kind == NK_MSPHERE) {  // D9: outward_normal = (p - center(r.time)) / radius, get_uv as a sphere
+    } else if (GENERAL == 2 && kind == NK_MSPHERE) {  // D9: outward_normal = (p - center(r.time)) / radius, get_uv as a sphere
         const double* q = A.msph + 10 * pl;
         rec.mat = (int)q[9];
         D3 p = add(o, muls(d, h.t));
@@ -1265,12 +1282,13 @@ DEV Rec materialize(const Acc& A, const Hit& h, D3 wo, D3 wd, int* err) {
 // branches: the texture lookup (every type reads its texture exactly once), the unit-sphere sample that Lambertian,
 // DiffuseLight and Metal all draw first, and the one normalisation each type performs (of that sample for the diffuse
 // types, of the incoming direction for Metal and Dielectric).  Per lane the operations and their order are unchanged.
+template <int GENERAL = 1>
 DEV bool shade(const Acc& A, const Rec& rec, D3 rdir, Rng& rng, D3& emitted, D3& att, D3& out_dir, bool& diffuse, int* err) {
     const MatDev mt = A.mats[rec.mat];
     const int type = mt.type;
     const bool lamb = (type == 0 || type == 3);  // Lambertian / DiffuseLight: Interaction::Diffuse (material.rs:111,207)
     diffuse = lamb;
-    const D3 tc = tex_color(A, mt.tex, rec);
+    const D3 tc = tex_color<GENERAL>(A, mt.tex, rec);
     const double FRAC_1_PI = 0.318309886183790671537767526745028724;
     emitted = (type == 3) ? tc : mk(0., 0., 0.);                                         // material.rs:209-211 (no face test)
     att = (type == 3) ? mk(1. * FRAC_1_PI, 1. * FRAC_1_PI, 1. * FRAC_1_PI) : tc;         // material.rs:201-203
@@ -1812,7 +1830,8 @@ __device__ __attribute__((noinline)) UnitInfo next_unit(uint32_t* wst_, uint32_t
     return u;
 }
 
-template <bool LDS, bool GENERAL, int ACCEL, int INTEG, bool MEDIA = false, bool POOL = false>
+// GENERAL: 0 = spheres under BVH nodes only, 1 = every primitive of the reference, 2 = 1 + the book-2 extensions (D9: moving spheres, noise textures, an open shutter)
+template <bool LDS, int GENERAL, int ACCEL, int INTEG, bool MEDIA = false, bool POOL = false>
 __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, RenderK rk, double* __restrict__ ring, double* accum,
                                                       unsigned int* tickets, unsigned int* __restrict__ counter, int* __restrict__ err) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1897,7 +1916,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
 #pragma unroll
         for (int i = 0; i < 25; i++) cfg[CFG_LVL + i] = rk.lvl[i / 5][i % 5];
     }
-    if (GENERAL && rk.time_slots) A.time_lds = (uint32_t)(uintptr_t)(AS_L char*)(cfg + CFG_WORDS);  // (8-aligned: every section before it is)
+    if (GENERAL == 2 && rk.time_slots) A.time_lds = (uint32_t)(uintptr_t)(AS_L char*)(cfg + CFG_WORDS);  // (8-aligned: every section before it is)
     __syncthreads();
     double* wring = ring + ((size_t)blockIdx.x * (PT_BLOCK / 64) + (size_t)wave) * RING_UNITS * UNIT_DOUBLES;
 
@@ -1979,10 +1998,10 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
                         double v = ((double)y + rng.gen_f64()) / (double)(rk.height - 1);
                         double st = 1.0 - v;
                         D3 rd = muls(random_in_unit_disk(rng), cam.lens_radius);  // drawn even for aperture 0 (Q4)
-                        if (GENERAL && rk.time1 > rk.time0) {  // D9: ray(origin + offset, .., random_double(time0, time1)), after the lens sample
+                        if (GENERAL == 2 && rk.time1 > rk.time0) {  // D9: ray(origin + offset, .., random_double(time0, time1)), after the lens sample
                             const double tm = rng.gen_range(rk.time0, rk.time1);
                             if (A.time_lds) *(AS_L double*)(uintptr_t)(A.time_lds + 8u * threadIdx.x) = tm;
-                        } else if (GENERAL && A.time_lds) {
+                        } else if (GENERAL == 2 && A.time_lds) {
                             *(AS_L double*)(uintptr_t)(A.time_lds + 8u * threadIdx.x) = rk.time0;
                         }
                         D3 offset = add(muls(cam.u, rd.x), muls(cam.v, rd.y));
@@ -2020,7 +2039,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
                     D3 emitted, att, ndir;
                     bool diffuse;
                     PH_BEGIN(ph_s0);
-                    bool scattered = shade(A, rec, d, rng, emitted, att, ndir, diffuse, err);
+                    bool scattered = shade<GENERAL>(A, rec, d, rng, emitted, att, ndir, diffuse, err);
                     PH_END(3, ph_s0);
                     L = add(L, elemul(beta, emitted));  // radiance += throughput * Le
                     if (scattered) {  // Diffuse continues like Specular/Reflect/Refract (photon_mapper.rs:346-347)
@@ -2291,8 +2310,6 @@ DEV void blas_pass(const Acc& A, bool act, uint32_t* stk, const int stride, D3 o
                 got = rect_hit(A.rects + 3 * pl, (int)kind - (int)NK_RECT_YZ, o, d, t_min, ht, t);
             } else if (kind == NK_CUBE) {
                 got = cube_hit(A.rects + 3 * (pl >> 3), o, d, t_min, ht, t, cube_side);
-            } else if (kind == NK_MSPHERE) {
-                got = msphere_hit(A.msph + 10 * pl, ray_time(A), o.x, o.y, o.z, d.x, d.y, d.z, a, t_min, ht, &t);
             } else if (kind == NK_TRI) {
                 double b1, b2;
                 got = tri_hit(A.tripre2 + 5 * (first + i), o, d, t_min, ht, t, b1, b2);
@@ -2795,7 +2812,6 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
                     double v = ((double)y + rng.gen_f64()) / (double)(rk.height - 1);
                     double stt = 1.0 - v;
                     D3 rd = muls(random_in_unit_disk(rng), cam.lens_radius);
-                    if (rk.time1 > rk.time0) (void)rng.gen_range(rk.time0, rk.time1);  // D9: the sample's time (nothing here moves: scenes with moving spheres take kernel 2)
                     D3 offset = add(muls(cam.u, rd.x), muls(cam.v, rd.y));
                     o = add(cam.origin, offset);
                     d = sub(sub(add(add(cam.llc, muls(cam.horizontal, u)), muls(cam.vertical, stt)), cam.origin), offset);
@@ -3371,9 +3387,11 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
 
     FlatView view = s.flat.view;
     view.base = device_blob(s, dev);
-    // (an open shutter makes every sample draw a time: that lives in the GENERAL variants only, the sphere-only ones stay as they are)
-    const bool general = (view.kinds_mask & ~((1u << NK_BOX) | (1u << NK_SPHERE))) != 0 || plan.time1 > plan.time0;
     const bool moving = (view.kinds_mask & (1u << NK_MSPHERE)) != 0;  // D9: the paths' times live in LDS, 8 bytes per lane
+    // D9: moving spheres, noise textures and an open shutter (every sample draws a time) live in their own kernel variants (GENERAL == 2,
+    // kernels 1 / 2, integrator 0): nothing of them is compiled into the others
+    const bool book2 = moving || view.has_noise != 0 || plan.time1 > plan.time0;
+    const bool general = (view.kinds_mask & ~((1u << NK_BOX) | (1u << NK_SPHERE))) != 0 || book2;
     const size_t lds_max = di.lds_max - (moving ? (size_t)PT_BLOCK * sizeof(double) : 0);
     // The accel kernels need the camera inside the region the f32 boxes were padded for (flatten.cpp: origin_limit2) and
     // t_min >= 0 (box32's proof); otherwise kernel 1 (reference order) renders.
@@ -3389,7 +3407,7 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
     const size_t stack5_bytes = (size_t)stack5 * PT_BLOCK * sizeof(uint32_t);
     const size_t coop_world = coop_world_bytes(view);  // world-level tables, always in LDS for this kernel
     const size_t coop_lds = (size_t)3 * COOP_RING * sizeof(uint16_t) + 8 * sizeof(uint32_t) + ((sizeof(CoopArgs) + 15) & ~size_t(15)) + coop_world;  // + three rings of pool-slot ids, counters, argument block
-    const bool coop_usable = accel2_usable && general && !media && !moving && view.coop_data_ok != 0 && view.n_inst2 >= 1 && view.n_inst2 <= (uint32_t)COOP_MAX_INST &&
+    const bool coop_usable = accel2_usable && general && !media && !book2 && view.coop_data_ok != 0 && view.n_inst2 >= 1 && view.n_inst2 <= (uint32_t)COOP_MAX_INST &&
                              view.inst_depth2 <= (uint32_t)COOP_STACK_MAX && coop_world <= 32768 && stack5_bytes + coop_lds <= lds_max && plan.max_depth < (1 << 24);
     // kernel 6 = the same instance service across the whole GPU and across launches (wavefront.inc)
     const uint32_t stack6 = std::max<uint32_t>(std::max(view.world_depth2 + 2u, view.stack2_inline), (uint32_t)WF_ENTRY_STACK + 1u);
@@ -3399,7 +3417,7 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
     const uint32_t stack6w = view.inst_depth2 + 2u;
     const size_t wf_tables_w = coop_a16(view.stage_bytes - view.off_xforms) + coop_a16(8u * view.n_inst2) + coop_a16((uint32_t)sizeof(QGrid) * view.n_inst2);
     const size_t wf_lds_walk_min = wf_tables_w + (size_t)stack6w * WF_WALK_BLOCK * sizeof(uint32_t);
-    const bool wf_usable = accel2_usable && general && !media && !moving && view.coop_data_ok != 0 && view.n_inst2 >= 1 && view.n_inst2 <= (uint32_t)WF_MAX_INST &&
+    const bool wf_usable = accel2_usable && general && !media && !book2 && view.coop_data_ok != 0 && view.n_inst2 >= 1 && view.n_inst2 <= (uint32_t)WF_MAX_INST &&
                            coop_world <= 32768 && wf_lds_pt <= lds_max && wf_lds_walk_min <= lds_max && plan.max_depth < (1 << 24);
     int kernel = plan.kernel;
     // auto: the cooperative kernel as soon as an instance is more than a handful of triangles (Cornell box + torus instance, 64 spp,
@@ -3429,8 +3447,8 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
     const int integ = plan.integrator;
     if (integ == 1 && view.n_lights == 0) throw RtError(RT_ERR_ARG, "integrator 1 (light importance sampling) needs rt_scene_set_lights");
     if (integ == 2 && !plan.sppm_est) throw RtError(RT_ERR_ARG, "integrator 2 (SPPM) is reached through rt_render_sppm");
-    if (integ == 2 && (moving || plan.time1 > plan.time0))
-        throw RtError(RT_ERR_UNSUPPORTED, "the SPPM integrator has no notion of time: moving spheres / an open shutter render with integrators 0 and 1");
+    if (integ != 0 && book2)
+        throw RtError(RT_ERR_UNSUPPORTED, "the book-2 extensions (moving spheres, noise textures, an open shutter) render with integrator 0 (kernels 1 and 2)");
     if (media && integ != 0)
         throw RtError(RT_ERR_UNSUPPORTED, "scenes with a ConstantMedium render with integrator 0 only (the medium's random draw is part of the "
                                           "reference-order walk; light sampling and SPPM have no volume events)");
@@ -3449,6 +3467,10 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
     if (media)
         fn = (kernel == 2) ? (lds ? pt_kernel<true, true, 2, 0, true> : pt_kernel<false, true, 2, 0, true>)
                            : (lds ? pt_kernel<true, true, 1, 0, true> : pt_kernel<false, true, 1, 0, true>);
+    if (book2)  // GENERAL == 2
+        fn = media ? ((kernel == 2) ? (lds ? pt_kernel<true, 2, 2, 0, true> : pt_kernel<false, 2, 2, 0, true>)
+                                    : (lds ? pt_kernel<true, 2, 1, 0, true> : pt_kernel<false, 2, 1, 0, true>))
+                   : ((kernel == 2) ? (lds ? pt_kernel<true, 2, 2, 0> : pt_kernel<false, 2, 2, 0>) : (lds ? pt_kernel<true, 2, 1, 0> : pt_kernel<false, 2, 1, 0>));
     // scene too large for LDS: spend what is left after the stacks on the shallowest BVH levels (the Node2 array is depth-sorted)
     int n_top = 0, n_topq = 0;
     if (kernel == 2 && !lds && lds_max > stack_bytes) {
@@ -3474,7 +3496,7 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
     const int grid = di.cus * blocks_per_cu;
     // a rank that owns fewer tiles than the launch has waves: single-unit jobs (below) folded out of order (next_unit_pool)
     const bool pool = POOL_MODE && SINGLE_UNITS_BELOW_WAVES && plan.tiles_owned < (int64_t)grid * (PT_BLOCK / 64) &&
-                      ((kernel == 2 && !media) || (kernel == 5 && fn_coop == fn_coop_early));
+                      ((kernel == 2 && !media && !book2) || (kernel == 5 && fn_coop == fn_coop_early));
     if (pool && kernel == 2) {
         fn = pick_pt_kernel_pool(lds, general, integ);  // (same resources as the variant the occupancy was asked for)
         if (smem > 48 * 1024) HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -4154,6 +4176,7 @@ void debug_math_device(int op, size_t n, const double* a, const double* bb, doub
     HIP_CHECK(hipMemcpy(out, dc.p, n * 8, hipMemcpyDeviceToHost));
 }
 void debug_hit_device(const rt_scene& s, int kernel, size_t n, const double* rays, double t_min, double t_max, double* out) {
+    if (s.flat.view.kinds_mask & (1u << NK_MSPHERE)) throw RtError(RT_ERR_UNSUPPORTED, "rt_debug_hit_device has no ray time: scenes with moving spheres are not supported");
     if (!s.committed) throw RtError(RT_ERR_NOT_COMMITTED, "scene not committed");
     int dev = 0;
     HIP_CHECK(hipGetDevice(&dev));

@@ -699,6 +699,8 @@ void flatten(rt_scene& s) {
     v.off_texs = append(f.blob, texs);
     v.off_media = append(f.blob, b.media);
     v.n_media = (uint32_t)b.media.size();
+    v.has_noise = 0;
+    for (auto& tx : s.textures) v.has_noise |= (tx.type == TEX_NOISE) ? 1u : 0u;
     v.off_msph = append(f.blob, b.msph);
     v.n_msph = (uint32_t)(b.msph.size() / 10);
     v.off_parent_box = append(f.blob, b.parent_box);
