@@ -122,11 +122,9 @@ struct FlatView {  // by-value kernel argument
     uint32_t off_msph;     // cold part: moving spheres (NK_MSPHERE), 10 f64 each
     uint32_t n_msph;
     uint32_t has_noise;    // 1 if some texture is a noise texture (D9): such scenes take the book-2 kernel variants
-    // cold part, one word per program node: for a leaf, the box (index into `boxes`) of the innermost BVHNode that encloses it in the
-    // reference's tree -- what BVHNode::hit tests, with t_max = closest hit so far, before it visits the leaf (bvh.rs:88).  Bit 31: that
-    // box lies in world space although the leaf sits under a Transform (no BVHNode between the Transform and the leaf);
-    // 0xFFFFFFFF: no enclosing BVHNode (lists).  Read by the accel kernels on EXACT ties only (tie_later_wins, kernels.hip).
-    uint32_t off_parent_box;
+    // cold part: eight words {off_meta, off_boxes, off_spheres, off_rects, off_tripre, off_xforms, this record's own offset, n_nodes}:
+    // the reference-order program's tables in GLOBAL memory, for the out-of-line walk that settles an exact tie (tie_resolve, kernels.hip)
+    uint32_t off_tie_view;
     uint32_t n_nodes;
     uint32_t stage_bytes;  // kernel 1 stages bytes [0, stage_bytes) into LDS: [meta|boxes|spheres|rects|tris|xforms|vpos]
     uint32_t kinds_mask;   // bit k set if some node has kind k

@@ -198,8 +198,7 @@ struct Acc {  // typed views into the blob (LDS or global; the address space is 
     uint32_t n_lights;
     const MediumDev* media;  // always global
     const double* msph;      // moving spheres (D9), always global: 10 f64 each
-    const double2* gboxes;   // the reference's BVHNode boxes, always global (kernel 2 does not stage them) ...
-    const uint32_t* parent_box;  // ... and per program node the innermost one around a leaf (FlatView::off_parent_box): read on exact ties only
+    const uint32_t* tie_view;  // FlatView::off_tie_view, always global: read on exact ties only (tie_resolve)
     uint32_t time_lds;       // LDS byte address of the per-lane ray times (D9; 0: the scene has no moving sphere, every time is 0)
     // kernel 5's serving waves: compact object-space data (flat.h "Compact instance data")
     const uint4* n2q;        // 2 x uint4 per NodeQ
@@ -238,8 +237,7 @@ DEV Acc make_acc(P hot, const char* gbase, const FlatView& v) {  // hot: LDS cop
     a.n_lights = v.n_lights;
     a.media = (const MediumDev*)(gbase + v.off_media);
     a.msph = (const double*)(gbase + v.off_msph);
-    a.gboxes = (const double2*)(gbase + v.off_boxes);
-    a.parent_box = (const uint32_t*)(gbase + v.off_parent_box);
+    a.tie_view = (const uint32_t*)(gbase + v.off_tie_view);
     a.time_lds = 0u;
     return a;
 }
@@ -467,34 +465,23 @@ struct Hit {
 // interval that has shrunk to a point (aabb.rs:28-30).  A later object whose innermost BVHNode box BEGINS at t (a Cube's exact box,
 // cube.rs:67-69, entered through a face that is coplanar with what was hit before: a rectangle lying on the face, the face it shares
 // with the cube the ray is leaving, a floor under a box lit from below) is therefore never visited and the earlier object keeps the
-// hit.  Boxes nest, so the innermost enclosing one decides.  The walk itself keeps the round-3 rule (the later object wins: nothing in
-// the leaf loops but a compare) and NOTES the tie -- the earlier party goes to a record in private memory; when the walk is over and the
-// noted later party is still the best hit, its innermost reference box is tested once (tie_resolve, three divisions) and the hit goes
-// back to the earlier party if the reference would have culled it.  (A call in the leaf loop instead cost every kernel 6-18 %: the
-// register allocator pays for a call site whether it is taken or not.)  Three-way exact ties keep the last note only.
-struct TieNote {  // written through a volatile pointer: stays in scratch, costs the loops no register
-    int later, earlier, earlier_xf;
-    uint32_t earlier_kp;
-};
-DEV void tie_note(volatile TieNote* n, int cand_order, int cand_xf, uint32_t cand_kp, const Hit& h) {  // cand and h.node tie at h.t; orders differ
-    const bool cand_later = cand_order > h.node;
-    n->later = cand_later ? cand_order : h.node;
-    n->earlier = cand_later ? h.node : cand_order;
-    n->earlier_xf = cand_later ? h.xf : cand_xf;
-    n->earlier_kp = cand_later ? h.kp : cand_kp;
-}
-DEV bool ref_box_visited(const uint32_t* parent_box, const double2* gboxes, const double* xforms, int order, int xf, D3 wo, D3 wd, double t_min, double t) {
-    const uint32_t pb = parent_box[order];
-    if (pb == 0xFFFFFFFFu) return true;  // no enclosing BVHNode (a list)
-    D3 o = wo, d = wd;
-    if (xf >= 0 && (pb >> 31) == 0u) {  // the box is in the object space of the leaf's Transform (transform.rs:153-156)
-        const double* Minv = xforms + 32 * xf;
-        o = xf_point(Minv, wo);
-        d = xf_dir(Minv, wd);
-    }
-    const D3 inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
-    return aabb_hit(gboxes + 3 * (pb & 0x7FFFFFFFu), o, inv, t_min, t);
-}
+// hit.  The accel walk itself keeps the round-3 rule (the later object wins) and only FLAGS the tie in the winner's Hit::xf (TIE_FLAG;
+// any closer hit overwrites it): one compare and a select in the leaf loops.  When the walk is over and the flag is still there -- the
+// best hit is shared by two objects -- the ray is walked once more, through the reference-order program with the reference's own
+// box tests (tie_resolve = traverse<>, out of line), and that walk's answer is the hit.  (Cheaper forms of the rule were measured:
+// a call in the leaf loop cost every kernel 6-18 %, a note of the earlier party kept in private memory 6-12 % of the GENERAL
+// kernels -- the register allocator pays for a call site or a store sequence in the loop whether it is executed or not.)
+// Kernels 5 and 6 defer instances and merge their hits later: they keep the round-3 rule.
+#ifdef RT_NO_TIE_RULE  // A/B build: the round-3 rule alone (the later object always wins a tie)
+#define TIE_RULE 0
+#else
+#define TIE_RULE 1
+#endif
+#ifndef RT_TIE_NOTRACK
+#define RT_TIE_NOTRACK 0
+#endif
+#define TIE_FLAG 0x40000000  // in Hit::xf (-1 or a small index): bits 30 and 31 differ <=> the hit is an exact tie of two objects
+DEV bool tie_flagged(int xf) { return (((uint32_t)xf >> 30) & 1u) != ((uint32_t)xf >> 31); }
 
 // World::hit -> BVHNode::hit / Vec::hit / Transform::hit, flattened (common/flat.h).
 // Visits nodes in the reference's own order; a leaf is accepted when t_min <= t <= best
@@ -562,6 +549,8 @@ DEV Hit traverse(const Acc& A, D3 wo, D3 wd, double t_min, double t_max, Rng* rn
                 }
             }
             n++;
+        } else if (!MEDIA && GENERAL && kind == NK_MEDIUM_BEGIN) {  // surfaces only (tie_resolve): a medium's brackets and boundary copies are passed over
+            n = A.media[pl].n_end + 1u;
         } else if (kind == NK_SPHERE) {
             double t;
             if (sphere_hit(A.spheres + 2 * pl, o, d, a, t_min, h.t, t)) {
@@ -627,6 +616,27 @@ DEV Hit traverse(const Acc& A, D3 wo, D3 wd, double t_min, double t_max, Rng* rn
     return h;
 }
 
+// The accel walk found two objects at the best t (see "EXACT ties" above): the reference's own walk decides.  Out of line, and
+// called after the loops: rare, and the walks keep their registers.
+template <int GENERAL>
+#ifdef RT_TIE_NOCALL  // A/B build: the flag is kept in the loops but nothing is resolved
+DEV Hit tie_resolve(const Acc& A, D3 wo, D3 wd, double t_min, double t_max, Hit h) { h.xf ^= TIE_FLAG; return h; }
+#else
+// (The Acc goes by reference: handing over the ten values the walk needs one by one cost the Cornell box 11 % instead of 2 %.)
+__device__ __noinline__ Hit tie_resolve(const Acc& A, D3 wo, D3 wd, double t_min, double t_max, Hit) {
+    Acc G = A;  // the program's tables in global memory: the accel kernels stage other things, or nothing, into LDS
+    const uint32_t* tv = A.tie_view;
+    const char* g = (const char*)tv - tv[6];
+    G.meta = (const uint2*)(g + tv[0]);
+    G.boxes = (const double2*)(g + tv[1]);
+    G.spheres = (const double2*)(g + tv[2]);
+    G.rects = (const double2*)(g + tv[3]);
+    G.tripre = (const double2*)(g + tv[4]);
+    G.xforms = (const double*)(g + tv[5]);
+    G.n_nodes = tv[7];
+    return traverse<GENERAL, false>(G, wo, wd, t_min, t_max);
+}
+#endif
 
 // ---------------------------------------------------------------- kernel 2 traversal ----
 // Conservative f32 slab test of one child box of a Node2: 6 fma + 6 min/max + max3/min3 + one multiply.
@@ -783,7 +793,8 @@ DEV double track_bound(const MediaTrack& K, double best) {
 }
 // ENTER: instance items may be entered in the lane (always, unless DEFER; with DEFER only in the MIXED variants of kernels 5 / 6,
 // for the NK_INSTANCE_INLINE items of scenes that have any: compiling the enter path into their world-space walk costs C4 6 %).
-template <int GENERAL, bool DEFER = false, bool TOP = true, bool WIDE = false, class PEND = uint32_t, bool LIMIT = false, bool ENTER = !DEFER, bool TRACK = false>
+// RESOLVE: an exact tie (TIE_FLAG) is settled before returning; false: the caller does it (traverse2_media: one call site for its two walks).
+template <int GENERAL, bool DEFER = false, bool TOP = true, bool WIDE = false, class PEND = uint32_t, bool LIMIT = false, bool ENTER = !DEFER, bool TRACK = false, bool RESOLVE = true>
 DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, double t_min, double t_max, PEND* pend = nullptr, uint32_t order_limit = 0xFFFFFFFFu,
                   MediaTrack* track = nullptr) {
     D3 o = wo, d = wd;
@@ -794,8 +805,8 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
     h.xf = -1;
     h.kp = 0;
     int cur_xf = -1;
-    volatile TieNote tie;  // (see "EXACT ties" above)
-    tie.later = -2;
+    // exact ties are settled here unless the walk defers instances (kernels 5 / 6) or sees only a part of the scene (LIMIT: only t is used)
+    constexpr bool TIE = TIE_RULE && GENERAL != 0 && !DEFER && !LIMIT && !(TRACK && RT_TIE_NOTRACK);
     Ray32 r = make_ray32(o, d, t_min, t_max);
     float best_all32 = r.best;  // TRACK: the best hit's own (outward-rounded) t, beside r.best = the track bound
     if (WIDE) ray32_wide_addr(r, A.n2w_lds);
@@ -927,23 +938,28 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
                     if (got) {
                         if (it.y < track->lim[0] && t < track->T[0]) track->T[0] = t;
                         if (it.y < track->lim[1] && t < track->T[1]) track->T[1] = t;
-                        if (t == h.t && h.node >= 0 && (int)it.y != h.node) tie_note(&tie, (int)it.y, cur_xf, it.x + (cube_side << NK_BITS), h);
                         if (t < h.t || (t == h.t && (int)it.y > h.node) || !(t == t)) {  // (a candidate may lie beyond the best hit here)
+                            const bool tied = TIE && t == h.t && h.node >= 0;
                             h.t = t;
                             h.node = (int)it.y;
-                            h.xf = cur_xf;
+                            h.xf = tied ? (cur_xf ^ TIE_FLAG) : cur_xf;
                             h.kp = it.x + (cube_side << NK_BITS);
                             best_all32 = ray32_best(t);
+                        } else if (TIE && t == h.t && (int)it.y < h.node && !tie_flagged(h.xf)) {  // the candidate is the earlier party
+                            h.xf ^= TIE_FLAG;
                         }
                         r.best = ray32_best(track_bound(*track, h.t));
                     }
                 } else if (got) {
                     // accepted candidates satisfy t <= h.t; an exact tie goes to the later one in reference order (and is noted: tie_resolve)
-                    if (t == h.t && h.node >= 0 && (int)it.y != h.node) tie_note(&tie, (int)it.y, cur_xf, it.x + (cube_side << NK_BITS), h);
-                    if (!(t < h.t || (int)it.y > h.node || !(t == t))) continue;
+                    if (!(t < h.t || (int)it.y > h.node || !(t == t))) {
+                        if (TIE && (int)it.y < h.node && !tie_flagged(h.xf)) h.xf ^= TIE_FLAG;  // t == h.t and the candidate is the earlier party
+                        continue;
+                    }
+                    const bool tied = TIE && t == h.t && h.node >= 0;
                     h.t = t;
                     h.node = (int)it.y;
-                    h.xf = cur_xf;
+                    h.xf = tied ? (cur_xf ^ TIE_FLAG) : cur_xf;
                     h.kp = it.x + (cube_side << NK_BITS);
                     r.best = ray32_best(t);
                 }
@@ -992,13 +1008,7 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
         PH_END(9, ph_leaf0);
     }
     // the last exact tie noted, if its later party is still the hit: would the reference have visited that object at all?
-    if (GENERAL && h.node >= 0 && tie.later == h.node) {
-        if (!ref_box_visited(A.parent_box, A.gboxes, A.xforms, h.node, h.xf, wo, wd, t_min, h.t)) {
-            h.node = tie.earlier;
-            h.xf = tie.earlier_xf;
-            h.kp = tie.earlier_kp;
-        }
-    }
+    if (TIE && RESOLVE && tie_flagged(h.xf)) h = tie_resolve<GENERAL>(A, wo, wd, t_min, t_max, h);
     return h;
 }
 
@@ -1083,8 +1093,9 @@ DEV Hit traverse2_media(const Acc& A, uint32_t n_media, uint32_t* stk, const int
         }
     }
     // 2. the accel walk
-    const Hit S = (tk0 != 0xFFFFFFFFu) ? traverse2<GENERAL, false, TOP, WIDE, uint32_t, false, true, true>(A, stk, stride, o, d, t_min, INFINITY, nullptr, 0xFFFFFFFFu, &K)
-                                       : traverse2<GENERAL, false, TOP, WIDE>(A, stk, stride, o, d, t_min, INFINITY);
+    Hit S = (tk0 != 0xFFFFFFFFu) ? traverse2<GENERAL, false, TOP, WIDE, uint32_t, false, true, true, false>(A, stk, stride, o, d, t_min, INFINITY, nullptr, 0xFFFFFFFFu, &K)
+                                 : traverse2<GENERAL, false, TOP, WIDE, uint32_t, false, true, false, false>(A, stk, stride, o, d, t_min, INFINITY);
+    if (TIE_RULE && GENERAL && tie_flagged(S.xf)) S = tie_resolve<GENERAL>(A, o, d, t_min, INFINITY, S);  // two surfaces share the best t ("EXACT ties" above)
     // 3. the media in the reference's order
     Hit best = S;
     double t_med = INFINITY;  // t of the latest accepted medium hit
@@ -3961,6 +3972,8 @@ void render_sppm(const rt_scene& s, const CameraDev& cam, RenderPlan plan, const
     if (s.lights.empty()) throw RtError(RT_ERR_ARG, "SPPM needs lights (rt_scene_set_lights)");
     if (s.flat.view.kinds_mask & (1u << NK_MEDIUM_BEGIN))
         throw RtError(RT_ERR_UNSUPPORTED, "the SPPM pre-pass does not support ConstantMedium (volume events have no photon-map estimate)");
+    if (s.flat.view.n_msph != 0u || s.flat.view.has_noise != 0u || plan.time1 > plan.time0)
+        throw RtError(RT_ERR_UNSUPPORTED, "the photon passes have no notion of time: the book-2 extensions (moving spheres, noise textures, an open shutter) render with integrator 0");
     if (cfg.iterations < 1 || cfg.photons_per_iter < 1 || cfg.k_global < 1 || cfg.k_caustic < 1 || cfg.max_bounces < 1 || !(cfg.alpha > 0.))
         throw RtError(RT_ERR_ARG, "bad rt_sppm_config");
     hipStream_t stream = (hipStream_t)stream_;

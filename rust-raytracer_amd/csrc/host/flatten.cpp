@@ -23,8 +23,6 @@ namespace {
 struct Builder {
     rt_scene& s;
     std::vector<uint32_t> meta;
-    std::vector<uint32_t> parent_box;                       // per program node (see FlatView::off_parent_box)
-    std::vector<std::pair<uint32_t, int>> box_stack;        // enclosing BVHNode boxes: (box index, xf_depth it was emitted at)
     std::vector<double> boxes, spheres, rects, xforms, vpos, vnrm;
     std::vector<int32_t> sphere_mat, rect_mat;
     std::vector<uint32_t> tris;
@@ -76,7 +74,6 @@ struct Builder {
         if (payload >= (1u << (32 - NK_BITS))) throw RtError(RT_ERR_UNSUPPORTED, "scene too large for 28-bit payload index");
         meta.push_back(kind | (payload << NK_BITS));
         meta.push_back(skip);
-        parent_box.push_back(box_stack.empty() ? 0xFFFFFFFFu : (box_stack.back().first | ((box_stack.back().second < xf_depth) ? 0x80000000u : 0u)));
         kinds |= 1u << kind;
         return (uint32_t)(meta.size() / 2 - 1);
     }
@@ -169,10 +166,8 @@ struct Builder {
                 boxes.insert(boxes.end(), {o.box.mn[0], o.box.mn[1], o.box.mn[2], o.box.mx[0], o.box.mx[1], o.box.mx[2]});
                 uint32_t n = node(NK_BOX, bi);
                 if (bi >= 0x7FFFFFFFu) throw RtError(RT_ERR_UNSUPPORTED, "too many BVH nodes");
-                box_stack.emplace_back(bi, xf_depth);
                 emit(o.children[0]);
                 emit(o.children[1]);
-                box_stack.pop_back();
                 meta[2 * n + 1] = (uint32_t)(meta.size() / 2);
                 break;
             }
@@ -703,7 +698,13 @@ void flatten(rt_scene& s) {
     for (auto& tx : s.textures) v.has_noise |= (tx.type == TEX_NOISE) ? 1u : 0u;
     v.off_msph = append(f.blob, b.msph);
     v.n_msph = (uint32_t)(b.msph.size() / 10);
-    v.off_parent_box = append(f.blob, b.parent_box);
+    {   // where the reference-order program lies in the blob, for the one walk that must read it from global memory whatever the
+        // kernel staged (tie_resolve, kernels.hip); the last word is the record's own offset
+        std::vector<uint32_t> tv = {v.off_meta, v.off_boxes, v.off_spheres, v.off_rects, v.off_tripre, v.off_xforms, 0u, (uint32_t)(b.meta.size() / 2)};
+        f.blob.resize((f.blob.size() + 15) & ~size_t(15));
+        tv[6] = (uint32_t)f.blob.size();
+        v.off_tie_view = append(f.blob, tv);
+    }
     v.off_lights = append(f.blob, lights);
     v.n_lights = (uint32_t)(lights.size() / 2);
     v.off_vpos = append(f.blob, b.vpos);  // kept for introspection; the kernels read tripre instead
