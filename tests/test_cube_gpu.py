@@ -126,8 +126,9 @@ def test_cube_hit_records_match_the_six_rectangle_scan(variant, as_list):
     assert nhit > len(rays) // 3 and nuv > 10
     finite = np.isfinite(outs[1][:, 1]) & np.isfinite(outs[2][:, 1]) & np.array([not any(r[3 + a] == 0.0 and r[a] in planes[a] for a in range(3)) for r in rays])
     # incl. the winning node's reference-order index: on an EXACT tie (a rectangle lying on a cube's face, the face two stacked cubes share) the
-    # accel kernels ask whether the reference would have visited the later object at all -- its BVHNode::hit culls a box that BEGINS at the tied t
-    # (bvh.rs:88, aabb.rs:28-30) -- and so agree with the reference-order kernel and the oracle (tie_candidate_wins, kernels.hip)
+    # accel kernels flag the hit and let the reference-order walk decide (the reference's BVHNode::hit culls a box that BEGINS at the tied t --
+    # bvh.rs:88, aabb.rs:28-30 -- so the later object may never be visited) and so agree with the reference-order kernel and the oracle
+    # (tie_resolve, kernels.hip)
     # (the index itself may name the other of two emissions of ONE object -- BVHNode::new puts a single object into both children, Q14: the
     # reference's second visit is culled by the same rule once the first has set closest-so-far to the box's entry, the accel keeps one
     # item with the later index -- so the records are compared without it, and the indices where no object is emitted twice)

@@ -2,7 +2,8 @@
 # End-of-round records, all measured on ONE build, in one GPU call: PMC model of the headline kernel and of every BASELINE configuration,
 # the configuration table with its roofline objects, the bench lines (default, under rocprofv3 --kernel-trace --stats, forced RCCL process
 # group at world 1, 2-rank rehearsal, single-process rt_render_multi), the share-scaling rehearsal, the phase statistics.
-#   tools/final_records.sh            on the GPU box (gpurun): writes gpurun_out/final/
+#   tools/final_records.sh [pmc|rest] on the GPU box (gpurun): writes gpurun_out/final/ (pmc: the counter passes only; rest: everything
+#                                     after them, with the models the pmc stage left in profiles/ -- two calls fit gpurun's time limit)
 #   tools/final_records.sh collect R  here, afterwards: copies what came back into profiles/rR/ and profiles/pt_kernel_model.json
 set -o pipefail
 cd "$(dirname "$0")/.."
@@ -10,7 +11,7 @@ export TMPDIR=/tmp
 if [ "$1" = collect ]; then
   R=profiles/r$2; mkdir -p $R
   cp gpurun_out/pmc_headline/model_headline.json profiles/pt_kernel_model.json
-  for c in headline scene_10 scene_500_c2 cornell cornell_mix c4 c5r; do
+  for c in headline scene_10 scene_500_c2 cornell cornell_mix c4 c5r c5; do
     [ -f gpurun_out/pmc_$c/model_$c.json ] && cp gpurun_out/pmc_$c/model_$c.json gpurun_out/pmc_$c/pmc_summary_$c.csv $R/
   done
   cp gpurun_out/final/*.json gpurun_out/final/*.csv gpurun_out/final/*.txt $R/ 2>/dev/null
@@ -18,10 +19,15 @@ if [ "$1" = collect ]; then
   ls $R | wc -l
   exit 0
 fi
-OUT=gpurun_out/final; rm -rf $OUT; mkdir -p $OUT
+OUT=gpurun_out/final; STAGE=${1:-all}
+if [ "$STAGE" = all ] || [ "$STAGE" = pmc ]; then
+rm -rf $OUT; mkdir -p $OUT
 echo "== headline PMC (the bench workload itself, 1000 spp)"; tools/pmc_passes.sh headline 2>&1 | tail -1 || exit 1
 mkdir -p profiles; cp gpurun_out/pmc_headline/model_headline.json profiles/pt_kernel_model.json   # (so that the bench lines below carry this build's model)
-echo "== config PMC"; for c in scene_10 scene_500_c2 cornell cornell_mix c4 c5r; do tools/pmc_passes.sh $c 2>&1 | tail -1 || exit 1; mkdir -p profiles/r04; cp gpurun_out/pmc_$c/model_$c.json profiles/r04/model_$c.json; done
+echo "== config PMC"; for c in scene_10 scene_500_c2 cornell cornell_mix c4 c5r c5; do tools/pmc_passes.sh $c 2>&1 | tail -1 || exit 1; mkdir -p profiles/r04; cp gpurun_out/pmc_$c/model_$c.json profiles/r04/model_$c.json; done
+fi
+[ "$STAGE" = pmc ] && exit 0
+mkdir -p $OUT
 echo "== config bench"; timeout -k 10 900 python3 tools/config_bench.py > $OUT/config_bench.log 2>&1 || { tail -5 $OUT/config_bench.log; exit 1; }
 cp gpurun_out/config_bench.json $OUT/config_bench_1gpu.json
 echo "== bench records"

@@ -8,8 +8,8 @@ set -o pipefail
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 NAME=$1
-declare -A SPP=( [headline]=1000 [scene_10]=100 [scene_500_c2]=500 [cornell]=2000 [cornell_mix]=2000 [c4]=1000 [c5r]=500 )
-declare -A PIX=( [headline]=$((1200*1200)) [scene_10]=$((400*225)) [scene_500_c2]=$((1200*800)) [cornell]=$((800*800)) [cornell_mix]=$((800*800)) [c4]=$((1200*1200)) [c5r]=$((1600*1600)) )
+declare -A SPP=( [headline]=1000 [scene_10]=100 [scene_500_c2]=500 [cornell]=2000 [cornell_mix]=2000 [c4]=1000 [c5r]=500 [c5]=500 )
+declare -A PIX=( [headline]=$((1200*1200)) [scene_10]=$((400*225)) [scene_500_c2]=$((1200*800)) [cornell]=$((800*800)) [cornell_mix]=$((800*800)) [c4]=$((1200*1200)) [c5r]=$((1600*1600)) [c5]=$((1600*1600)) )
 S=${2:-${SPP[$NAME]}}
 OUT=gpurun_out/pmc_$NAME; rm -rf $OUT; mkdir -p $OUT
 if [ "$NAME" = headline ]; then CMD="python3 bench.py --steps 1 --warmup 0 --spp $S --cpu-spp 0"; N=$(( ${PIX[$NAME]} * S )); else CMD="python3 tools/config_run.py $NAME $S"; N=$(( ${PIX[$NAME]} * (S + 2) )); fi
