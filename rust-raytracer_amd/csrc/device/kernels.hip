@@ -1031,11 +1031,13 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
 // rec1 = boundary.hit(r, -inf, +inf); rec2 = boundary.hit(r, rec1.t + 0.0001, +inf) (medium.rs:26-27): false unless both exist.
 // Any other boundary: the reference-order walk over the medium's own copies of the boundary subtree, out of line (two inlined walks in
 // the middle of traverse2_media cost the MEDIA kernels registers whether a scene has such a boundary or not: C5 as named +6.5 %).
+template <int GENERAL>
 __device__ __noinline__ Hit walk_program(const Acc& A, D3 o, D3 d, double t_min, double t_max, uint32_t n0, uint32_t n1) {
-    return traverse<true, false>(A, o, d, t_min, t_max, nullptr, n0, n1);
+    return traverse<GENERAL, false>(A, o, d, t_min, t_max, nullptr, n0, n1);
 }
 // A boundary that is one world-space sphere (MediumDev::boundary_kp) is asked directly -- the walk over its one-node subtree would make
 // exactly these two Sphere::hit calls, after three f64 divisions for box tests that never come.
+template <int GENERAL>
 DEV bool medium_boundary(const Acc& A, const MediumDev& M, D3 o, D3 d, double& t_a, double& t_b) {
     if (M.boundary_kp != 0u) {
         // Both Sphere::hit calls (sphere.rs:24-43) see the same ray and sphere, so oc, half_b, c, the discriminant and its root are the
@@ -1063,9 +1065,9 @@ DEV bool medium_boundary(const Acc& A, const MediumDev& M, D3 o, D3 d, double& t
         t_b = tb;
         return true;
     }
-    const Hit r1h = walk_program(A, o, d, -INFINITY, INFINITY, M.n_begin + 1u, M.n_mid);
+    const Hit r1h = walk_program<GENERAL>(A, o, d, -INFINITY, INFINITY, M.n_begin + 1u, M.n_mid);
     if (r1h.node < 0) return false;
-    const Hit r2h = walk_program(A, o, d, r1h.t + 0.0001, INFINITY, M.n_mid + 1u, M.n_end);
+    const Hit r2h = walk_program<GENERAL>(A, o, d, r1h.t + 0.0001, INFINITY, M.n_mid + 1u, M.n_end);
     if (r2h.node < 0) return false;
     t_a = r1h.t;
     t_b = r2h.t;
@@ -1086,7 +1088,7 @@ DEV Hit traverse2_media(const Acc& A, uint32_t n_media, uint32_t* stk, const int
     for (uint32_t k = 0; k < n_media; k++) {
         const MediumDev M = A.media[k];
         double qa, qb;
-        if (!medium_boundary(A, M, o, d, qa, qb)) continue;
+        if (!medium_boundary<GENERAL>(A, M, o, d, qa, qb)) continue;
         if (tk0 == 0xFFFFFFFFu) {
             tk0 = k; ta0 = qa; tb0 = qb;
             K.lim[0] = M.n_begin; K.exitt[0] = qb;
@@ -1115,7 +1117,7 @@ DEV Hit traverse2_media(const Acc& A, uint32_t n_media, uint32_t* stk, const int
             t_max = fmin(t_max, (k == tk0) ? K.T[0] : K.T[1]);
         } else if (k >= k_rest) {  // a third, fourth ... crossed medium: its own queries, and a restricted walk where needed
             M = A.media[k];
-            if (!medium_boundary(A, M, o, d, t_a, t_b)) continue;
+            if (!medium_boundary<GENERAL>(A, M, o, d, t_a, t_b)) continue;
             if (S.node >= 0) {
                 if ((uint32_t)S.node < M.n_begin) {
                     t_max = fmin(t_max, S.t);

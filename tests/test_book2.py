@@ -171,6 +171,38 @@ def test_motion_blur_and_marble_render_bit_exact(kernel, shutter):
         assert not np.array_equal(mix, still)
 
 
+def _fog_scene(B):
+    """media in a book-2 scene: a fog whose boundary MOVES (the two boundary queries walk the medium's copies of the subtree with the ray's
+    time), one in a cube (general boundary: out-of-line program walk) and one in a fixed sphere (asked directly)"""
+    items = _scene(B)[:3] + _scene(B)[5:]
+    items.append(B.ConstantMedium(0.9, B.MovingSphere((1.0, 1.2, 1.0), (2.5, 1.2, 1.0), 0.0, 1.0, 1.1, B.Lambertian(B.ConstantTexture((1.0, 1.0, 1.0)))),
+                                  B.Isotropic(B.ConstantTexture((0.9, 0.9, 0.2)))))
+    items.append(B.ConstantMedium(0.6, B.Cube((-1.5, 0.0, -4.0), (0.5, 1.8, -2.5), B.Lambertian(B.ConstantTexture((1.0, 1.0, 1.0)))),
+                                  B.Isotropic(B.ConstantTexture((0.2, 0.8, 0.9)))))
+    items.append(B.ConstantMedium(0.004, B.Sphere((0.0, 0.0, 0.0), 30.0, B.Lambertian(B.ConstantTexture((1.0, 1.0, 1.0)))),
+                                  B.Isotropic(B.ConstantTexture((1.0, 1.0, 1.0)))))
+    return items
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kernel", [0, 1, 2])
+def test_fog_with_a_moving_boundary_renders_bit_exact(kernel):
+    import oracle
+    import rtamd
+    w = rtamd.World()
+    w.new(_fog_scene(w), bvh_seed=7)
+    o = oracle.Scene()
+    o.World(_fog_scene(o), 7)
+    cam = ((0.0, 3.0, -9.0), (0.0, 1.0, 0.0), (0.0, 1.0, 0.0), 40.0, 4.0 / 3.0, 0.1, 9.0)
+    o.Camera(*cam)
+    o.set_shutter(0.0, 1.0)
+    f, t, up, vfov, asp, ap, fd = cam
+    img, st = w.render(rtamd.Camera((f, t), up, vfov, asp, ap, fd), width=80, height=60, spp=10, seed=5, kernel=kernel, shutter=(0.0, 1.0))
+    exp, _ = o.render(80, 60, 10, seed=5)
+    assert np.array_equal(img, exp, equal_nan=True), "%d pixels differ" % int((img != exp).any(axis=2).sum())
+    assert img.max() > 0 and (kernel == 0 or st["kernel_used"] == kernel)
+
+
 @pytest.mark.gpu
 def test_an_open_shutter_shifts_the_stream_of_every_scene_alike():
     """scene_500 (spheres only: the sphere-only kernel variants) with an open shutter: the time draw is made although nothing moves"""
