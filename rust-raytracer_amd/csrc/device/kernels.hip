@@ -480,6 +480,9 @@ struct Hit {
 #ifndef RT_TIE_NOTRACK
 #define RT_TIE_NOTRACK 0
 #endif
+#ifndef RT_TIE_DEFER
+#define RT_TIE_DEFER 0
+#endif
 #define TIE_FLAG 0x40000000  // in Hit::xf (-1 or a small index): bits 30 and 31 differ <=> the hit is an exact tie of two objects
 DEV bool tie_flagged(int xf) { return (((uint32_t)xf >> 30) & 1u) != ((uint32_t)xf >> 31); }
 
@@ -806,7 +809,7 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
     h.kp = 0;
     int cur_xf = -1;
     // exact ties are settled here unless the walk defers instances (kernels 5 / 6) or sees only a part of the scene (LIMIT: only t is used)
-    constexpr bool TIE = TIE_RULE && GENERAL != 0 && !DEFER && !LIMIT && !(TRACK && RT_TIE_NOTRACK);
+    constexpr bool TIE = TIE_RULE && GENERAL != 0 && (!DEFER || RT_TIE_DEFER) && !LIMIT && !(TRACK && RT_TIE_NOTRACK);
     Ray32 r = make_ray32(o, d, t_min, t_max);
     float best_all32 = r.best;  // TRACK: the best hit's own (outward-rounded) t, beside r.best = the track bound
     if (WIDE) ray32_wide_addr(r, A.n2w_lds);
