@@ -259,6 +259,9 @@ def single_process(args):
            "roofline": roof, "roofline_contract": contract}
     if hbm is not None:
         out["roofline_hbm"] = hbm
+    if len(set(devices)) < len(devices):  # ranks that share a device queue behind each other: a rank's kernel time then contains its neighbours'
+        out["rehearsal"] = "%d ranks on %d device(s): kernel times of ranks that share a device overlap; the roofline objects are not utilisations, NOT a scaling measurement" % (len(devices), len(set(devices)))
+        out["roofline"]["frac"] = None
     if args.frame_out:
         import numpy as np
         np.save(args.frame_out, img)

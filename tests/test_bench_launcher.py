@@ -182,6 +182,7 @@ def test_single_process_mode_renders_through_rt_render_multi(tmp_path):
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["launch"] == "single-process" and out["n_gpus"] == 1 and out["value"] > 0 and out["rccl_version"] >= 20000
     assert [x["device"] for x in out["ranks"]] == [0, 0] and sum(x["samples"] for x in out["ranks"]) == 96 * 72 * 8 * 2
+    assert "rehearsal" in out and out["roofline"]["frac"] is None     # ranks that share a device: the line says it is no utilisation figure
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
         assert k in out, k
     assert np.array_equal(np.load(out_npy), _plain_frame(96, 72, 8))

@@ -42,7 +42,7 @@ python3 - <<PY
 import json
 for n in ("bench_default", "bench_under_rocprof", "bench_forced_rccl_world1", "bench_rehearsal_2ranks_on_1gpu", "bench_single_process_1gpu", "bench_single_process_2ranks_on_1gpu"):
     d = json.load(open("$OUT/%s.json" % n))
-    print("%-40s %8.1f Msamples/s  %7.2f ms/step  frac %s" % (n, d["value"], d["ms_per_step"], d["roofline"].get("frac")))
+    print("%-40s %8.1f Msamples/s  %7.2f ms/step  frac %s%s" % (n, d["value"], d["ms_per_step"], d["roofline"].get("frac"), "  (rehearsal)" if "rehearsal" in d else ""))
 PY
 echo "== share scaling (rank 0's share of the headline frame, kernel ms, best of 3)"
 for W in 1 2 4 8 16; do timeout 200 python3 tools/share_repeat.py $W 1000 3 2>/dev/null | tail -1; done | tee $OUT/share_scaling.txt
