@@ -94,7 +94,10 @@ typedef struct rt_params {
                             6 = the same service across the whole GPU and across launches (parked paths in HBM pools, a
                             dedicated walk launch per cycle; 1..64 instances; by request only -- it is slower than
                             kernel 5; workspace within rt_tuning.wf_workspace_mb, default 1.9 GB).
-                            All give bit-identical images (same f64 primitive tests, same tie rule). */
+                            All give bit-identical images (same f64 primitive tests, same tie rule) -- with one documented exception:
+                            when two objects share the closest t EXACTLY and the reference's own BVHNode box test would have culled
+                            the later one (a Cube face coplanar with another surface), kernels 1 / 2 follow the reference, kernels
+                            5 / 6 give the hit to the later object. */
     int32_t device;      /* HIP device ordinal; -1 = current */
     int32_t integrator;  /* 0 = sample_ray as the reference structures it (BSDF sampling only; default);
                             1 = light importance sampling: on Diffuse hits the direction is drawn from the
