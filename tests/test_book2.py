@@ -259,3 +259,26 @@ def test_final_scene_as_named_bit_exact(kernel):
     assert st["kernel_used"] == (2 if kernel == 0 else kernel)
     red, _ = w.render(cam, width=80, height=80, spp=6, seed=1, kernel=kernel)          # shutter closed: the sphere stands at center0, but the marble stays
     assert not np.array_equal(red, img)
+
+
+@pytest.mark.gpu
+def test_final_scene_as_named_full_size_windows_match_the_oracle():
+    """C5 as BASELINE words it at its own frame size (1600 x 1600, shutter [0, 1); 500 of its 4 000 spp, what the configuration table times):
+    five 8 x 8 windows spread over the frame equal the oracle's values bit for bit
+    (the in-kernel fold in sample order at this size, the time draws, the MEDIA + book-2 kernel variant with the tables in L2)."""
+    import oracle
+    import rtamd
+    from rtamd import shapes
+    w = rtamd.World()
+    w.new(shapes.final_scene(w), bvh_seed=3)
+    o = oracle.Scene()
+    o.World(shapes.final_scene(o), 3)
+    o.Camera(*shapes.FINAL_SCENE_CAMERA)
+    o.set_shutter(*shapes.FINAL_SCENE_SHUTTER)
+    f, t, up, vfov, asp, ap, fd = shapes.FINAL_SCENE_CAMERA
+    img, st = w.render(rtamd.Camera((f, t), up, vfov, asp, ap, fd), width=1600, height=1600, spp=500, seed=1, shutter=shapes.FINAL_SCENE_SHUTTER)
+    assert st["samples"] == 1600 * 1600 * 500 and st["kernel_used"] == 2 and np.isfinite(img).all()
+    for (x0, y0) in [(560, 440), (1040, 1000), (800, 1400), (320, 160), (1200, 600)]:
+        exp, _ = o.render(1600, 1600, 500, seed=1, window=(x0, y0, x0 + 8, y0 + 8), n_jobs=8)
+        assert np.array_equal(img[y0:y0 + 8, x0:x0 + 8], exp), "window at (%d, %d)" % (x0, y0)
+
