@@ -190,11 +190,14 @@ def roofline_objects(stats_acc, dt_kernel_s, clock_note=None, model_path=None, a
                      # the counter that does not depend on any cycle table: 4 * SQ_ACTIVE_INST_VALU / SIMD cycles of the PMC pass
                      "valu_busy_measured": model.get("valu_busy_measured"),
                      "cost_table": {"cycles_per_wave64_instruction": model.get("valu_class_cycles"),
-                                    "measured_classes": "f32 add/mul/fma, f64 add/mul/fma/ldexp/div_fixup, conversions, v_mul_lo_u32, integer add/xor/shift/alignbit, "
-                                                        "compare + v_cndmask, f32 min/max, f32 and f64 rcp/rsq/sqrt (tools/microbench/valu_cost.hip, "
-                                                        "profiles/r03/valu_cost_microbench.txt; anchored on f64 fma = 4 cycles)",
-                                    "unmeasured_priced_as_other": "v_mov, v_readlane / v_writelane (SGPR spill moves), LDS-address adds, v_perm / bfe: priced at "
-                                                                  "the 3.5-cycle average of the measured integer / compare classes"},
+                                    "measured_classes": "ns per wave-instruction per SIMD converted with f64 fma = 4 cycles: f32 add/mul/fma 2.5, f64 add/mul/fma/ldexp/div_fixup 4.0, "
+                                                        "conversions 3.8 (SDWA halves 3.5), v_mul_lo_u32 3.9, integer add/xor/and/or/shift/alignbit/lshl_add/bfe 3.2-3.3, "
+                                                        "compare 3.5, v_cndmask 3.6 (3.25 paired with a compare), f32 min/max 3.7, min3/max3 3.6, v_mov 2.2, "
+                                                        "v_readlane / v_writelane 3.5, 64-bit add 2 x 3.7, f32 rcp/rsq/sqrt 7.0, f64 rcp/rsq/sqrt 13.7 "
+                                                        "(tools/microbench/valu_cost.hip, profiles/r04/valu_cost_microbench.txt; 1024 threads per CU, independent streams)",
+                                    "other_class": "the model's 'other' (SQ_INSTS_VALU minus the typed counters: moves, compares, selects, integer and address "
+                                                   "arithmetic, min/max, lane moves) is priced at 3.5 cycles; every member is measured since round 4 and lies "
+                                                   "between 2.2 (v_mov) and 3.7; at an average of 3.3 the headline's frac would read 0.86 instead of 0.89"},
                      "useful_frac": frac * model["lane_utilisation"] if frac else None,
                      "valu_insts_per_sample": ipc, "valu_issue_cycles_per_inst": cyc, "clock_ghz": clk, "clock_ghz_in_pmc_pass": model["clock_ghz"],
                      "valu_mix_per_sample": model.get("valu_mix_per_sample"),

@@ -27,6 +27,15 @@ __global__ void __launch_bounds__(1024) k(unsigned long long* out, int iters, do
         if (OP == 9) { REP64(asm volatile("v_add_f64 %0, %4, %0\n v_mul_f64 %1, %4, %1\n v_add_f64 %2, %5, %2\n v_mul_f64 %3, %5, %3" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(a), "v"(b));) }
         if (OP == 10) { REP64(asm volatile("v_cmp_lt_f32 vcc, %4, %0\n v_cndmask_b32 %1, %4, %1, vcc\n v_cmp_lt_f64 vcc, %6, %7\n v_cndmask_b32 %3, %5, %3, vcc" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3) : "v"(fa), "v"(fb), "v"(a), "v"(b) : "vcc");) }
         if (OP == 11) { REP64(asm volatile("v_ldexp_f64 %0, %4, 3\n v_div_fixup_f64 %1, %4, %5, %1\n v_ldexp_f64 %2, %5, 2\n v_div_fixup_f64 %3, %5, %4, %3" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(a), "v"(b));) }
+        // round 4: the members of the model's "other" class that round 3 priced at the class average without measuring them
+        if (OP == 12) { REP64(asm volatile("v_mov_b32 %0, %4\n v_mov_b32 %1, %5\n v_mov_b32 %2, %4\n v_mov_b32 %3, %5" : "=v"(u0), "=v"(u1), "=v"(u2), "=v"(u3) : "v"(ua), "v"(fa));) }
+        if (OP == 13) { REP64(asm volatile("v_writelane_b32 %0, s20, 3\n v_readlane_b32 s21, %1, 5\n v_writelane_b32 %2, s20, 7\n v_readlane_b32 s22, %3, 9" : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3) : : "s20", "s21", "s22");) }
+        if (OP == 14) { REP64(asm volatile("v_min3_f32 %0, %4, %5, %0\n v_max3_f32 %1, %4, %5, %1\n v_min3_f32 %2, %5, %4, %2\n v_max3_f32 %3, %5, %4, %3" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3) : "v"(fa), "v"(fb));) }
+        if (OP == 15) { REP64(asm volatile("v_and_b32 %0, %4, %0\n v_or_b32 %1, %4, %1\n v_lshl_add_u32 %2, %4, 2, %2\n v_bfe_u32 %3, %4, 3, 9" : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3) : "v"(ua));) }
+        if (OP == 16) { REP64(asm volatile("v_cndmask_b32_e64 %0, %4, %0, s[20:21]\n v_cndmask_b32_e64 %1, %4, %1, s[22:23]\n v_cndmask_b32_e64 %2, %4, %2, s[20:21]\n v_cndmask_b32_e64 %3, %4, %3, s[22:23]" : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3) : "v"(ua) : "s20", "s21", "s22", "s23");) }
+        if (OP == 17) { REP64(asm volatile("v_cmp_lt_f32 vcc, %4, %0\n v_cmp_gt_u32 vcc, %5, %1\n v_cmp_nlt_f32 s[20:21], %4, %2\n v_cmp_ngt_f32 s[22:23], %4, %3" : : "v"(f0), "v"(u1), "v"(f2), "v"(f3), "v"(fa), "v"(ua) : "vcc", "s20", "s21", "s22", "s23");) }
+        if (OP == 18) { REP64(asm volatile("v_add_co_u32 %0, vcc, %4, %0\n v_addc_co_u32 %1, vcc, %4, %1, vcc\n v_add_co_u32 %2, vcc, %4, %2\n v_addc_co_u32 %3, vcc, %4, %3, vcc" : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3) : "v"(ua) : "vcc");) }
+        if (OP == 19) { REP64(asm volatile("v_cvt_f32_u32_sdwa %0, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n v_cvt_f32_u32_sdwa %1, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n v_cvt_f32_u32_sdwa %2, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n v_cvt_f32_u32_sdwa %3, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : "v"(ua));) }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     if ((threadIdx.x & 63) == 0) out[(blockIdx.x * 16 + (threadIdx.x >> 6)) * 2] = t1 - t0;
@@ -71,5 +80,13 @@ int main() {
     run<8>("v_rcp_f32 / v_sqrt_f32 / v_rsq_f32");
     run<3>("v_rcp_f64");
     run<4>("v_sqrt_f64 / v_rsq_f64");
+    run<12>("v_mov_b32");
+    run<13>("v_writelane_b32 / v_readlane_b32 (SGPR spill moves)");
+    run<14>("v_min3_f32 / v_max3_f32");
+    run<15>("v_and / v_or / v_lshl_add_u32 / v_bfe_u32");
+    run<16>("v_cndmask_b32_e64 (SGPR-pair mask)");
+    run<17>("v_cmp f32 / u32 (to vcc and to SGPR pairs)");
+    run<18>("v_add_co_u32 / v_addc_co_u32 (64-bit add)");
+    run<19>("v_cvt_f32_u32 SDWA (16-bit halves)");
     return 0;
 }
