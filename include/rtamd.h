@@ -303,6 +303,17 @@ int rt_render_sppm(const rt_scene* s, const rt_camera* cam, const rt_params* p, 
  * The call returns after the work has completed on that stream. */
 int rt_render_tiles_device(const rt_scene* s, const rt_camera* cam, const rt_params* p, double* d_tiles, void* hip_stream,
                            rt_stats* stats);
+/* Resumable / progressive rendering (checkpoint and restart of a long frame).  capture_image adds a pixel's samples in index order
+ * and divides once (camera.rs:96-102); here the running sums are the CALLER's: rt_render_accumulate_device traces the sample indices
+ * [sample_begin, sample_end) of every pixel of this rank's tiles (0 <= begin < end <= p->spp) and adds them, in index order, to d_accum
+ * (DEVICE memory, rt_tiles_owned(p)*64*3 f64; sample_begin == 0 initialises it, no zeroing needed); rt_accum_finalize_device writes
+ * d_tiles = d_accum / p->spp (0 outside the image) as rt_render_tiles_device would have.  Calls with consecutive ranges, in order, give
+ * that function's result bit for bit however the range is cut (the additions are the same sequence), so the state of an interrupted
+ * frame is d_accum and the next sample index -- the RNG is keyed by (seed, pixel, sample) and has no state to save.  p must be the
+ * same in every call (spp = the frame's total).  Kernels 1 / 2 / 5, integrators 0 / 1. */
+int rt_render_accumulate_device(const rt_scene* s, const rt_camera* cam, const rt_params* p, int32_t sample_begin, int32_t sample_end,
+                                double* d_accum, void* hip_stream, rt_stats* stats);
+int rt_accum_finalize_device(const rt_params* p, const double* d_accum, double* d_tiles, void* hip_stream);
 /* SPPM across GPUs: every rank runs the same deterministic pre-pass (photon maps + per-pixel statistics of the WHOLE
  * frame: ~0.13 s for the reference's 50 x 500 000 photons) and renders only its own tiles; the buffers are gathered and
  * stitched exactly like rt_render_tiles_device's.  (The per-pixel pre-pass statistics are only returned by rt_render_sppm.) */

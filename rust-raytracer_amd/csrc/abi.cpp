@@ -558,6 +558,47 @@ int rt_render_tiles_device(const rt_scene* s, const rt_camera* cam, const rt_par
     });
 }
 
+int rt_render_accumulate_device(const rt_scene* s, const rt_camera* cam, const rt_params* p, int32_t sample_begin, int32_t sample_end,
+                                double* d_accum, void* hip_stream, rt_stats* stats) {
+    return guard([&] {
+        REQUIRE(s && cam && p && d_accum, "null argument");
+        if (!s->committed) throw RtError(RT_ERR_NOT_COMMITTED, "rt_scene_commit has not been called");
+        if (device_count() < 1) throw RtError(RT_ERR_NO_DEVICE, "no HIP device: librtamd has no CPU fallback");
+        auto t0 = std::chrono::steady_clock::now();
+        RenderPlan pl = make_plan(p);
+        REQUIRE(sample_begin >= 0 && sample_begin < sample_end && sample_end <= pl.spp, "sample range: 0 <= begin < end <= spp");
+        REQUIRE(pl.integrator == 0 || pl.integrator == 1, "resumable rendering: integrators 0 and 1");
+        pl.s_first = sample_begin;
+        pl.s_last = sample_end;
+        pl.ext_accum = d_accum;
+        if (p->device >= 0) dev_set_device(p->device);  // (d_accum and hip_stream must belong to it)
+        CameraDev cd = make_camera(*cam);
+        if (stats) std::memset(stats, 0, sizeof(*stats));
+        render_tiles(*s, cd, pl, nullptr, hip_stream, stats);
+        if (stats) {
+            stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            uint64_t px = 0;
+            for (int64_t lt = 0; lt < pl.tiles_owned; lt++) {
+                int64_t t = lt * pl.world + pl.rank;
+                int tx = (int)(t % pl.tiles_x), ty = (int)(t / pl.tiles_x);
+                px += (uint64_t)std::min(TILE_W, pl.width - tx * TILE_W) * std::min(TILE_H, pl.height - ty * TILE_H);
+            }
+            stats->samples = px * (uint64_t)(sample_end - sample_begin);
+        }
+        return (int)RT_OK;
+    });
+}
+int rt_accum_finalize_device(const rt_params* p, const double* d_accum, double* d_tiles, void* hip_stream) {
+    return guard([&] {
+        REQUIRE(p && d_accum && d_tiles, "null argument");
+        if (device_count() < 1) throw RtError(RT_ERR_NO_DEVICE, "no HIP device: librtamd has no CPU fallback");
+        const RenderPlan pl = make_plan(p);
+        if (p->device >= 0) dev_set_device(p->device);
+        finalize_tiles(pl, d_accum, d_tiles, hip_stream);
+        return (int)RT_OK;
+    });
+}
+
 int rt_render_sppm_tiles_device(const rt_scene* s, const rt_camera* cam, const rt_params* p, const rt_sppm_config* cfg, double* d_tiles,
                                 void* hip_stream, rt_stats* stats) {
     return guard([&] {

@@ -23,6 +23,10 @@ struct RenderPlan {
     int integrator;  // 0 BSDF sampling, 1 light/cosine mixture pdf, 2 SPPM final gather (needs sppm_est)
     double time0 = 0., time1 = 0.;  // D9: the camera's shutter (time1 > time0: every sample draws a time)
     const double* sppm_est = nullptr;  // device: per pixel {caustic estimate[3], global estimate[3]}
+    // resumable rendering (rt_render_accumulate_device): only the sample indices [s_first, s_last) are traced (s_last < 0: spp) and folded
+    // into the CALLER's accumulator (device, [tiles_owned][64][3] f64 sums; s_first == 0 initialises it); no division by spp, d_tiles unused
+    int s_first = 0, s_last = -1;
+    double* ext_accum = nullptr;
 };
 
 // Renders plan.tiles_owned tiles into d_tiles (device, tile-major f64 RGB) on `stream`; blocks until done.
@@ -32,6 +36,8 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
 void render_sppm(const rt_scene& s, const CameraDev& cam, RenderPlan plan, const rt_sppm_config& cfg, double* d_tiles, double* stats_host,
                  void* stream, rt_stats* st, uint64_t* totals2);
 void assemble_frame(const RenderPlan& plan, const double* d_gathered, int64_t tiles_per_rank_stride, double* d_frame, void* stream);
+// pixel_color /= spp (camera.rs:102) of an accumulator filled by render_tiles(plan.ext_accum): d_tiles = d_accum / plan.spp inside the image, 0 outside
+void finalize_tiles(const RenderPlan& plan, const double* d_accum, double* d_tiles, void* stream);
 void debug_rng_device(uint64_t seed, uint64_t pixel, uint64_t sample, int n, uint64_t* out_host);
 void debug_rng_floats_device(uint64_t seed, uint64_t pixel, uint64_t sample, int n, double lo, double hi, double* out_gen, double* out_range);
 void debug_math_device(int op, size_t n, const double* a, const double* b, double* out);

@@ -3457,6 +3457,8 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
                                           "larger than LDS, negative t_min, or camera farther than 64x the scene extent); use kernel 0/1");
     const size_t ring_meta = ((size_t)(PT_BLOCK / 64) * (RING_UNITS * 4 + 8) + CFG_WORDS) * sizeof(uint32_t);  // ring / job bookkeeping, behind the stacks
     const size_t stack_bytes = ((kernel == 2) ? stack2_bytes : (kernel == 5) ? stack5_bytes : 0) + ring_meta + ((kernel == 5) ? coop_lds : 0);
+    if (plan.ext_accum && (kernel == 6 || plan.integrator == 2))
+        throw RtError(RT_ERR_UNSUPPORTED, "resumable rendering (rt_render_accumulate_device) runs with kernels 1 / 2 / 5 and integrators 0 / 1");
     if (kernel == 6) {
         render_tiles_wf(s, view, cam, plan, tun, d_tiles, stream, st, dev, di, stack6, n_entry6, wf_lds_pt, stack6w, wf_tables_w);
         return;
@@ -3533,14 +3535,15 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
         void* p;
     };
     char* small = (char*)lease.w->small;
-    Ptr ringp{lease.w->ring}, accum{lease.w->accum}, tickets{lease.w->tickets}, counter{small}, err{small + 16};
+    Ptr ringp{lease.w->ring}, accum{plan.ext_accum ? (void*)plan.ext_accum : lease.w->accum}, tickets{lease.w->tickets}, counter{small}, err{small + 16};
+    const int s_first = plan.ext_accum ? plan.s_first : 0, s_last = (plan.ext_accum && plan.s_last >= 0) ? plan.s_last : plan.spp;
     HIP_CHECK(hipMemsetAsync(small, 0, WS_SMALL, stream));
     Events events;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pt_ev;
     CamK ck = to_camk(cam);
     int launches = 0;
-    for (int s0 = 0; s0 < plan.spp; s0 += plan.spp_chunk) {
-        const int s1 = std::min(s0 + plan.spp_chunk, plan.spp);
+    for (int s0 = s_first; s0 < s_last; s0 += plan.spp_chunk) {
+        const int s1 = std::min(s0 + plan.spp_chunk, s_last);
         RenderK rk = {};
         rk.width = plan.width; rk.height = plan.height; rk.max_depth = plan.max_depth;
         rk.t_min = plan.t_min; rk.seed = plan.seed;
@@ -3591,7 +3594,7 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
         pt_ev.emplace_back(e0, e1);
         launches++;
     }
-    if (n_pix > 0) {
+    if (n_pix > 0 && !plan.ext_accum) {
         hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((n_pix + 255) / 256)), dim3(256), 0, stream, (const double*)accum.p, d_tiles,
                            n_pix, plan.spp, plan.width, plan.height, plan.tiles_x, plan.rank, plan.world);
         HIP_CHECK(hipGetLastError());
@@ -4160,6 +4163,17 @@ void render_sppm(const rt_scene& s, const CameraDev& cam, RenderPlan plan, const
         render_tiles(s, cam, plan, d_tiles, stream_, st);
     }
     if (st) st->reserved[0] = (uint64_t)(prepass_s * 1e6);  // SPPM pre-pass time, microseconds
+}
+
+void finalize_tiles(const RenderPlan& plan, const double* d_accum, double* d_tiles, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const int64_t n_pix = plan.tiles_owned * TILE_PIX;
+    if (n_pix > 0) {
+        hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((n_pix + 255) / 256)), dim3(256), 0, stream, d_accum, d_tiles, n_pix, plan.spp, plan.width,
+                           plan.height, plan.tiles_x, plan.rank, plan.world);
+        HIP_CHECK(hipGetLastError());
+    }
+    HIP_CHECK(hipStreamSynchronize(stream));
 }
 
 void assemble_frame(const RenderPlan& plan, const double* d_gathered, int64_t stride, double* d_frame, void* stream_) {

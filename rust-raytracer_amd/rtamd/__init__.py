@@ -153,6 +153,9 @@ _SIGS = [
                                          C.POINTER(rt_stats)]),
     ("rt_render_sppm_tiles_device", C.c_int, [C.c_void_p, C.POINTER(rt_camera), C.POINTER(rt_params), C.POINTER(rt_sppm_config), C.c_void_p,
                                               C.c_void_p, C.POINTER(rt_stats)]),
+    ("rt_render_accumulate_device", C.c_int, [C.c_void_p, C.POINTER(rt_camera), C.POINTER(rt_params), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                              C.POINTER(rt_stats)]),
+    ("rt_accum_finalize_device", C.c_int, [C.POINTER(rt_params), C.c_void_p, C.c_void_p, C.c_void_p]),
     ("rt_tiles_total", C.c_int64, [C.POINTER(rt_params)]),
     ("rt_tiles_owned", C.c_int64, [C.POINTER(rt_params)]),
     ("rt_assemble_frame_device", C.c_int, [C.POINTER(rt_params), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
@@ -513,6 +516,14 @@ class World:
                                            C.c_void_p(stream_ptr or 0), C.byref(st)))
         return st.as_dict()
 
+    def render_accumulate_device(self, camera, params, sample_begin, sample_end, d_accum_ptr, stream_ptr=None):
+        """rt_render_accumulate_device: samples [sample_begin, sample_end) of this rank's tiles are added, in index order, to the caller's
+        accumulator (raw device pointer, rt_tiles_owned * 64 * 3 f64; sample_begin == 0 initialises it) -- resumable rendering."""
+        st = rt_stats()
+        _chk(self.L.rt_render_accumulate_device(self.h, C.byref(camera.c), C.byref(params), int(sample_begin), int(sample_end), C.c_void_p(d_accum_ptr),
+                                                C.c_void_p(stream_ptr or 0), C.byref(st)))
+        return st.as_dict()
+
     def render_sppm_tiles_device(self, camera, params, d_tiles_ptr, stream_ptr=None, **sppm):
         """rt_render_sppm_tiles_device: the (replicated, deterministic) SPPM pre-pass, then this rank's tiles of the final pass.
         sppm: iterations, photons_per_iter, alpha, k_global, k_caustic, max_bounces (defaults = the reference's constants)."""
@@ -593,6 +604,11 @@ def tiles_total(params):
 def assemble_frame_device(params, d_gathered_ptr, tiles_per_rank_stride, d_frame_ptr, stream_ptr=None):
     _chk(lib().rt_assemble_frame_device(C.byref(params), C.c_void_p(d_gathered_ptr), int(tiles_per_rank_stride),
                                         C.c_void_p(d_frame_ptr), C.c_void_p(stream_ptr or 0)))
+
+
+def accum_finalize_device(params, d_accum_ptr, d_tiles_ptr, stream_ptr=None):
+    """rt_accum_finalize_device: d_tiles = d_accum / params.spp (the end of a resumable render, World.render_accumulate_device)"""
+    _chk(lib().rt_accum_finalize_device(C.byref(params), C.c_void_p(d_accum_ptr), C.c_void_p(d_tiles_ptr), C.c_void_p(stream_ptr or 0)))
 
 
 def tonemap_u8(rgb):

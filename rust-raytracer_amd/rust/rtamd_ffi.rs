@@ -245,6 +245,8 @@ extern "C" {
     pub fn rt_render_sppm(s: *const rt_scene, cam: *const rt_camera, p: *const rt_params, cfg: *const rt_sppm_config, out_rgb: *mut c_double, stats_out: *mut c_double, photons_stored: *mut u64, stats: *mut rt_stats) -> c_int;
     pub fn rt_render_tiles_device(s: *const rt_scene, cam: *const rt_camera, p: *const rt_params, d_tiles: *mut c_double, hip_stream: *mut c_void, stats: *mut rt_stats) -> c_int;
     pub fn rt_render_sppm_tiles_device(s: *const rt_scene, cam: *const rt_camera, p: *const rt_params, cfg: *const rt_sppm_config, d_tiles: *mut c_double, hip_stream: *mut c_void, stats: *mut rt_stats) -> c_int;
+    pub fn rt_render_accumulate_device(s: *const rt_scene, cam: *const rt_camera, p: *const rt_params, sample_begin: i32, sample_end: i32, d_accum: *mut c_double, hip_stream: *mut c_void, stats: *mut rt_stats) -> c_int;
+    pub fn rt_accum_finalize_device(p: *const rt_params, d_accum: *const c_double, d_tiles: *mut c_double, hip_stream: *mut c_void) -> c_int;
     pub fn rt_tiles_total(p: *const rt_params) -> i64;
     pub fn rt_tiles_owned(p: *const rt_params) -> i64;
     pub fn rt_assemble_frame_device(p: *const rt_params, d_gathered: *const c_double, tiles_per_rank_stride: i64, d_frame: *mut c_double, hip_stream: *mut c_void) -> c_int;

@@ -72,6 +72,7 @@ void assemble_frame(const RenderPlan& pl, const double* gathered, int64_t stride
             for (int c = 0; c < 3; c++) frame[((size_t)y * pl.width + x) * 3 + c] = gathered[((size_t)(r * stride + lt) * TILE_PIX + pix) * 3 + c];
         }
 }
+void finalize_tiles(const RenderPlan&, const double*, double*, void*) { none(); }
 void debug_rng_device(uint64_t, uint64_t, uint64_t, int, uint64_t*) { none(); }
 void debug_rng_floats_device(uint64_t, uint64_t, uint64_t, int, double, double, double*, double*) { none(); }
 void debug_math_device(int, size_t, const double*, const double*, double*) { none(); }

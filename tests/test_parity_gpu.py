@@ -907,3 +907,45 @@ def test_wavefront_kernel_workspace_stays_within_its_budget(tuning):
     k5, _ = w.render(cam, width=1200, height=1200, spp=8, seed=1, kernel=5)
     assert np.array_equal(k5, img)
     rtamd.release_workspaces()
+
+
+def test_resumable_render_equals_the_one_call_render(tuning):
+    """rt_render_accumulate_device / rt_accum_finalize_device (checkpoint and restart, SURVEY s5 aux): a frame rendered as consecutive sample
+    ranges into the caller's accumulator -- cut unevenly, with the accumulator taken to the host and put back between two calls as a restart
+    would, on a 3-rank tile partition too, kernels 1 / 2 / 5, both integrators -- equals rt_render_tiles_device's frame bit for bit."""
+    import torch
+    import rtamd
+    from rtamd import shapes
+    world, cam = rtamd.select_scene(scene_path("cube.obj"), 1.0, 1)
+    mesh_world = rtamd.World()
+    P, N, I = shapes.torus(24, 48)
+    mesh_world.new(shapes.cornell_with_mesh(mesh_world, P, N, I), bvh_seed=1)
+    mcam = rtamd.Camera(((278, 278, -800), (278, 278, 278)), (0, 1, 0), 50, 1.0, 0.0, 10.0)
+    cases = [(world, cam, 1, 0, 1, 0), (world, cam, 2, 0, 1, 0), (world, cam, 2, 1, 3, 1), (world, cam, 2, 0, 3, 2), (mesh_world, mcam, 5, 0, 1, 0)]
+    for w, c, kernel, integ, wsize, rank in cases:
+        p = rtamd.default_params(width=100, height=76, spp=37, seed=9, kernel=kernel, integrator=integ, rank=rank, world=wsize)
+        n = rtamd.tiles_owned(p)
+        ref = torch.zeros((n, 64, 3), dtype=torch.float64, device="cuda")
+        st = w.render_tiles_device(c, p, ref.data_ptr())
+        assert st["kernel_used"] == kernel
+        acc = torch.full((n, 64, 3), float("nan"), dtype=torch.float64, device="cuda")      # sample_begin == 0 initialises it
+        cuts = [0, 5, 6, 20, 37]
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            st = w.render_accumulate_device(c, p, a, b, acc.data_ptr())
+            assert st["kernel_used"] == kernel
+            if b == 6:                                                                      # "checkpoint": the state is the accumulator and b
+                saved = acc.cpu().clone()
+                del acc
+                acc = saved.cuda()
+        out = torch.empty((n, 64, 3), dtype=torch.float64, device="cuda")
+        rtamd.accum_finalize_device(p, acc.data_ptr(), out.data_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref), "kernel %d integrator %d rank %d/%d" % (kernel, integ, rank, wsize)
+    # refusals: a range outside the frame, the wavefront kernel, SPPM's integrator
+    p = rtamd.default_params(width=16, height=16, spp=4, kernel=2)
+    acc = torch.zeros((4, 64, 3), dtype=torch.float64, device="cuda")
+    for a, b in [(2, 2), (-1, 2), (0, 5)]:
+        with pytest.raises(rtamd.RtError):
+            world.render_accumulate_device(cam, p, a, b, acc.data_ptr())
+    with pytest.raises(rtamd.RtError):
+        world.render_accumulate_device(cam, rtamd.default_params(width=16, height=16, spp=4, kernel=6), 0, 4, acc.data_ptr())
