@@ -159,7 +159,7 @@ def test_forced_process_group_runs_the_rccl_exchange_at_world_1(how, tmp_path):
     assert "workload" in out["config"] and "model" not in out["config"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "valu_busy_measured", "cost_table"):
         assert k in out["roofline"], k
-    assert "measured_classes" in out["roofline"]["cost_table"] and "unmeasured_priced_as_other" in out["roofline"]["cost_table"]
+    assert "measured_classes" in out["roofline"]["cost_table"] and "other_class" in out["roofline"]["cost_table"]
     assert len(out["ranks"]) == 1 and out["ranks"][0]["tiles"] == 12 * 9 and out["ranks"][0]["samples"] == 96 * 72 * 8 * 2
     assert out["ranks"][0]["kernel_ms"] > 0 and out["ranks"][0]["exchange_ms"] > 0 and "all_gather" in pg["calls"]
     if how == "flag":
