@@ -314,6 +314,14 @@ int rt_render_tiles_device(const rt_scene* s, const rt_camera* cam, const rt_par
 int rt_render_accumulate_device(const rt_scene* s, const rt_camera* cam, const rt_params* p, int32_t sample_begin, int32_t sample_end,
                                 double* d_accum, void* hip_stream, rt_stats* stats);
 int rt_accum_finalize_device(const rt_params* p, const double* d_accum, double* d_tiles, void* hip_stream);
+/* The same for a host that holds no device memory (the reference's Rust host): the running sums travel in `accum_state`, HOST memory,
+ * rt_accum_state_doubles(p) f64, opaque to the caller (it is this rank's tile-major accumulator) -- write it to disk to checkpoint, read it
+ * back to resume.  rt_accum_finalize turns a complete state (all p->spp samples) into the frame out_rgb[H][W][3] that rt_render would
+ * have returned (world == 1), bit for bit.  Each call copies the state to the device and back (24 B per pixel). */
+int64_t rt_accum_state_doubles(const rt_params* p);
+int rt_render_accumulate(const rt_scene* s, const rt_camera* cam, const rt_params* p, int32_t sample_begin, int32_t sample_end,
+                         double* accum_state, rt_stats* stats);
+int rt_accum_finalize(const rt_params* p, const double* accum_state, double* out_rgb);
 /* SPPM across GPUs: every rank runs the same deterministic pre-pass (photon maps + per-pixel statistics of the WHOLE
  * frame: ~0.13 s for the reference's 50 x 500 000 photons) and renders only its own tiles; the buffers are gathered and
  * stitched exactly like rt_render_tiles_device's.  (The per-pixel pre-pass statistics are only returned by rt_render_sppm.) */

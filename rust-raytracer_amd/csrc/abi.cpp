@@ -599,6 +599,55 @@ int rt_accum_finalize_device(const rt_params* p, const double* d_accum, double* 
     });
 }
 
+int64_t rt_accum_state_doubles(const rt_params* p) {
+    const int64_t n = rt_tiles_owned(p);
+    return n < 0 ? n : std::max<int64_t>(1, n) * TILE_PIX * 3;
+}
+namespace {
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() {
+        if (p) dev_free(p);
+    }
+};
+}  // namespace
+int rt_render_accumulate(const rt_scene* s, const rt_camera* cam, const rt_params* p, int32_t sample_begin, int32_t sample_end,
+                         double* accum_state, rt_stats* stats) {
+    return guard([&] {
+        REQUIRE(s && cam && p && accum_state, "null argument");
+        if (device_count() < 1) throw RtError(RT_ERR_NO_DEVICE, "no HIP device: librtamd has no CPU fallback");
+        const int64_t n = rt_accum_state_doubles(p);
+        REQUIRE(n > 0, "bad image size or partition");
+        if (p->device >= 0) dev_set_device(p->device);
+        DevBuf acc;
+        acc.p = dev_alloc((size_t)n * sizeof(double));
+        if (sample_begin > 0) dev_copy_to_device(acc.p, accum_state, (size_t)n * sizeof(double));
+        const int rc = rt_render_accumulate_device(s, cam, p, sample_begin, sample_end, (double*)acc.p, nullptr, stats);
+        if (rc != RT_OK) return rc;
+        dev_copy_to_host(accum_state, acc.p, (size_t)n * sizeof(double));
+        return (int)RT_OK;
+    });
+}
+int rt_accum_finalize(const rt_params* p, const double* accum_state, double* out_rgb) {
+    return guard([&] {
+        REQUIRE(p && accum_state && out_rgb, "null argument");
+        REQUIRE(p->world == 1 && p->rank == 0, "rt_accum_finalize stitches a whole frame: rank / world must be 0 / 1");
+        if (device_count() < 1) throw RtError(RT_ERR_NO_DEVICE, "no HIP device: librtamd has no CPU fallback");
+        const RenderPlan pl = make_plan(p);
+        const size_t n = (size_t)std::max<int64_t>(1, pl.tiles_owned) * TILE_PIX * 3, frame_bytes = (size_t)pl.width * pl.height * 3 * sizeof(double);
+        if (p->device >= 0) dev_set_device(p->device);
+        DevBuf acc, tiles, frame;
+        acc.p = dev_alloc(n * sizeof(double));
+        tiles.p = dev_alloc(n * sizeof(double));
+        frame.p = dev_alloc(frame_bytes);
+        dev_copy_to_device(acc.p, accum_state, n * sizeof(double));
+        finalize_tiles(pl, (const double*)acc.p, (double*)tiles.p, nullptr);
+        assemble_frame(pl, (const double*)tiles.p, pl.tiles_owned, (double*)frame.p, nullptr);
+        dev_copy_to_host(out_rgb, frame.p, frame_bytes);
+        return (int)RT_OK;
+    });
+}
+
 int rt_render_sppm_tiles_device(const rt_scene* s, const rt_camera* cam, const rt_params* p, const rt_sppm_config* cfg, double* d_tiles,
                                 void* hip_stream, rt_stats* stats) {
     return guard([&] {

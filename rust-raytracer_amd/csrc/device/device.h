@@ -47,6 +47,7 @@ int device_count();
 void* dev_alloc(size_t n);
 void dev_free(void* p);
 void dev_copy_to_host(void* dst, const void* src, size_t n);
+void dev_copy_to_device(void* dst, const void* src, size_t n);
 void dev_set_device(int d);
 void free_device_copies(rt_scene& s);
 size_t release_workspaces();

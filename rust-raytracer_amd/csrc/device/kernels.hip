@@ -3211,6 +3211,7 @@ void* dev_alloc(size_t n) {
 }
 void dev_free(void* p) { (void)hipFree(p); }
 void dev_copy_to_host(void* dst, const void* src, size_t n) { HIP_CHECK(hipMemcpy(dst, src, n, hipMemcpyDeviceToHost)); }
+void dev_copy_to_device(void* dst, const void* src, size_t n) { HIP_CHECK(hipMemcpy(dst, src, n, hipMemcpyHostToDevice)); }
 void dev_set_device(int d) { HIP_CHECK(hipSetDevice(d)); }
 
 static const char* device_blob(const rt_scene& s, int dev) {

@@ -47,6 +47,8 @@ int main(int argc, char** argv) {
     Config cfg;
     double aspect = -1;
     bool describe = false;
+    std::string checkpoint;  // --checkpoint FILE [--run-samples K]: trace the next K samples per pixel into the state in FILE; the image is written once all are in
+    int run_samples = 64;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto next = [&]() -> const char* { if (i + 1 >= argc) { std::fprintf(stderr, "missing value for %s\n", a.c_str()); std::exit(2); } return argv[++i]; };
@@ -69,6 +71,8 @@ int main(int argc, char** argv) {
             }
         }
         else if (a == "-o") out = next();
+        else if (a == "--checkpoint") { checkpoint = next(); }
+        else if (a == "--run-samples") run_samples = std::atoi(next());
         else if (a == "--describe") describe = true;
         else if (a == "--vec3-selftest") return vec3_selftest();
         else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
@@ -87,6 +91,14 @@ int main(int argc, char** argv) {
         std::printf("scene: %d nodes (%d boxes, %d spheres, %d rects, %d tris, %d xforms), %llu bytes flattened\n", info.n_nodes, info.n_boxes,
                     info.n_spheres, info.n_rects, info.n_tris, info.n_xforms, (unsigned long long)info.bytes);
         if (describe) return 0;
+        if (!checkpoint.empty()) {
+            RgbImage img;
+            int done = 0;
+            const bool complete = world->capture_image_resumable(cfg, checkpoint, run_samples, &img, &done);
+            std::printf("checkpoint %s: %d of %d samples per pixel done%s\n", checkpoint.c_str(), done, cfg.sample_per_pixel, complete ? "" : " (run again to continue)");
+            if (complete) img.save(out);
+            return 0;
+        }
         auto rt_start = std::chrono::steady_clock::now();
         rt_stats st{};
         std::vector<rt_stats> ranks;

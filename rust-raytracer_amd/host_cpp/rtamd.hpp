@@ -12,8 +12,11 @@
 //   raytracer/src/world.rs       -> World
 //   raytracer/src/camera.rs      -> Camera
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
+#include <cstring>
 #include <map>
 #include <memory>
 #include <stdexcept>
@@ -393,6 +396,54 @@ class World {
         check(rt_tonemap_u8(rad.data(), rad.size(), img.data.data()));
         if (radiance) *radiance = std::move(rad);
         return img;
+    }
+
+    // capture_image in instalments (rt_render_accumulate / rt_accum_finalize): every call traces the next `run_samples` sample indices of
+    // every pixel into the accumulator kept in `state_file` (created on the first call; its header pins the frame it belongs to) and
+    // returns true, with the finished image, once all cfg.sample_per_pixel samples are in.  Killing the process between calls loses at
+    // most one instalment; the finished frame equals capture_image's bit for bit (the RNG is keyed by pixel and sample: no other state).
+    bool capture_image_resumable(const Config& cfg, const std::string& state_file, int run_samples, RgbImage* out, int* done_samples = nullptr) const {
+        rt_params p;
+        rt_default_params(&p);
+        p.width = cfg.width; p.height = cfg.height; p.spp = cfg.sample_per_pixel; p.max_depth = cfg.max_depth;
+        p.t_min = cfg.t_min; p.seed = cfg.seed; p.integrator = cfg.integrator;
+        struct Header {
+            char magic[8];
+            int32_t width, height, spp, max_depth, integrator, next_sample;
+            uint64_t seed;
+            double t_min;
+            int64_t n_doubles;
+        } want = {{'R', 'T', 'A', 'M', 'D', 'C', 'K', '1'}, p.width, p.height, p.spp, p.max_depth, p.integrator, 0, p.seed, p.t_min, rt_accum_state_doubles(&p)};
+        if (want.n_doubles <= 0 || run_samples < 1) throw Error(RT_ERR_ARG, "capture_image_resumable: bad frame size or instalment");
+        std::vector<double> state((size_t)want.n_doubles, 0.);
+        Header h = want;
+        if (FILE* f = std::fopen(state_file.c_str(), "rb")) {
+            const bool ok = std::fread(&h, sizeof(h), 1, f) == 1 && std::fread(state.data(), sizeof(double), state.size(), f) == state.size();
+            std::fclose(f);
+            Header cmp = h;
+            cmp.next_sample = 0;
+            if (!ok || std::memcmp(&cmp, &want, sizeof(Header)) != 0 || h.next_sample < 0 || h.next_sample > p.spp)
+                throw Error(RT_ERR_ARG, "capture_image_resumable: " + state_file + " is not the state of this frame");
+        }
+        if (h.next_sample < p.spp) {
+            const int end = std::min(p.spp, h.next_sample + run_samples);
+            check(rt_render_accumulate(s_, &cam.c, &p, h.next_sample, end, state.data(), nullptr));
+            h.next_sample = end;
+            const std::string tmp = state_file + ".tmp";  // written beside, then renamed: a kill never leaves half a state
+            FILE* f = std::fopen(tmp.c_str(), "wb");
+            if (!f) throw Error(RT_ERR_IO, "cannot write " + tmp);
+            const bool ok = std::fwrite(&h, sizeof(h), 1, f) == 1 && std::fwrite(state.data(), sizeof(double), state.size(), f) == state.size();
+            if (std::fclose(f) != 0 || !ok || std::rename(tmp.c_str(), state_file.c_str()) != 0) throw Error(RT_ERR_IO, "cannot write " + state_file);
+        }
+        if (done_samples) *done_samples = h.next_sample;
+        if (h.next_sample < p.spp) return false;
+        std::vector<double> rad((size_t)cfg.width * cfg.height * 3);
+        check(rt_accum_finalize(&p, state.data(), rad.data()));
+        out->width = cfg.width;
+        out->height = cfg.height;
+        out->data.resize(rad.size());
+        check(rt_tonemap_u8(rad.data(), rad.size(), out->data.data()));
+        return true;
     }
 
    private:

@@ -156,6 +156,9 @@ _SIGS = [
     ("rt_render_accumulate_device", C.c_int, [C.c_void_p, C.POINTER(rt_camera), C.POINTER(rt_params), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                               C.POINTER(rt_stats)]),
     ("rt_accum_finalize_device", C.c_int, [C.POINTER(rt_params), C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("rt_accum_state_doubles", C.c_int64, [C.POINTER(rt_params)]),
+    ("rt_render_accumulate", C.c_int, [C.c_void_p, C.POINTER(rt_camera), C.POINTER(rt_params), C.c_int32, C.c_int32, _dp, C.POINTER(rt_stats)]),
+    ("rt_accum_finalize", C.c_int, [C.POINTER(rt_params), _dp, _dp]),
     ("rt_tiles_total", C.c_int64, [C.POINTER(rt_params)]),
     ("rt_tiles_owned", C.c_int64, [C.POINTER(rt_params)]),
     ("rt_assemble_frame_device", C.c_int, [C.POINTER(rt_params), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
@@ -516,6 +519,20 @@ class World:
                                            C.c_void_p(stream_ptr or 0), C.byref(st)))
         return st.as_dict()
 
+    def render_accumulate(self, camera, params, sample_begin, sample_end, state=None):
+        """rt_render_accumulate: samples [sample_begin, sample_end) added to the host-held accumulator state (numpy f64, created when None);
+        returns (state, stats).  accum_finalize(params, state) gives the frame once every sample is in."""
+        n = int(lib().rt_accum_state_doubles(C.byref(params)))
+        if n <= 0:
+            raise RtError(n, "bad image size or partition")
+        if state is None:
+            state = np.zeros(n, dtype=np.float64)
+        assert state.dtype == np.float64 and state.size == n and state.flags["C_CONTIGUOUS"]
+        st = rt_stats()
+        _chk(self.L.rt_render_accumulate(self.h, C.byref(camera.c), C.byref(params), int(sample_begin), int(sample_end),
+                                         state.ctypes.data_as(_dp), C.byref(st)))
+        return state, st.as_dict()
+
     def render_accumulate_device(self, camera, params, sample_begin, sample_end, d_accum_ptr, stream_ptr=None):
         """rt_render_accumulate_device: samples [sample_begin, sample_end) of this rank's tiles are added, in index order, to the caller's
         accumulator (raw device pointer, rt_tiles_owned * 64 * 3 f64; sample_begin == 0 initialises it) -- resumable rendering."""
@@ -604,6 +621,13 @@ def tiles_total(params):
 def assemble_frame_device(params, d_gathered_ptr, tiles_per_rank_stride, d_frame_ptr, stream_ptr=None):
     _chk(lib().rt_assemble_frame_device(C.byref(params), C.c_void_p(d_gathered_ptr), int(tiles_per_rank_stride),
                                         C.c_void_p(d_frame_ptr), C.c_void_p(stream_ptr or 0)))
+
+
+def accum_finalize(params, state):
+    """rt_accum_finalize: the frame [H, W, 3] of a complete host-held accumulator state (World.render_accumulate)"""
+    out = np.zeros((params.height, params.width, 3), dtype=np.float64)
+    _chk(lib().rt_accum_finalize(C.byref(params), state.ctypes.data_as(_dp), out.ctypes.data_as(_dp)))
+    return out
 
 
 def accum_finalize_device(params, d_accum_ptr, d_tiles_ptr, stream_ptr=None):

@@ -247,6 +247,9 @@ extern "C" {
     pub fn rt_render_sppm_tiles_device(s: *const rt_scene, cam: *const rt_camera, p: *const rt_params, cfg: *const rt_sppm_config, d_tiles: *mut c_double, hip_stream: *mut c_void, stats: *mut rt_stats) -> c_int;
     pub fn rt_render_accumulate_device(s: *const rt_scene, cam: *const rt_camera, p: *const rt_params, sample_begin: i32, sample_end: i32, d_accum: *mut c_double, hip_stream: *mut c_void, stats: *mut rt_stats) -> c_int;
     pub fn rt_accum_finalize_device(p: *const rt_params, d_accum: *const c_double, d_tiles: *mut c_double, hip_stream: *mut c_void) -> c_int;
+    pub fn rt_accum_state_doubles(p: *const rt_params) -> i64;
+    pub fn rt_render_accumulate(s: *const rt_scene, cam: *const rt_camera, p: *const rt_params, sample_begin: i32, sample_end: i32, accum_state: *mut c_double, stats: *mut rt_stats) -> c_int;
+    pub fn rt_accum_finalize(p: *const rt_params, accum_state: *const c_double, out_rgb: *mut c_double) -> c_int;
     pub fn rt_tiles_total(p: *const rt_params) -> i64;
     pub fn rt_tiles_owned(p: *const rt_params) -> i64;
     pub fn rt_assemble_frame_device(p: *const rt_params, d_gathered: *const c_double, tiles_per_rank_stride: i64, d_frame: *mut c_double, hip_stream: *mut c_void) -> c_int;
@@ -496,6 +499,29 @@ impl Scene {
         let mut st = vec![rt_stats::default(); n];
         check(unsafe { rt_render_multi_camera_frame(self.raw, frame, p, n as c_int, std::ptr::null(), out.as_mut_ptr(), st.as_mut_ptr()) })?;
         Ok((out, st))
+    }
+    /// capture_image in instalments: the sample indices `[begin, end)` of every pixel are added, in index order, to the running sums in
+    /// `state` (an empty vector on the first call, `begin == 0`; opaque: write it to disk to checkpoint).  `finish_accumulated` turns a
+    /// complete state into the frame `render` would have returned, bit for bit -- the RNG is keyed by (seed, pixel, sample), so the
+    /// state and the next sample index are all there is to save.
+    pub fn render_accumulate(&self, cam: &rt_camera, p: &rt_params, begin: i32, end: i32, state: &mut Vec<f64>) -> Result<rt_stats, RtError> {
+        let n64 = unsafe { rt_accum_state_doubles(p) };
+        if n64 <= 0 {
+            return Err(RtError { code: n64 as c_int, message: "bad image size or partition".to_string() });
+        }
+        let n = n64 as usize;
+        if state.len() != n {
+            state.clear();
+            state.resize(n, 0.0);
+        }
+        let mut st = rt_stats::default();
+        check(unsafe { rt_render_accumulate(self.raw, cam, p, begin, end, state.as_mut_ptr(), &mut st) })?;
+        Ok(st)
+    }
+    pub fn finish_accumulated(p: &rt_params, state: &[f64]) -> Result<Vec<f64>, RtError> {
+        let mut out = vec![0.0f64; (p.width as usize) * (p.height as usize) * 3];
+        check(unsafe { rt_accum_finalize(p, state.as_ptr(), out.as_mut_ptr()) })?;
+        Ok(out)
     }
     pub fn render_sppm_multi(&self, cam: &rt_camera, p: &rt_params, cfg: &rt_sppm_config, gpus: usize) -> Result<(Vec<f64>, Vec<rt_stats>), RtError> {
         let n = if gpus == 0 { (unsafe { rt_device_count() }).max(1) as usize } else { gpus };

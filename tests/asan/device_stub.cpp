@@ -96,6 +96,10 @@ void dev_copy_to_host(void* dst, const void* src, size_t n) {
     if (stub_devices() < 1) none();
     std::memcpy(dst, src, n);
 }
+void dev_copy_to_device(void* dst, const void* src, size_t n) {
+    if (stub_devices() < 1) none();
+    std::memcpy(dst, src, n);
+}
 void dev_set_device(int d) {
     if (d < 0 || d >= stub_devices()) none();
     t_device = d;

@@ -55,3 +55,21 @@ def test_cpp_main_is_the_reference_binary_with_sppm(tmp_path):
     exp, _, _ = oracle.cornell_box_scene(scene_path("cube.obj"), 1.0, seed=1).render_sppm(24, 24, 3, iterations=3, photons_per_iter=6000,
                                                                                           k_global=100, k_caustic=50, seed=1)
     assert np.array_equal(np.asarray(Image.open(out)), oracle.tonemap_u8(exp))
+
+
+@pytest.mark.gpu
+def test_cpp_main_resumes_a_frame_from_its_checkpoint_file(tmp_path):
+    """rtamd_render --checkpoint FILE --run-samples K (World::capture_image_resumable -> rt_render_accumulate / rt_accum_finalize): the frame
+    rendered in instalments by SEPARATE processes -- 3 + 3 + 2 of 8 samples, the state in a file between them -- is the frame of one
+    plain run, byte for byte; a state file of another frame is refused."""
+    plain, resumed, ck = str(tmp_path / "plain.png"), str(tmp_path / "resumed.png"), str(tmp_path / "state.bin")
+    common = ["--scene", scene_path("scene_10.json"), "-w", "96", "-h", "54", "--spp", "8", "--seed", "3"]
+    r = run(*common, "-o", plain)
+    assert r.returncode == 0, r.stderr
+    for i, want in enumerate(["3 of 8", "6 of 8", "8 of 8"]):
+        r = run(*common, "-o", resumed, "--checkpoint", ck, "--run-samples", "3")
+        assert r.returncode == 0 and want in r.stdout, (r.stdout, r.stderr)
+        assert os.path.exists(resumed) == (i == 2)
+    assert open(plain, "rb").read() == open(resumed, "rb").read()
+    r = run(*common[:-2], "--seed", "4", "-o", resumed, "--checkpoint", ck)
+    assert r.returncode == 1 and "not the state of this frame" in r.stderr

@@ -949,3 +949,20 @@ def test_resumable_render_equals_the_one_call_render(tuning):
             world.render_accumulate_device(cam, p, a, b, acc.data_ptr())
     with pytest.raises(rtamd.RtError):
         world.render_accumulate_device(cam, rtamd.default_params(width=16, height=16, spp=4, kernel=6), 0, 4, acc.data_ptr())
+
+
+def test_resumable_render_with_host_held_state_equals_rt_render():
+    """rt_render_accumulate / rt_accum_finalize (the form for a host without device memory, e.g. the reference's Rust host): the accumulator
+    state travels through host memory between the calls; 2 + 9 + 5 of 16 samples give rt_render's frame bit for bit."""
+    import rtamd
+    world, cam = rtamd.load_scene_file(scene_path("scene_10.json"))
+    p = rtamd.default_params(width=120, height=68, spp=16, seed=2)
+    ref, _ = world.render(cam, width=120, height=68, spp=16, seed=2)
+    state = None
+    for a, b in [(0, 2), (2, 11), (11, 16)]:
+        state, st = world.render_accumulate(cam, p, a, b, state)
+        assert st["samples"] == 120 * 68 * (b - a)
+        state = state.copy()                      # (what a restart reads back from disk)
+    assert np.array_equal(rtamd.accum_finalize(p, state), ref)
+    with pytest.raises(rtamd.RtError):
+        rtamd.accum_finalize(rtamd.default_params(width=120, height=68, spp=16, seed=2, rank=1, world=2), state)
