@@ -137,7 +137,10 @@ void exchange_rows(Exchange* e, const RowMove* m, size_t n) {
                 throw RtError(RT_ERR_INTERNAL, "stub: a row's buffer is not on its communicator rank's device");
         }
         std::memcpy(m[i].dst, m[i].src, m[i].count * sizeof(double));
-        g_rows_moved++;
+        {
+            std::lock_guard<std::mutex> g(g_stub_mu);
+            g_rows_moved++;
+        }
     }
 }
 size_t exchange_release_idle() { return 0; }
