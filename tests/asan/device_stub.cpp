@@ -33,8 +33,9 @@ static long g_rows_moved = 0;
 
 double stub_value(int64_t t, int pix, int c, uint64_t seed) { return (double)(t * 1000 + pix * 3 + c) + (double)(seed % 7) * 0.125; }
 
-void render_tiles(const rt_scene&, const CameraDev&, const RenderPlan& pl, double* d_tiles, void*, rt_stats* st) {
+void render_tiles(const rt_scene&, const CameraDev&, const RenderPlan& pl, double* d_tiles_in, void*, rt_stats* st) {
     if (stub_devices() < 1) none();
+    double* d_tiles = pl.ext_accum ? pl.ext_accum : d_tiles_in;  // (what the call writes: it must be memory of the current device)
     {
         std::lock_guard<std::mutex> g(g_stub_mu);
         // the rows must live on the device this thread has made current (rt_render_multi's per-rank threads)
@@ -48,6 +49,17 @@ void render_tiles(const rt_scene&, const CameraDev&, const RenderPlan& pl, doubl
         }
         if (!found) throw RtError(RT_ERR_INTERNAL, "stub: rows are not device memory");
     }
+    if (pl.ext_accum) {  // resumable rendering: every sample index of the range adds the pattern once (s_first == 0 initialises)
+        const int n = (pl.s_last < 0 ? pl.spp : pl.s_last) - pl.s_first;
+        for (int64_t lt = 0; lt < pl.tiles_owned; lt++) {
+            const int64_t t = lt * pl.world + pl.rank;
+            for (int pix = 0; pix < TILE_PIX; pix++)
+                for (int c = 0; c < 3; c++) {
+                    double& a = pl.ext_accum[((size_t)lt * TILE_PIX + pix) * 3 + c];
+                    a = (pl.s_first == 0 ? 0. : a) + n * stub_value(t, pix, c, pl.seed);
+                }
+        }
+    } else
     for (int64_t lt = 0; lt < pl.tiles_owned; lt++) {
         const int64_t t = lt * pl.world + pl.rank;
         for (int pix = 0; pix < TILE_PIX; pix++)
@@ -72,7 +84,10 @@ void assemble_frame(const RenderPlan& pl, const double* gathered, int64_t stride
             for (int c = 0; c < 3; c++) frame[((size_t)y * pl.width + x) * 3 + c] = gathered[((size_t)(r * stride + lt) * TILE_PIX + pix) * 3 + c];
         }
 }
-void finalize_tiles(const RenderPlan&, const double*, double*, void*) { none(); }
+void finalize_tiles(const RenderPlan& pl, const double* acc, double* tiles, void*) {
+    if (stub_devices() < 1) none();
+    for (int64_t i = 0; i < pl.tiles_owned * TILE_PIX * 3; i++) tiles[i] = acc[i] / pl.spp;
+}
 void debug_rng_device(uint64_t, uint64_t, uint64_t, int, uint64_t*) { none(); }
 void debug_rng_floats_device(uint64_t, uint64_t, uint64_t, int, double, double, double*, double*) { none(); }
 void debug_math_device(int, size_t, const double*, const double*, double*) { none(); }

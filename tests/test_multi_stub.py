@@ -88,3 +88,22 @@ def test_sppm_multi_takes_the_same_path():
     world, cam = _world()
     img, st = world.render_sppm_multi(cam, devices=[1, 0, 1], width=24, height=16, spp=1, seed=4, iterations=1, photons_per_iter=10)
     assert np.array_equal(img, _expected(24, 16, 4)) and len(st) == 3
+
+
+def test_resumable_render_with_host_held_state_on_the_stub():
+    """rt_accum_state_doubles / rt_render_accumulate / rt_accum_finalize: state size, the copies to and from the (fake) device, the sample
+    range checks and the final stitch, under ASan (a wrong size is a heap overflow there); 16 samples as 1 + 9 + 6."""
+    import rtamd
+    world, cam = _world()
+    p = rtamd.default_params(width=52, height=28, spp=16, seed=6)
+    state = None
+    for a, b in [(0, 1), (1, 10), (10, 16)]:
+        state, st = world.render_accumulate(cam, p, a, b, state)
+        assert st["samples"] == 52 * 28 * (b - a) and state.size == 7 * 4 * 64 * 3
+    assert np.array_equal(rtamd.accum_finalize(p, state), _expected(52, 28, 6))
+    for a, b in [(3, 3), (-1, 4), (0, 17)]:
+        with pytest.raises(rtamd.RtError):
+            world.render_accumulate(cam, p, a, b, state)
+    with pytest.raises(rtamd.RtError):
+        rtamd.accum_finalize(rtamd.default_params(width=52, height=28, spp=16, rank=1, world=2), state)
+
