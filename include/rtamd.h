@@ -148,7 +148,8 @@ typedef struct rt_tuning {
 void rt_tuning_default(rt_tuning* t);
 int rt_tuning_set(const rt_tuning* t);
 /* The render entry points keep a workspace per device for the life of the process (unit rings of the resident waves, ~0.3 GB,
- * accumulator, tickets: no hipMalloc on the hot path), rt_render_multi also its RCCL communicators.  This frees the idle ones;
+ * accumulator, tickets: no hipMalloc on the hot path), rt_render_multi also its RCCL communicators and its frame-sized buffers (gathered
+ * rows, stitched frame, the ranks' rows: up to 4 idle ones per device and size).  This frees the idle ones;
  * returns the bytes released. */
 int64_t rt_release_workspaces(void);
 

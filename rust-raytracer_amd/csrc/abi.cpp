@@ -6,10 +6,12 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <new>
 #include <string>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #include "common/rng.h"
@@ -84,10 +86,67 @@ void rt_default_params(rt_params* p) {
     p->time1 = 0.;
 }
 int rt_device_count(void) { return device_count(); }
+// Frame-sized device buffers of rt_render_multi (the gathered rows, the stitched frame, the ranks' own rows) are kept between calls:
+// allocating and freeing them cost every frame about a millisecond (hipFree waits for the device).  Per (device, size): at most
+// FRAME_POOL_KEEP idle buffers; rt_release_workspaces frees them all.
+namespace {
+const size_t FRAME_POOL_KEEP = 4;
+std::mutex g_frame_pool_mu;
+std::map<std::pair<int, size_t>, std::vector<void*>> g_frame_pool;
+void* frame_pool_take(int dev, size_t bytes) {
+    {
+        std::lock_guard<std::mutex> g(g_frame_pool_mu);
+        auto it = g_frame_pool.find({dev, bytes});
+        if (it != g_frame_pool.end() && !it->second.empty()) {
+            void* p = it->second.back();
+            it->second.pop_back();
+            return p;
+        }
+    }
+    return dev_alloc(bytes);  // (the caller has made `dev` current)
+}
+void frame_pool_give(int dev, size_t bytes, void* p) {  // the caller has made `dev` current
+    {
+        std::lock_guard<std::mutex> g(g_frame_pool_mu);
+        auto& v = g_frame_pool[{dev, bytes}];
+        if (v.size() < FRAME_POOL_KEEP) {
+            v.push_back(p);
+            return;
+        }
+    }
+    dev_free(p);
+}
+size_t frame_pool_release() {
+    std::map<std::pair<int, size_t>, std::vector<void*>> all;
+    {
+        std::lock_guard<std::mutex> g(g_frame_pool_mu);
+        all.swap(g_frame_pool);
+    }
+    size_t freed = 0;
+    for (auto& kv : all)
+        for (void* p : kv.second) {
+            try {
+                dev_set_device(kv.first.first);
+                dev_free(p);
+                freed += kv.first.second;
+            } catch (...) {
+            }
+        }
+    return freed;
+}
+}  // namespace
+
 int64_t rt_release_workspaces(void) {
     int64_t n = 0;
     guard([&] {
+        int cur = -1;
+        try {
+            cur = dev_get_device();
+        } catch (...) {
+        }
         n = (int64_t)release_workspaces();
+        n += (int64_t)frame_pool_release();
+        if (cur >= 0) dev_set_device(cur);
         exchange_release_idle();
         return (int)RT_OK;
     });
@@ -781,18 +840,20 @@ struct DevMem {  // device memory that remembers which device it lives on
     DevMem() = default;
     DevMem(const DevMem&) = delete;
     DevMem& operator=(const DevMem&) = delete;
+    size_t size = 0;
     void alloc(int dev, size_t bytes) {
         dev_set_device(dev);
-        p = dev_alloc(bytes);
+        p = frame_pool_take(dev, bytes);
         device = dev;
+        size = bytes;
     }
     ~DevMem() {
         if (!p) return;
         try {
             dev_set_device(device);
+            frame_pool_give(device, size, p);
         } catch (...) {
         }
-        dev_free(p);
     }
 };
 struct ExchangeLease {
