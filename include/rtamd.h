@@ -94,17 +94,16 @@ typedef struct rt_params {
                             6 = the same service across the whole GPU and across launches (parked paths in HBM pools, a
                             dedicated walk launch per cycle; 1..64 instances; by request only -- it is slower than
                             kernel 5; workspace within rt_tuning.wf_workspace_mb, default 1.9 GB).
-                            All give bit-identical images (same f64 primitive tests, same tie rule) -- with one documented exception:
-                            when two objects share the closest t EXACTLY and the reference's own BVHNode box test would have culled
-                            the later one (a Cube face coplanar with another surface), kernels 1 / 2 follow the reference, kernels
-                            5 / 6 give the hit to the later object. */
+                            All give bit-identical images (same f64 primitive tests, same tie rule: when two objects share the
+                            closest t EXACTLY the later-visited one wins unless the reference's own BVHNode box test would have
+                            culled it -- bvh.rs:88, aabb.rs:28-30 -- in every kernel). */
     int32_t device;      /* HIP device ordinal; -1 = current */
     int32_t integrator;  /* 0 = sample_ray as the reference structures it (BSDF sampling only; default);
                             1 = light importance sampling: on Diffuse hits the direction is drawn from the
                                 0.5*lights + 0.5*cosine mixture pdf (book-3 MixturePDF semantics; needs rt_scene_set_lights);
                             2 = the reference's SPPM sample_ray (only through rt_render_sppm) */
     double time0, time1; /* book-2 extension (the reference has no code for it: its Ray has no time, ray.rs:3-6): the camera's shutter.
-                            With time1 > time0 every sample draws a time in [time0, time1) right after its lens sample and moving spheres
+                            With time1 > time0 every sample draws a time in [time0, time1] (gen_range's product may round up to time1) right after its lens sample and moving spheres
                             (rt_object_moving_sphere) are where they are at that time; default 0, 0 = no draw */
 } rt_params;
 
@@ -178,7 +177,9 @@ int rt_material_isotropic(rt_scene* s, int albedo_tex);
 int rt_object_sphere(rt_scene* s, const double center[3], double radius, int material);
 /* Book-2 extension, no reference counterpart: moving_sphere(center0, center1, time0, time1, radius, material) -- Sphere::hit around
  * the centre center0 + (center1 - center0) (ray.time - time0) / (time1 - time0); box = the union of the boxes at both times.
- * Rendered by kernels 1 and 2 with integrators 0 and 1; needs rt_params.time1 > rt_params.time0 to move */
+ * Rendered by kernels 1 and 2 with integrator 0; needs rt_params.time1 > rt_params.time0 to move.  The shutter [rt_params.time0,
+ * rt_params.time1] must lie inside [time0, time1] of every moving sphere of the scene (their boxes are the union of the boxes at those two
+ * times): a render with a shutter outside that range is refused with RT_ERR_ARG */
 int rt_object_moving_sphere(rt_scene* s, const double center0[3], const double center1[3], double time0, double time1, double radius, int material);
 /* objects/rectangle.rs:7-12,44-49,82-87 : {a0,b0}=xy0|xz0|yz0, {a1,b1}=xy1|xz1|yz1, k = z|y|x */
 int rt_object_rect_xy(rt_scene* s, double x0, double y0, double x1, double y1, double z, int material);
@@ -379,7 +380,9 @@ int rt_debug_rng_floats(uint64_t seed, uint64_t pixel, uint64_t sample, int n, d
 /* device f64 sqrt / divide / rtamd-ln-1 / rtamd-sin-1, element-wise: op 0 = sqrt(a), 1 = a/b, 2 = det_ln(a), 3 = det_sin(a) */
 int rt_debug_math_device(int op, size_t n, const double* a_host, const double* b_host, double* out_host);
 /* closest hit of explicit world-space rays through device traversal `kernel` (1, 2, or 3 = kernel 2's LDS node table "NodeW" with
- * its own box test, which pt_kernel uses when the scene is LDS-resident): rays n*6 (orig,dir);
+ * its own box test, which pt_kernel uses when the scene is LDS-resident; 5 / 6 = the walks of the instance service in one lane: the
+ * world-space walk with the large instances deferred, then their object-space walks over the Node2 / item records (5: the in-lane
+ * fallback of kernel 5) or over the compact NodeQ / Tri32 copies (6: what the serving waves of kernels 5 / 6 walk), with the exact-tie rule): rays n*6 (orig,dir);
  * out n*12 = {hit, t, p[3], normal[3], front_face, u, v, leaf index in the reference-order program} */
 int rt_debug_hit_device(const rt_scene* s, int kernel, size_t n, const double* rays_host, double t_min, double t_max, double* out_host);
 /* the per-tile job sequence of one launch over samples [s_begin, s_end) for a rank that owns `tiles_owned` tiles on a GPU with `n_waves`

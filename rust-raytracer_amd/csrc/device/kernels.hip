@@ -471,7 +471,13 @@ struct Hit {
 // box tests (tie_resolve = traverse<>, out of line), and that walk's answer is the hit.  (Cheaper forms of the rule were measured:
 // a call in the leaf loop cost every kernel 6-18 %, a note of the earlier party kept in private memory 6-12 % of the GENERAL
 // kernels -- the register allocator pays for a call site or a store sequence in the loop whether it is executed or not.)
-// Kernels 5 and 6 defer instances and merge their hits later: they keep the round-3 rule.
+// Kernels 5 and 6 (round 5) follow the same rule in their TIE variants, picked by the host for every scene that holds a rectangle or a
+// cube (sphere / triangle boxes never begin exactly where another surface lies: spheres touch their box in six points, triangle boxes
+// are padded by 0.1): the world-space walk notes ties among the world-level items (TIEDEF), the object-space walks of the instance
+// service note a tie between a triangle and the best hit they were posted with (or an earlier triangle) in a per-lane bit that travels
+// with the answer (bit 30 of the order word, same encoding as TIE_FLAG in Hit::xf), and whoever holds the path when a flag turns up
+// -- the walking lane, or the lane that adopts the answer -- lets tie_resolve walk the WHOLE ray through the reference-order
+// program: that answer is final for the segment, instances included, so the path's remaining deferred instances are dropped.
 #ifdef RT_NO_TIE_RULE  // A/B build: the round-3 rule alone (the later object always wins a tie)
 #define TIE_RULE 0
 #else
@@ -479,9 +485,6 @@ struct Hit {
 #endif
 #ifndef RT_TIE_NOTRACK
 #define RT_TIE_NOTRACK 0
-#endif
-#ifndef RT_TIE_DEFER
-#define RT_TIE_DEFER 0
 #endif
 #define TIE_FLAG 0x40000000  // in Hit::xf (-1 or a small index): bits 30 and 31 differ <=> the hit is an exact tie of two objects
 DEV bool tie_flagged(int xf) { return (((uint32_t)xf >> 30) & 1u) != ((uint32_t)xf >> 31); }
@@ -797,7 +800,9 @@ DEV double track_bound(const MediaTrack& K, double best) {
 // ENTER: instance items may be entered in the lane (always, unless DEFER; with DEFER only in the MIXED variants of kernels 5 / 6,
 // for the NK_INSTANCE_INLINE items of scenes that have any: compiling the enter path into their world-space walk costs C4 6 %).
 // RESOLVE: an exact tie (TIE_FLAG) is settled before returning; false: the caller does it (traverse2_media: one call site for its two walks).
-template <int GENERAL, bool DEFER = false, bool TOP = true, bool WIDE = false, class PEND = uint32_t, bool LIMIT = false, bool ENTER = !DEFER, bool TRACK = false, bool RESOLVE = true>
+// TIEDEF: a DEFER walk (kernels 5 / 6) notes exact ties among the world-level items as well; its caller settles them (RESOLVE is false there).
+template <int GENERAL, bool DEFER = false, bool TOP = true, bool WIDE = false, class PEND = uint32_t, bool LIMIT = false, bool ENTER = !DEFER, bool TRACK = false, bool RESOLVE = true,
+          bool TIEDEF = false>
 DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, double t_min, double t_max, PEND* pend = nullptr, uint32_t order_limit = 0xFFFFFFFFu,
                   MediaTrack* track = nullptr) {
     D3 o = wo, d = wd;
@@ -808,8 +813,9 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
     h.xf = -1;
     h.kp = 0;
     int cur_xf = -1;
-    // exact ties are settled here unless the walk defers instances (kernels 5 / 6) or sees only a part of the scene (LIMIT: only t is used)
-    constexpr bool TIE = TIE_RULE && GENERAL != 0 && (!DEFER || RT_TIE_DEFER) && !LIMIT && !(TRACK && RT_TIE_NOTRACK);
+    // exact ties are noted here unless the walk sees only a part of the scene (LIMIT: only t is used); a walk that defers instances
+    // (kernels 5 / 6) notes them in its TIE variants (TIEDEF)
+    constexpr bool TIE = TIE_RULE && GENERAL != 0 && (!DEFER || TIEDEF) && !LIMIT && !(TRACK && RT_TIE_NOTRACK);
     Ray32 r = make_ray32(o, d, t_min, t_max);
     float best_all32 = r.best;  // TRACK: the best hit's own (outward-rounded) t, beside r.best = the track bound
     if (WIDE) ray32_wide_addr(r, A.n2w_lds);
@@ -2285,8 +2291,10 @@ struct CoopLds {
 
 // One while-while pass of the object-space walk for the lanes with `act`: descend to a leaf, test its items (traverse2's
 // node and leaf steps; no instances below an instance).  cur == REF_DONE afterwards means the walk is complete.
+// TIE: `tied` is set when a candidate shares the best t exactly with the hit the walk holds (see "EXACT ties" above), cleared by a closer hit.
+template <bool TIE>
 DEV void blas_pass(const Acc& A, bool act, uint32_t* stk, const int stride, D3 o, D3 d, double a, double t_min, Ray32& r, double& ht, int& hnode,
-                   uint32_t& hkp, uint32_t& cur, int& sp, int* err) {
+                   uint32_t& hkp, uint32_t& cur, int& sp, int* err, bool& tied) {
     while (act && (cur >> REF_TAG_SHIFT) == 0u) {  // inner node: both children, conservative f32 boxes
         f32x4 q0, q1, q2;
         f32x2 q3;
@@ -2338,10 +2346,13 @@ DEV void blas_pass(const Acc& A, bool act, uint32_t* stk, const int stride, D3 o
                 atomicOr(err, 2);  // an instance below an instance: flatten.cpp refuses such scenes
             }
             if (got && (t < ht || (int)it.y > hnode || !(t == t))) {
+                if (TIE) tied = t == ht && hnode >= 0;
                 ht = t;
                 hnode = (int)it.y;
                 hkp = it.x + (cube_side << NK_BITS);
                 r.best = ray32_best(t);
+            } else if (TIE && got && (int)it.y < hnode) {  // t == ht and the candidate is the earlier party
+                tied = true;
             }
         }
         if (sp > 0) {
@@ -2371,8 +2382,9 @@ struct ServeCtx {
 // `act`: descend to a leaf, test its triangles.  NodeQ boxes are grid integers and `r` is the ray in grid coordinates; triangles
 // come as f32 vertices with order and kind|payload in the record; (o, d) is the object-space ray.  cur == REF_DONE afterwards
 // means the walk is complete.
+template <bool TIE>
 DEV void blas_pass_q(const ServeCtx& X, bool act, AS_L uint32_t* stk, const int stride, D3 o, D3 d, double t_min, Ray32& r, double& ht, int& hnode,
-                     uint32_t& hkp, uint32_t& cur, int& sp) {
+                     uint32_t& hkp, uint32_t& cur, int& sp, bool& tied) {
     // (measured and dropped: speculative descent -- a leaf reached early is set aside while the lane walks on -- 805 against 924;
     // publishing a pass's answers one pass later, behind their stores' round trip, -1 %; ending the descent early once fewer than 16 / 24 / 32 / 40 lanes still descend -- 631 / 574 / 547 / 517
     // against 632 Msamples/s -- and testing at most 1 or 2 triangles of a leaf per pass, 543 / 612)
@@ -2422,10 +2434,13 @@ DEV void blas_pass_q(const ServeCtx& X, bool act, AS_L uint32_t* stk, const int 
             double t = 0., b1, b2;
             const bool got = tri_hit_v(pa, sub(pb, pa), sub(pc, pa), o, d, t_min, ht, t, b1, b2);
             if (got && (t < ht || (int)c.y > hnode || !(t == t))) {
+                if (TIE) tied = t == ht && hnode >= 0;
                 ht = t;
                 hnode = (int)c.y;
                 hkp = c.z;
                 r.best = ray32_best(t);
+            } else if (TIE && got && (int)c.y < hnode) {  // t == ht and the triangle is the earlier party
+                tied = true;
             }
         }
         if (sp > 0) {
@@ -2519,6 +2534,9 @@ DEV ServeCtx serve_ctx(const CoopArgs* args_generic, char* lds0_generic) {
 
 // Serve the request ring with this wave: walk, refill, suspend the tail.  `may_suspend`: the wave has other work to go back to.
 // Out of line: the caller's paths stay in callee-saved registers (saved once per call) instead of squeezing the walk's loop.
+// TIE: the walks note exact ties (blas_pass_q); the bit travels in the order word of the answer / of a suspended walk (tie_order).
+DEV uint32_t tie_order(int hnode, bool tied) { return (uint32_t)(tied ? hnode ^ TIE_FLAG : hnode); }
+template <bool TIE>
 __device__ __attribute__((noinline)) void coop_serve(const CoopArgs* args, char* lds0, uint32_t* stk_generic, bool may_suspend COOP_STATS_ARG) {
     const ServeCtx X = serve_ctx(args, lds0);
     const CoopLds& C = X.C;
@@ -2535,6 +2553,7 @@ __device__ __attribute__((noinline)) void coop_serve(const CoopArgs* args, char*
     int hnode = -1;
     uint32_t hkp = 0, cur = REF_DONE;
     int sp = 0;
+    bool tied = false;
     for (;;) {
         // ---- refill: idle lanes take requests (fresh ones start at the instance's root, suspended ones where they stopped) ----
         const int got = ring_pop(C.rq, __ballot(rid < 0), lane, lanemask_lt);
@@ -2556,10 +2575,13 @@ __device__ __attribute__((noinline)) void coop_serve(const CoopArgs* args, char*
                 hnode = (int)(uint32_t)u3.y;
                 hkp = 0u;
                 sp = 0;
+                tied = false;  // (a posted hit is never a pending tie: ties are settled before a path is parked or re-posted)
             } else {  // suspended walk: its best hit so far in unit 5; the stack comes back into this lane's LDS stack
                 const U2 u5 = q[5];
                 ht = bitsd(u5.x);
                 hnode = (int)(uint32_t)u5.y;
+                tied = TIE && tie_flagged(hnode);
+                if (tied) hnode ^= TIE_FLAG;
                 hkp = (uint32_t)(u5.y >> 32);
                 const int n = n_saved - 1;
                 for (int i = 0; i < n; i += 4) {
@@ -2581,12 +2603,12 @@ __device__ __attribute__((noinline)) void coop_serve(const CoopArgs* args, char*
         bool thin = false;
         for (;;) {
             COOP_STAT(1, __ballot(rid >= 0));  // serve passes: busy lanes
-            blas_pass_q(X, rid >= 0, stk, stride, o, d, t_min, r, ht, hnode, hkp, cur, sp);
+            blas_pass_q<TIE>(X, rid >= 0, stk, stride, o, d, t_min, r, ht, hnode, hkp, cur, sp, tied);
             const bool fin = rid >= 0 && cur == REF_DONE;
             if (fin) {
                 U2 ans;
                 ans.x = dbits(ht);
-                ans.y = ((uint64_t)hkp << 32) | (uint64_t)(uint32_t)hnode;
+                ans.y = ((uint64_t)hkp << 32) | (uint64_t)tie_order(hnode, TIE && tied);
                 X.pool[(size_t)(COOP_REC / 2) * (size_t)rid + 5] = ans;
             }
             ring_push(C.aq, fin, (uint32_t)rid, lane, lanemask_lt, true);
@@ -2612,7 +2634,7 @@ __device__ __attribute__((noinline)) void coop_serve(const CoopArgs* args, char*
                 w4.x = ((uint64_t)cur << 32) | (uint64_t)(uint32_t)u4.x;
                 w4.y = (u4.y & ~(0xffull << 24)) | ((uint64_t)(n + 1) << 24);
                 w5.x = dbits(ht);
-                w5.y = ((uint64_t)hkp << 32) | (uint64_t)(uint32_t)hnode;
+                w5.y = ((uint64_t)hkp << 32) | (uint64_t)tie_order(hnode, TIE && tied);
                 q[4] = w4;
                 q[5] = w5;
                 for (int i = 0; i < n; i += 4) {
@@ -2631,10 +2653,13 @@ __device__ __attribute__((noinline)) void coop_serve(const CoopArgs* args, char*
 }
 
 // A path whose deferred instances cannot be parked (pool exhausted; rare): walk them here, as the plain kernel would.
+// TIE: an exact tie noted by these walks comes back as TIE_FLAG in the hit's xf; the caller settles it.
+template <bool TIE>
 __device__ __attribute__((noinline)) Hit coop_walk_inline(const CoopArgs* args, char* lds0, uint32_t* stk_generic, D3 o, D3 d, Hit h, uint64_t pend) {
     const CoopCtx X = coop_ctx(args, lds0);
     const Acc& A = X.A;
     uint32_t* stk = AS_LDS(uint32_t, stk_generic);
+    bool tied = false;
     while (pend != 0ull) {
         const uint32_t ni = (uint32_t)(__ffsll((long long)pend) - 1);
         pend &= pend - 1ull;
@@ -2646,7 +2671,7 @@ __device__ __attribute__((noinline)) Hit coop_walk_inline(const CoopArgs* args, 
         double ht = h.t;
         int hnode = h.node, sp = 0;
         uint32_t hkp = 0u, cur = in.y;
-        while (cur != REF_DONE) blas_pass(A, true, stk, PT_BLOCK, oo, dd, a, X.t_min, r, ht, hnode, hkp, cur, sp, X.err);
+        while (cur != REF_DONE) blas_pass<TIE>(A, true, stk, PT_BLOCK, oo, dd, a, X.t_min, r, ht, hnode, hkp, cur, sp, X.err, tied);
         if (hnode != h.node) {
             h.t = ht;
             h.node = hnode;
@@ -2654,12 +2679,15 @@ __device__ __attribute__((noinline)) Hit coop_walk_inline(const CoopArgs* args, 
             h.xf = (int)in.x;
         }
     }
+    if (TIE && tied) h.xf ^= TIE_FLAG;
     return h;
 }
 
 // PEND: the type of the per-path mask of deferred instances: uint32_t for scenes with up to 32 instances, uint64_t for 33..64 (the wider
 // mask costs the 32-instance scenes 5 % in registers: C4 837 instead of 883 Msamples/s, so it is a variant, not the default)
-template <int INTEG, bool MIXED = false, bool EARLY = false, typename PEND = uint32_t>
+// TIE: the exact-tie rule of the reference ("EXACT ties" above) -- for scenes with rectangles or cubes; its own variant because the flag
+// in the world-space walk and the resolver's call sites cost the others registers (C4 -6 % when it was a build switch, round 4)
+template <int INTEG, bool MIXED = false, bool EARLY = false, typename PEND = uint32_t, bool TIE = false>
 __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam, RenderK rk, double* __restrict__ ring, double* accum,
                                                            unsigned int* tickets, unsigned int* __restrict__ counter, int* __restrict__ err, uint64_t* coop) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -2851,7 +2879,11 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
         // ---- world-space walk of the lanes that start a segment, instances deferred ----
         if (__ballot(alive && !ready && pend == (PEND)0) != 0ull) COOP_STAT(2, __ballot(alive && !ready && pend == (PEND)0));
         if (alive && !ready && pend == (PEND)0) {  // (pend != 0: a path between two deferred instances of one segment)
-            h = traverse2<true, true, true, false, PEND, false, MIXED>(A, stk, stk_stride, o, d, rk.t_min, INFINITY, &pend);
+            h = traverse2<true, true, true, false, PEND, false, MIXED, false, false, TIE>(A, stk, stk_stride, o, d, rk.t_min, INFINITY, &pend);
+            if (TIE && tie_flagged(h.xf)) {  // two world-level objects share the best t: the reference-order walk answers for the whole ray
+                h = tie_resolve<1>(A, o, d, rk.t_min, INFINITY, h);
+                pend = (PEND)0;
+            }
             if (pend == (PEND)0) ready = true;
         }
         COOP_TIME(1);
@@ -2939,7 +2971,8 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
                 // pool exhausted (rare): walk the deferred instances in this lane, sparsely, as the plain kernel does
                 if (__ballot(need && id < 0) != 0ull) {
                     if (need && id < 0) {
-                        h = coop_walk_inline(cargs, smem, stk, o, d, h, pend);
+                        h = coop_walk_inline<TIE>(cargs, smem, stk, o, d, h, pend);
+                        if (TIE && tie_flagged(h.xf)) h = tie_resolve<1>(A, o, d, rk.t_min, INFINITY, h);
                         pend = (PEND)0;
                         ready = true;
                     }
@@ -2968,15 +3001,19 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
                     h.node = (int)(uint32_t)u3.y;
                     h.kp = (uint32_t)(u3.y >> 32);
                     h.xf = (int)(uint32_t)u4.x - 1;
-                    if ((int)(uint32_t)u5.y != h.node) {  // the walk accepted a candidate of this instance
+                    int a_node = (int)(uint32_t)u5.y;
+                    const bool a_tied = TIE && tie_flagged(a_node);  // the walk met a triangle at exactly the best t (tie_order)
+                    if (a_tied) a_node ^= TIE_FLAG;
+                    if (a_node != h.node) {  // the walk accepted a candidate of this instance
                         hit_inside = true;
                         h.t = bitsd(u5.x);
-                        h.node = (int)(uint32_t)u5.y;
+                        h.node = a_node;
                         h.kp = (uint32_t)(u5.y >> 32);
                         h.xf = (int)A.inst2[inst].x;
                     }
                     pend = (PEND)(u4.y >> 32);
                     if (wide_pend) pend |= (PEND)(ld_unit(q, 10 + COOP_STACK_MAX / 4).x << 32);
+                    if (a_tied) pend = (PEND)0;  // the reference-order walk below answers for the whole ray
                     out_slot = (uint32_t)u4.y & 0xffffu;
                     if (pend != (PEND)0) {  // next deferred instance of the same segment: the path stays parked, new request
                         const uint32_t ni = (uint32_t)(__ffsll((long long)(uint64_t)pend) - 1);
@@ -2997,6 +3034,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
                         alive = true;
                         ready = true;
                         freed = true;
+                        if (a_tied) h = tie_resolve<1>(A, o, d, rk.t_min, INFINITY, h);
                     }
                 }
                 COOP_STAT(7, __ballot(hit_inside));
@@ -3055,7 +3093,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
         }
         COOP_TIME(4);
         // ---- serve: a wave's worth of requests waits ----
-        if (ring_len(C.rq) >= min((uint32_t)COOP_BATCH, (uint32_t)rk.coop_pool / 4u + 1u)) coop_serve(cargs, smem, stk, true COOP_STATS_PASS);
+        if (ring_len(C.rq) >= min((uint32_t)COOP_BATCH, (uint32_t)rk.coop_pool / 4u + 1u)) coop_serve<TIE>(cargs, smem, stk, true COOP_STATS_PASS);
         COOP_TIME(5);
         // ---- nothing in the lanes, nothing to adopt, no path to generate: fold / fetch, else serve whatever waits, else leave ----
         if (__ballot(alive) == 0ull && next >= pool && ring_len(C.aq) == 0u && __ballot(dec_slot >= 0) == 0ull) {
@@ -3076,7 +3114,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
             }
             if (!got_unit) {
                 if (ring_len(C.rq) != 0u) {
-                    coop_serve(cargs, smem, stk, false COOP_STATS_PASS);
+                    coop_serve<TIE>(cargs, smem, stk, false COOP_STATS_PASS);
                 } else if (finished && ring_len(C.fq) == (uint32_t)rk.coop_pool) {  // every pool slot is free again: no path is parked
                     break;
                 } else if (lds_load(C.rq.abort_flag) != 0u) {  // a ring overran (ring_pop): the frame is lost, leave instead of hanging
@@ -3180,9 +3218,57 @@ __global__ void hit_kernel(FlatView sv, int accel, size_t n, const double* rays,
     if (i >= n) return;
     D3 o = mk(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]), d = mk(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
     uint32_t* stk = (uint32_t*)(smem + stack_at) + threadIdx.x;
-    Hit h = (accel == 3) ? traverse2<true, false, false, true>(A, stk, (int)blockDim.x, o, d, t_min, t_max)
+    Hit h;
+    if (accel == 5 || accel == 6) {
+        // The walks of kernels 5 / 6 in one lane: the world-space walk with the large instances DEFERRED and exact ties noted (TIEDEF), then
+        // every deferred instance's object-space walk from that result -- 5: over Node2 / items / hoisted triangle records (coop_walk_inline's
+        // blas_pass), 6: over the compact NodeQ / Tri32 copies (the serving waves' blas_pass_q) -- with their tie bit, and the
+        // reference-order re-walk when a flag turns up.  (The parking, serving and adopting around these walks is pt_kernel_coop's.)
+        uint64_t pend = 0ull;
+        h = traverse2<true, true, false, false, uint64_t, false, true, false, false, true>(A, stk, (int)blockDim.x, o, d, t_min, t_max, &pend);
+        if (tie_flagged(h.xf)) {
+            h = tie_resolve<1>(A, o, d, t_min, t_max, h);
+            pend = 0ull;
+        }
+        bool tied = false;
+        ServeCtx X;
+        X.n2q = (const AS_G u32x4*)(sv.base + sv.off_n2q);
+        X.tri32 = (const AS_G u32x4*)(sv.base + sv.off_tri32);
+        X.n2q_top = nullptr;
+        X.n_topq = 0u;
+        while (pend != 0ull) {
+            const uint32_t ni = (uint32_t)(__ffsll((long long)pend) - 1);
+            pend &= pend - 1ull;
+            const uint2 in = A.inst2[ni];
+            const double* Minv = A.xforms + 32 * in.x;
+            const D3 oo = xf_point(Minv, o), dd = xf_dir(Minv, d);
+            double ht = h.t;
+            int hnode = h.node, sp = 0;
+            uint32_t hkp = 0u, cur = in.y;
+            if (accel == 5) {
+                const double a = sqlen(dd);
+                Ray32 r = make_ray32(oo, dd, t_min, h.t);
+                while (cur != REF_DONE) blas_pass<true>(A, true, stk, (int)blockDim.x, oo, dd, a, t_min, r, ht, hnode, hkp, cur, sp, err, tied);
+            } else {
+                const double* g = (const double*)(sv.base + sv.off_qgrid) + 8 * ni;  // the ray on the instance's grid: same t (QGrid, flat.h)
+                const D3 og = mk((oo.x - g[0]) * g[3] + g[6], (oo.y - g[1]) * g[4] + g[6], (oo.z - g[2]) * g[5] + g[6]);
+                const D3 dg = mk(dd.x * g[3], dd.y * g[4], dd.z * g[5]);
+                Ray32 r = make_ray32(og, dg, t_min, h.t);
+                while (cur != REF_DONE) blas_pass_q<true>(X, true, (AS_L uint32_t*)stk, (int)blockDim.x, oo, dd, t_min, r, ht, hnode, hkp, cur, sp, tied);
+            }
+            if (hnode != h.node) {
+                h.t = ht;
+                h.node = hnode;
+                h.kp = hkp;
+                h.xf = (int)in.x;
+            }
+        }
+        if (tied) h = tie_resolve<1>(A, o, d, t_min, t_max, h);
+    } else {
+        h = (accel == 3) ? traverse2<true, false, false, true>(A, stk, (int)blockDim.x, o, d, t_min, t_max)
           : (accel == 2) ? traverse2<true, false, false>(A, stk, (int)blockDim.x, o, d, t_min, t_max)
                          : traverse<true>(A, o, d, t_min, t_max);
+    }
     double* q = out + 12 * i;
     for (int k = 0; k < 12; k++) q[k] = 0.;
     if (h.node < 0) return;
@@ -3398,6 +3484,26 @@ static void render_tiles_wf(const rt_scene& s, const FlatView& view, const Camer
                             hipStream_t stream, rt_stats* st, int dev, const DevInfo& di, uint32_t stack6, uint32_t n_entry6, size_t lds_pt, uint32_t stack6w,
                             size_t tables_w);
 
+// Kernels 5 / 6 run their TIE variants ("EXACT ties" above traverse<>) for every scene that holds a rectangle or a cube: only those have
+// boxes that can BEGIN exactly where another surface lies (bvh.rs:88 + aabb.rs:28-30).  Scenes of spheres and triangle meshes alone keep the
+// variants without the flag (as the sphere-only variants of kernels 1 / 2 carry no tie code).
+static bool tie_scene(const FlatView& v) {
+    return TIE_RULE != 0 && (v.kinds_mask & ((1u << NK_RECT_YZ) | (1u << NK_RECT_XZ) | (1u << NK_RECT_XY) | (1u << NK_CUBE))) != 0u;
+}
+template <bool TIE>
+static void pick_coop(int integ, bool mixed, bool wide, pt_coop_fn& fn, pt_coop_fn& fn_early) {
+    if (wide) {
+        fn_early = (integ == 1) ? pt_kernel_coop<1, true, true, uint64_t, TIE> : (integ == 2) ? pt_kernel_coop<2, true, true, uint64_t, TIE> : pt_kernel_coop<0, true, true, uint64_t, TIE>;
+        fn = (integ == 1) ? pt_kernel_coop<1, true, false, uint64_t, TIE> : (integ == 2) ? pt_kernel_coop<2, true, false, uint64_t, TIE> : pt_kernel_coop<0, true, false, uint64_t, TIE>;
+    } else if (mixed) {
+        fn_early = (integ == 1) ? pt_kernel_coop<1, true, true, uint32_t, TIE> : (integ == 2) ? pt_kernel_coop<2, true, true, uint32_t, TIE> : pt_kernel_coop<0, true, true, uint32_t, TIE>;
+        fn = (integ == 1) ? pt_kernel_coop<1, true, false, uint32_t, TIE> : (integ == 2) ? pt_kernel_coop<2, true, false, uint32_t, TIE> : pt_kernel_coop<0, true, false, uint32_t, TIE>;
+    } else {
+        fn_early = (integ == 1) ? pt_kernel_coop<1, false, true, uint32_t, TIE> : (integ == 2) ? pt_kernel_coop<2, false, true, uint32_t, TIE> : pt_kernel_coop<0, false, true, uint32_t, TIE>;
+        fn = (integ == 1) ? pt_kernel_coop<1, false, false, uint32_t, TIE> : (integ == 2) ? pt_kernel_coop<2, false, false, uint32_t, TIE> : pt_kernel_coop<0, false, false, uint32_t, TIE>;
+    }
+}
+
 void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& plan_in, double* d_tiles, void* stream_, rt_stats* st) {
     if (!s.committed) throw RtError(RT_ERR_NOT_COMMITTED, "scene not committed");
     const Tuning tun = tuning();  // one snapshot per call
@@ -3413,6 +3519,12 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
     // D9: moving spheres, noise textures and an open shutter (every sample draws a time) live in their own kernel variants (GENERAL == 2,
     // kernels 1 / 2, integrator 0): nothing of them is compiled into the others
     const bool book2 = moving || view.has_noise != 0 || plan.time1 > plan.time0;
+    if (moving) {  // a moving sphere's box covers its positions between ITS time0 and time1 only (scene.cpp: add_moving_sphere)
+        const double sh0 = plan.time0, sh1 = plan.time1 > plan.time0 ? plan.time1 : plan.time0;
+        if (!(sh0 >= s.flat.msph_t0_max && sh1 <= s.flat.msph_t1_min))
+            throw RtError(RT_ERR_ARG, "the shutter [time0, time1] = [" + std::to_string(sh0) + ", " + std::to_string(sh1) + "] must lie inside [time0, time1] of every moving sphere ([" +
+                                          std::to_string(s.flat.msph_t0_max) + ", " + std::to_string(s.flat.msph_t1_min) + "] for this scene): their boxes are built for that range");
+    }
     const bool general = (view.kinds_mask & ~((1u << NK_BOX) | (1u << NK_SPHERE))) != 0 || book2;
     const size_t lds_max = di.lds_max - (moving ? (size_t)PT_BLOCK * sizeof(double) : 0);
     // The accel kernels need the camera inside the region the f32 boxes were padded for (flatten.cpp: origin_limit2) and
@@ -3479,14 +3591,11 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
     pt_fn fn = (kernel == 1) ? pick_pt_kernel<1>(lds, general, integ) : pick_pt_kernel<2>(lds, general, integ);
     pt_coop_fn fn_coop = nullptr;
     pt_coop_fn fn_coop_early = nullptr;  // the variant that folds from the main loop: for a rank that owns few tiles (see pt_kernel_coop)
-    if (kernel == 5 && view.n_inst2 <= 32u) {
-        fn_coop_early = (view.n_inline2 != 0u) ? ((integ == 1) ? pt_kernel_coop<1, true, true> : (integ == 2) ? pt_kernel_coop<2, true, true> : pt_kernel_coop<0, true, true>)
-                                               : ((integ == 1) ? pt_kernel_coop<1, false, true> : (integ == 2) ? pt_kernel_coop<2, false, true> : pt_kernel_coop<0, false, true>);
-        fn_coop = (view.n_inline2 != 0u) ? ((integ == 1) ? pt_kernel_coop<1, true> : (integ == 2) ? pt_kernel_coop<2, true> : pt_kernel_coop<0, true>)
-                                         : ((integ == 1) ? pt_kernel_coop<1> : (integ == 2) ? pt_kernel_coop<2> : pt_kernel_coop<0>);
-    } else if (kernel == 5) {  // 33..64 instances: the 64-bit pending mask (the MIXED code covers scenes without inline instances too)
-        fn_coop_early = (integ == 1) ? pt_kernel_coop<1, true, true, uint64_t> : (integ == 2) ? pt_kernel_coop<2, true, true, uint64_t> : pt_kernel_coop<0, true, true, uint64_t>;
-        fn_coop = (integ == 1) ? pt_kernel_coop<1, true, false, uint64_t> : (integ == 2) ? pt_kernel_coop<2, true, false, uint64_t> : pt_kernel_coop<0, true, false, uint64_t>;
+    if (kernel == 5) {
+        // 33..64 instances: the 64-bit pending mask (the MIXED code covers scenes without inline instances too); exact ties: see tie_scene()
+        const bool wide = view.n_inst2 > 32u, mixed = view.n_inline2 != 0u;
+        if (tie_scene(view)) pick_coop<true>(integ, mixed, wide, fn_coop, fn_coop_early);
+        else pick_coop<false>(integ, mixed, wide, fn_coop, fn_coop_early);
     }
     if (media)
         fn = (kernel == 2) ? (lds ? pt_kernel<true, true, 2, 0, true> : pt_kernel<false, true, 2, 0, true>)
@@ -3724,8 +3833,12 @@ static void render_tiles_wf(const rt_scene& s, const FlatView& view, const Camer
     if (integ == 1 && view.n_lights == 0) throw RtError(RT_ERR_ARG, "integrator 1 (light importance sampling) needs rt_scene_set_lights");
     if (integ == 2 && !plan.sppm_est) throw RtError(RT_ERR_ARG, "integrator 2 (SPPM) is reached through rt_render_sppm");
     typedef void (*pt_wf_fn)(FlatView, CamK, RenderK, double*, double*, unsigned int*, unsigned int*, int*, WfArgs);
-    pt_wf_fn fn = (view.n_inline2 != 0u) ? ((integ == 1) ? pt_kernel_wf<1, true> : (integ == 2) ? pt_kernel_wf<2, true> : pt_kernel_wf<0, true>)
-                                         : ((integ == 1) ? pt_kernel_wf<1> : (integ == 2) ? pt_kernel_wf<2> : pt_kernel_wf<0>);
+    const bool tie = tie_scene(view);  // the TIE variants of both launches ("EXACT ties" above traverse<>)
+    pt_wf_fn fn = tie ? ((view.n_inline2 != 0u) ? ((integ == 1) ? pt_kernel_wf<1, true, true> : (integ == 2) ? pt_kernel_wf<2, true, true> : pt_kernel_wf<0, true, true>)
+                                                : ((integ == 1) ? pt_kernel_wf<1, false, true> : (integ == 2) ? pt_kernel_wf<2, false, true> : pt_kernel_wf<0, false, true>))
+                      : ((view.n_inline2 != 0u) ? ((integ == 1) ? pt_kernel_wf<1, true> : (integ == 2) ? pt_kernel_wf<2, true> : pt_kernel_wf<0, true>)
+                                                : ((integ == 1) ? pt_kernel_wf<1> : (integ == 2) ? pt_kernel_wf<2> : pt_kernel_wf<0>));
+    void (*fn_walk)(FlatView, WfWalkK) = tie ? wf_walk_kernel<true> : wf_walk_kernel<false>;
     if (lds_pt > 48 * 1024) HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pt));
     int bpc = 0;
     HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)fn, PT_BLOCK, lds_pt));
@@ -3738,9 +3851,9 @@ static void render_tiles_wf(const rt_scene& s, const FlatView& view, const Camer
     uint32_t n_topq_w = (uint32_t)std::min<size_t>((share - tables_w - stacks_w) / sizeof(NodeQ), view.n_nodes2);
     if (tun.n_top >= 0) n_topq_w = std::min<uint32_t>(n_topq_w, (uint32_t)tun.n_top);
     const size_t lds_walk = tables_w + coop_a16(n_topq_w * (uint32_t)sizeof(NodeQ)) + stacks_w;
-    if (lds_walk > 48 * 1024) HIP_CHECK(hipFuncSetAttribute((const void*)wf_walk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_walk));
+    if (lds_walk > 48 * 1024) HIP_CHECK(hipFuncSetAttribute((const void*)fn_walk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_walk));
     int bpc_w = 0;
-    HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc_w, (const void*)wf_walk_kernel, WF_WALK_BLOCK, lds_walk));
+    HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc_w, (const void*)fn_walk, WF_WALK_BLOCK, lds_walk));
     if (bpc_w < 1) bpc_w = 1;
     const int grid_w = di.cus * bpc_w;
     // Workspace within a budget (rt_tuning.wf_workspace_mb; default 1 900 MB -- the first version took 8.6 GB flat: 96 unit buffers per
@@ -3828,7 +3941,7 @@ static void render_tiles_wf(const rt_scene& s, const FlatView& view, const Camer
                 wk.n_topq = n_topq_w;
                 wk.stack = stack6w;
                 wk.t_min = plan.t_min;
-                hipLaunchKernelGGL(wf_walk_kernel, dim3(grid_w), dim3(WF_WALK_BLOCK), lds_walk, stream, view, wk);
+                hipLaunchKernelGGL(fn_walk, dim3(grid_w), dim3(WF_WALK_BLOCK), lds_walk, stream, view, wk);
                 HIP_CHECK(hipGetLastError());
                 launches++;
             }
@@ -4226,11 +4339,15 @@ void debug_hit_device(const rt_scene& s, int kernel, size_t n, const double* ray
     err.alloc(4);
     HIP_CHECK(hipMemset(err.p, 0, 4));
     HIP_CHECK(hipMemcpy(dr.p, rays, n * 48, hipMemcpyHostToDevice));
-    if ((kernel == 2 || kernel == 3) && !view.accel_ok) throw RtError(RT_ERR_UNSUPPORTED, "no accel for this scene");
-    if ((kernel == 2 || kernel == 3) && !(t_min >= 0.)) throw RtError(RT_ERR_UNSUPPORTED, "kernel 2 needs t_min >= 0 (box32)");
+    if (kernel < 1 || kernel > 6 || kernel == 4) throw RtError(RT_ERR_ARG, "rt_debug_hit_device: kernel 1, 2, 3, 5 or 6");
+    if (kernel != 1 && !view.accel_ok) throw RtError(RT_ERR_UNSUPPORTED, "no accel for this scene");
+    if (kernel != 1 && !(t_min >= 0.)) throw RtError(RT_ERR_UNSUPPORTED, "kernel 2 needs t_min >= 0 (box32)");
+    if ((kernel == 5 || kernel == 6) && (view.coop_data_ok == 0 || view.n_inst2 < 1 || view.n_inst2 > (uint32_t)COOP_MAX_INST))
+        throw RtError(RT_ERR_UNSUPPORTED, "the instance walks of kernels 5 / 6 need 1..64 instances of which at least one holds only f32-vertex triangles");
     if (view.kinds_mask & (1u << NK_MEDIUM_BEGIN))
         throw RtError(RT_ERR_UNSUPPORTED, "closest-hit queries on a scene with a ConstantMedium need the path's random stream");
     size_t smem = (kernel == 2 || kernel == 3) ? view.stack2 * 64 * sizeof(uint32_t) : 0;
+    if (kernel == 5 || kernel == 6) smem = (size_t)std::max(std::max(view.world_depth2, view.inst_depth2) + 2u, view.stack2_inline) * 64 * sizeof(uint32_t);
     if (kernel == 3) {  // kernel 2's LDS node table (NodeW, box32w) in isolation: the table must fit beside the stacks
         smem += ((size_t)(view.n_nodes2 + NODEW_CHUNK - 1) / NODEW_CHUNK) * 3 * NODEW_FAR;
         if (smem > 160 * 1024) throw RtError(RT_ERR_UNSUPPORTED, "the NodeW table of this scene does not fit in LDS");

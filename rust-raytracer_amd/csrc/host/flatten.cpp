@@ -698,6 +698,12 @@ void flatten(rt_scene& s) {
     for (auto& tx : s.textures) v.has_noise |= (tx.type == TEX_NOISE) ? 1u : 0u;
     v.off_msph = append(f.blob, b.msph);
     v.n_msph = (uint32_t)(b.msph.size() / 10);
+    f.msph_t0_max = -1e300;
+    f.msph_t1_min = 1e300;
+    for (size_t i = 0; i + 10 <= b.msph.size(); i += 10) {
+        f.msph_t0_max = std::max(f.msph_t0_max, b.msph[i + 6]);
+        f.msph_t1_min = std::min(f.msph_t1_min, b.msph[i + 7]);
+    }
     {   // where the reference-order program lies in the blob, for the one walk that must read it from global memory whatever the
         // kernel staged (tie_resolve, kernels.hip); the last word is the record's own offset
         std::vector<uint32_t> tv = {v.off_meta, v.off_boxes, v.off_spheres, v.off_rects, v.off_tripre, v.off_xforms, 0u, (uint32_t)(b.meta.size() / 2)};

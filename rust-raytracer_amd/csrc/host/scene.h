@@ -66,6 +66,9 @@ struct FlatScene {
     std::vector<char> blob;
     FlatView view{};  // base == nullptr on the host copy
     rt_scene_info info{};
+    // D9: the time range every moving sphere of the scene is defined on = [latest time0, earliest time1] (their boxes are the unions of the
+    // boxes at those two times, scene.cpp: a ray time outside it would move a centre out of its committed box); render_tiles checks the shutter
+    double msph_t0_max = -1e300, msph_t1_min = 1e300;
 };
 
 struct DeviceCopy {

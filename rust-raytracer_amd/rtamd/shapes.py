@@ -29,6 +29,42 @@ def torus(nu=160, nv=320, R=1.0, r=0.4):
     return pos.astype(np.float32).astype(np.float64), nrm.astype(np.float32).astype(np.float64), idx
 
 
+def sheet(n=8, size=(2.0, 2.0)):
+    """A flat n x n grid of quads (2 n^2 triangles) in the plane y = 0, x in [0, size[0]], z in [0, size[1]], normals (0, 1, 0): laid
+    exactly on a Cube's face or a rectangle (integer / dyadic coordinates) its triangles share their t with that surface -- bit for bit for a
+    fair share of the rays, since both are the same plane -- which is what the exact-tie tests of kernels 5 / 6 need from a mesh instance."""
+    g = np.arange(n + 1) / n
+    xx, zz = np.meshgrid(g * size[0], g * size[1], indexing="ij")
+    pos = np.stack([xx, np.zeros_like(xx), zz], axis=-1).reshape(-1, 3)
+    nrm = np.tile(np.array([0.0, 1.0, 0.0]), (pos.shape[0], 1))
+    i, j = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    a, b, c, d = i * (n + 1) + j, (i + 1) * (n + 1) + j, (i + 1) * (n + 1) + j + 1, i * (n + 1) + j + 1
+    idx = np.concatenate([np.stack([a, b, c], axis=-1).reshape(-1, 3), np.stack([a, c, d], axis=-1).reshape(-1, 3)]).astype(np.uint32)
+    return pos.astype(np.float32).astype(np.float64), nrm, idx
+
+
+def box_mesh(n=4, size=(1.0, 1.0, 1.0)):
+    """A closed axis-aligned box [0, size] as a triangle mesh: six faces of n x n quads (12 n^2 triangles), one normal per face (vertices
+    are duplicated along the edges, as an OBJ with per-face normals loads under tobj's single_index)."""
+    P, N, I = [], [], []
+    g = np.arange(n + 1) / n
+    for axis in range(3):
+        for side in (0, 1):
+            u, v = [a for a in range(3) if a != axis]
+            uu, vv = np.meshgrid(g * size[u], g * size[v], indexing="ij")
+            pos = np.zeros(uu.shape + (3,))
+            pos[..., u], pos[..., v], pos[..., axis] = uu, vv, side * size[axis]
+            nrm = np.zeros(3)
+            nrm[axis] = 1.0 if side else -1.0
+            base = sum(p.shape[0] for p in P)
+            P.append(pos.reshape(-1, 3))
+            N.append(np.tile(nrm, ((n + 1) ** 2, 1)))
+            i, j = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+            a, b, c, d = i * (n + 1) + j, (i + 1) * (n + 1) + j, (i + 1) * (n + 1) + j + 1, i * (n + 1) + j + 1
+            I.append(base + np.concatenate([np.stack([a, b, c], axis=-1).reshape(-1, 3), np.stack([a, c, d], axis=-1).reshape(-1, 3)]))
+    return (np.concatenate(P).astype(np.float32).astype(np.float64), np.concatenate(N), np.concatenate(I).astype(np.uint32))
+
+
 def cornell_with_mesh(world_or_scene, positions, normals, indices, scale=120.0, translate=(278.0, 200.0, 278.0), rotate=(30.0, 20.0, 0.0),
                       seed=1, mesh_fn=None):
     """scene.rs:16-112 with the cube.obj mesh replaced by a given mesh (C4).  Works on both builders

@@ -191,3 +191,121 @@ def test_cube_with_light_sampling_and_sppm_bit_exact():
     img, stats, tot, _ = w.render_sppm(cam, width=32, height=32, spp=3, seed=2, iterations=3, photons_per_iter=5000)
     exp, est, etot = o.render_sppm(32, 32, 3, iterations=3, photons_per_iter=5000, k_global=100, k_caustic=50, seed=2)
     assert tot == etot and np.array_equal(stats, est) and np.array_equal(img, exp, equal_nan=True)
+
+
+# ---- the exact-tie rule in the instance service (kernels 5 / 6): the same cubes and rectangles beside LARGE mesh instances -------------------
+def _mesh(B, PNI, mat, seed):
+    P, N, I = PNI
+    try:
+        return B.Mesh(P, N, I, mat, bvh_seed=seed)
+    except TypeError:   # the oracle's builder takes the seed by position
+        return B.Mesh(P, N, I, mat, seed)
+
+
+def _build_with_instances(B, variant):
+    """_build's cubes and rectangles plus five mesh instances whose object-space BVHs have >= 64 nodes (kernel 5 defers them): a torus leaning
+    into the cubes, and four meshes with faces EXACTLY coplanar with a cube face or a rectangle -- a sheet on a cube's top, a sheet on the
+    floor, a glass box on the floor against the back wall, a glass box stacked on the glass cube -- so that a triangle and a world-level
+    surface (or a triangle of another instance) share the closest t bit for bit for a fair share of the rays."""
+    from rtamd import shapes
+    items = _build(B, variant)
+    glass = B.Dielectric(1.5, B.ConstantTexture((1.0, 1.0, 1.0)))
+    grey = B.Lambertian(B.ConstantTexture((0.5, 0.6, 0.7)))
+    mirror = B.Metal(B.ConstantTexture((0.9, 0.8, 0.7)), 0.0)
+    none, one = (0.0, 0.0, 0.0), (1.0, 1.0, 1.0)
+    items.append(B.Transform((25.0, 40.0, 10.0), (1.2, 1.2, 1.2), (1.5, 2.2, 0.5), _mesh(B, shapes.torus(12, 20), glass, 5)))
+    items.append(B.Transform(none, one, (2.0, 1.5, 0.0), _mesh(B, shapes.sheet(8, (2.0, 2.0)), grey, 6)))        # on the red cube's top, y = 1.5
+    items.append(B.Transform(none, one, (-1.0, 0.0, -3.0), _mesh(B, shapes.sheet(8, (4.0, 2.0)), mirror, 7)))    # on the floor rectangle, y = 0
+    items.append(B.Transform(none, one, (7.0, 0.0, 5.0), _mesh(B, shapes.box_mesh(4, (1.0, 1.0, 1.0)), glass, 8)))   # on the floor, against the wall z = 6
+    items.append(B.Transform(none, one, (-3.0, 2.5, -1.0), _mesh(B, shapes.box_mesh(4, (2.0, 1.0, 2.0)), glass, 9)))  # stacked on the glass cube (its top y = 2.5)
+    return items
+
+
+_INST = {}
+
+
+def _pair_with_instances(variant):
+    if variant not in _INST:
+        import oracle
+        import rtamd
+        w = rtamd.World()
+        o = oracle.Scene()
+        w.new(_build_with_instances(w, variant), bvh_seed=3)
+        o.World(_build_with_instances(o, variant), 3)
+        cam_args = ((1.0, 3.5, -9.0), (1.0, 1.5, 0.0), (0.0, 1.0, 0.0), 50.0, 4.0 / 3.0, 0.05, 9.0)
+        o.Camera(*cam_args)
+        f, t, up, vfov, asp, ap, fd = cam_args
+        _INST[variant] = (w, rtamd.Camera((f, t), up, vfov, asp, ap, fd), o)
+    return _INST[variant]
+
+
+def _lattice_rays(n=2500):
+    """origins on the half-integer lattice, direction components multiples of 1/8, none zero: every product and quotient of the plane tests and
+    of Triangle::hit is exact or nearly so, which makes coplanar surfaces tie bit for bit; no ray lies IN a plane (the NaN case of SURVEY a11)"""
+    rng = np.random.default_rng(77)
+    o = rng.integers(-8, 18, (n, 3)) / 2.0 + np.array([0.0, 0.0, -2.0])
+    d = rng.integers(1, 9, (n, 3)) / 8.0 * rng.choice([-1.0, 1.0], (n, 3))
+    d[: n // 2, 1] = -np.abs(d[: n // 2, 1])        # half of them downwards: onto the sheets, the cubes' tops and the floor
+    return np.concatenate([o, d], axis=1)
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_instance_service_walks_follow_the_reference_on_exact_ties(variant):
+    """closest-hit records of the walks of kernels 5 / 6 (rt_debug_hit_device 5: Node2 / item records, 6: compact NodeQ / Tri32) against the
+    oracle and the reference-order kernel on rays that provoke exact ties between triangles of deferred instances and cubes / rectangles."""
+    world, _, ref = _pair_with_instances(variant)
+    info = world.info()
+    assert info["accel_compact"] == 1 and info["accel_instances"] >= 5
+    rays = np.concatenate([_lattice_rays(), _rays()])
+    planes = [{0.0, 2.0, 4.0, -3.0, -1.0, 5.0, 6.0, 7.0, 8.0}, {0.0, 1.0, 1.5, 2.0, 2.5, 3.0, 3.5}, {0.0, 1.0, 2.0, -1.0, -2.0, -3.0, 5.0, 6.0}]
+    ok = np.array([not any(r[3 + a] == 0.0 and r[a] in planes[a] for a in range(3)) for r in rays])
+    outs = {k: world.debug_hit(rays, t_min=1e-3, kernel=k) for k in (1, 2, 5, 6)}
+    ties = 0
+    for i, r in enumerate(rays):
+        if not ok[i]:
+            continue
+        h = ref.hit(r[:3], r[3:], t_min=1e-3)
+        for k, out in outs.items():
+            got = out[i]
+            assert (h is not None) == bool(got[0]), "ray %d kernel %d: hit/miss mismatch (%s)" % (i, k, r)
+            if h is None:
+                continue
+            assert got[1] == h["t"], (i, k, got[1], h["t"])
+            assert np.array_equal(got[2:5], h["p"]) and np.array_equal(got[5:8], h["normal"]) and bool(got[8]) == h["front_face"], (i, k)
+        if h is not None and r[4] < 0.0:   # rays that land from above on a sheet lying on a cube's top / on the floor: two coplanar surfaces
+            px, py, pz = h["p"]
+            ties += (py == 1.5 and 2.0 <= px <= 4.0 and 0.0 <= pz <= 2.0) or (py == 0.0 and -1.0 <= px <= 3.0 and -3.0 <= pz <= -1.0)
+    for k in (2, 5, 6):   # all 12 fields incl. the winning leaf's program index (variant 0 emits no object twice)
+        same = np.array_equal(outs[1][ok][:, :11], outs[k][ok][:, :11], equal_nan=True)
+        assert same, "kernel %d: %d records differ from the reference-order walk" % (k, int((outs[1][ok][:, :11] != outs[k][ok][:, :11]).any(axis=1).sum()))
+    assert np.array_equal(outs[5][ok], outs[6][ok]) and np.array_equal(outs[2][ok], outs[5][ok])
+    assert ties > 20, ties
+
+
+@pytest.mark.parametrize("kernel", [0, 2, 5, 6])
+@pytest.mark.parametrize("variant", [0, 1])
+def test_cube_scene_with_mesh_instances_renders_bit_exact(variant, kernel):
+    """the rendered image, strict, with the instance service: the camera looks at sheets lying on cube faces and glass boxes sharing faces with
+    cubes, rectangles and each other (exact ties at every bounce through them)"""
+    world, cam, ref = _pair_with_instances(variant)
+    img, st = world.render(cam, width=96, height=72, spp=12, seed=4, kernel=kernel)
+    exp, _ = ref.render(96, 72, 12, seed=4)
+    assert st["kernel_used"] == (5 if kernel == 0 else kernel)
+    assert np.array_equal(img, exp, equal_nan=True), "%d pixels differ" % int((img != exp).any(axis=2).sum())
+    img1, _ = world.render(cam, width=96, height=72, spp=12, seed=4, kernel=1)
+    assert np.array_equal(img, img1, equal_nan=True) and img.max() > 0
+
+
+def test_instance_service_ties_through_pool_exhaustion_and_partitions(tuning):
+    """the same frame through kernel 5's in-lane fallback (coop_walk_inline: its own tie bit) and as three ranks' tiles"""
+    world, cam, ref = _pair_with_instances(0)
+    exp, _ = ref.render(96, 72, 12, seed=4)
+    tuning(coop_pool=8)
+    img, st = world.render(cam, width=96, height=72, spp=12, seed=4, kernel=5)
+    tuning()
+    assert st["kernel_used"] == 5 and np.array_equal(img, exp, equal_nan=True)
+    acc = np.zeros_like(exp)
+    for r in range(3):
+        part, _ = world.render(cam, width=96, height=72, spp=12, seed=4, rank=r, world=3, kernel=5)
+        acc += part
+    assert np.array_equal(acc, exp, equal_nan=True)
