@@ -1143,7 +1143,7 @@ int rt_debug_math_device(int op, size_t n, const double* a_host, const double* b
 }
 int rt_debug_hit_device(const rt_scene* s, int kernel, size_t n, const double* rays_host, double t_min, double t_max, double* out_host) {
     return guard([&] {
-        REQUIRE(s && n > 0 && rays_host && out_host && (kernel == 1 || kernel == 2 || kernel == 3), "bad argument");
+        REQUIRE(s && n > 0 && rays_host && out_host && (kernel == 1 || kernel == 2 || kernel == 3 || kernel == 5 || kernel == 6), "bad argument");
         if (device_count() < 1) throw RtError(RT_ERR_NO_DEVICE, "no HIP device");
         debug_hit_device(*s, kernel, n, rays_host, t_min, t_max, out_host);
         return (int)RT_OK;

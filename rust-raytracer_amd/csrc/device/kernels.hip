@@ -488,6 +488,16 @@ struct Hit {
 #endif
 #define TIE_FLAG 0x40000000  // in Hit::xf (-1 or a small index): bits 30 and 31 differ <=> the hit is an exact tie of two objects
 DEV bool tie_flagged(int xf) { return (((uint32_t)xf >> 30) & 1u) != ((uint32_t)xf >> 31); }
+// NEAR ties (round 5).  "Exactly" above is too narrow: the reference's box test computes a box's entry as (min - o) * (1 / d) (aabb.rs:20-21)
+// while a rectangle's own t is (k - o) / d and a triangle's comes out of Moeller-Trumbore -- three roundings of the same real number.  When
+// the later object Y (exact box, entered through the face in question) and the earlier object X lie in ONE plane, the reference visits Y iff
+// fl((k - o) * fl(1 / d)) < t_X, and that differs from "t_Y <= t_X" (what a closest-hit walk decides) whenever t_X falls into the one or two
+// ulps between t_Y and Y's box entry: 1 ray in 10 000 on a mesh face lying on a cube face (tools/tie_soak.py inst, round 5: 0.26382042861594929
+// for the triangle, ...923 for the cube side; the reference keeps the triangle).  So the walks flag every pair of candidates whose t differ by
+// at most TIE_W - 1 (8 ulps: the box entry is within 1.5 ulps of t_Y), whichever of the two is closer, and let the reference-order walk decide:
+// the primitive tests see [t_min, best * TIE_W] in the TIE variants, a candidate beyond `best` is never accepted, only noted.  A flag that was
+// not needed costs a re-walk and returns the same hit.
+#define TIE_W (1.0 + 1.7763568394002505e-15)
 
 // World::hit -> BVHNode::hit / Vec::hit / Transform::hit, flattened (common/flat.h).
 // Visits nodes in the reference's own order; a leaf is accepted when t_min <= t <= best
@@ -643,6 +653,25 @@ __device__ __noinline__ Hit tie_resolve(const Acc& A, D3 wo, D3 wd, double t_min
     return traverse<GENERAL, false>(G, wo, wd, t_min, t_max);
 }
 #endif
+
+// The same for kernels 5 / 6, whose scene view lives in registers (LDS pointers): handing over the Acc by reference put it into scratch memory
+// for the whole kernel (pt_kernel_coop: 560 -> 976 bytes of scratch per lane, C4 -30 %).  These kernels render neither media nor the book-2
+// kinds, so the walk needs nothing but the program's tables, which the tie view (one pointer) locates.
+__device__ __noinline__ Hit tie_resolve_view(const uint32_t* tv, double ox, double oy, double oz, double dx, double dy, double dz, double t_min, double t_max) {
+    Acc G;
+    const char* g = (const char*)tv - tv[6];
+    G.meta = (const uint2*)(g + tv[0]);
+    G.boxes = (const double2*)(g + tv[1]);
+    G.spheres = (const double2*)(g + tv[2]);
+    G.rects = (const double2*)(g + tv[3]);
+    G.tripre = (const double2*)(g + tv[4]);
+    G.xforms = (const double*)(g + tv[5]);
+    G.n_nodes = tv[7];
+    G.media = nullptr;  // (never read: a scene with a ConstantMedium does not reach kernels 5 / 6)
+    G.msph = nullptr;
+    G.time_lds = 0u;
+    return traverse<1, false>(G, mk(ox, oy, oz), mk(dx, dy, dz), t_min, t_max);
+}
 
 // ---------------------------------------------------------------- kernel 2 traversal ----
 // Conservative f32 slab test of one child box of a Node2: 6 fma + 6 min/max + max3/min3 + one multiply.
@@ -920,7 +949,8 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
                 double t = 0.;
                 bool got = false;
                 uint32_t cube_side = 0u;  // NK_CUBE: the winning side goes into the hit's kp
-                const double t_far = TRACK ? track_bound(*track, h.t) : h.t;  // how far a candidate may lie
+                // how far a candidate may lie (TIE: a little beyond the best hit, to note near ties -- see TIE_W)
+                const double t_far = TRACK ? track_bound(*track, TIE ? h.t * TIE_W : h.t) : (TIE ? h.t * TIE_W : h.t);
                 if (LIMIT && it.y >= order_limit) {
                     // visited by the reference after the medium in question (an instance's subtree is contiguous in the program and
                     // media are world-level, so an instance lies wholly before or wholly after it: its item's order decides)
@@ -948,24 +978,24 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
                         if (it.y < track->lim[0] && t < track->T[0]) track->T[0] = t;
                         if (it.y < track->lim[1] && t < track->T[1]) track->T[1] = t;
                         if (t < h.t || (t == h.t && (int)it.y > h.node) || !(t == t)) {  // (a candidate may lie beyond the best hit here)
-                            const bool tied = TIE && t == h.t && h.node >= 0;
+                            const bool tied = TIE && h.node >= 0 && t * TIE_W >= h.t;  // (near) tie with the hit it replaces
                             h.t = t;
                             h.node = (int)it.y;
                             h.xf = tied ? (cur_xf ^ TIE_FLAG) : cur_xf;
                             h.kp = it.x + (cube_side << NK_BITS);
                             best_all32 = ray32_best(t);
-                        } else if (TIE && t == h.t && (int)it.y < h.node && !tie_flagged(h.xf)) {  // the candidate is the earlier party
+                        } else if (TIE && !(t > h.t * TIE_W) && (int)it.y < h.node && !tie_flagged(h.xf)) {  // the candidate is the earlier party of a (near) tie
                             h.xf ^= TIE_FLAG;
                         }
                         r.best = ray32_best(track_bound(*track, h.t));
                     }
                 } else if (got) {
-                    // accepted candidates satisfy t <= h.t; an exact tie goes to the later one in reference order (and is noted: tie_resolve)
-                    if (!(t < h.t || (int)it.y > h.node || !(t == t))) {
-                        if (TIE && (int)it.y < h.node && !tie_flagged(h.xf)) h.xf ^= TIE_FLAG;  // t == h.t and the candidate is the earlier party
+                    // candidates satisfy t <= h.t (TIE: h.t * TIE_W); an exact tie goes to the later one in reference order; (near) ties are noted: tie_resolve
+                    if (TIE ? !(t < h.t || (t == h.t && (int)it.y > h.node) || !(t == t)) : !(t < h.t || (int)it.y > h.node || !(t == t))) {
+                        if (TIE && (int)it.y < h.node && !tie_flagged(h.xf)) h.xf ^= TIE_FLAG;  // t within the tie margin of h.t and the candidate is the earlier party
                         continue;
                     }
-                    const bool tied = TIE && t == h.t && h.node >= 0;
+                    const bool tied = TIE && h.node >= 0 && t * TIE_W >= h.t;
                     h.t = t;
                     h.node = (int)it.y;
                     h.xf = tied ? (cur_xf ^ TIE_FLAG) : cur_xf;
@@ -2333,25 +2363,26 @@ DEV void blas_pass(const Acc& A, bool act, uint32_t* stk, const int stride, D3 o
             double t = 0.;
             bool got = false;
             uint32_t cube_side = 0u;
+            const double t_far = TIE ? ht * TIE_W : ht;  // (TIE: a little beyond the best hit, to note near ties -- see TIE_W)
             if (kind == NK_SPHERE) {
-                got = sphere_hit(A.spheres + 2 * pl, o, d, a, t_min, ht, t);
+                got = sphere_hit(A.spheres + 2 * pl, o, d, a, t_min, t_far, t);
             } else if (kind == NK_RECT_YZ || kind == NK_RECT_XZ || kind == NK_RECT_XY) {
-                got = rect_hit(A.rects + 3 * pl, (int)kind - (int)NK_RECT_YZ, o, d, t_min, ht, t);
+                got = rect_hit(A.rects + 3 * pl, (int)kind - (int)NK_RECT_YZ, o, d, t_min, t_far, t);
             } else if (kind == NK_CUBE) {
-                got = cube_hit(A.rects + 3 * (pl >> 3), o, d, t_min, ht, t, cube_side);
+                got = cube_hit(A.rects + 3 * (pl >> 3), o, d, t_min, t_far, t, cube_side);
             } else if (kind == NK_TRI) {
                 double b1, b2;
-                got = tri_hit(A.tripre2 + 5 * (first + i), o, d, t_min, ht, t, b1, b2);
+                got = tri_hit(A.tripre2 + 5 * (first + i), o, d, t_min, t_far, t, b1, b2);
             } else {
                 atomicOr(err, 2);  // an instance below an instance: flatten.cpp refuses such scenes
             }
-            if (got && (t < ht || (int)it.y > hnode || !(t == t))) {
-                if (TIE) tied = t == ht && hnode >= 0;
+            if (got && (TIE ? (t < ht || (t == ht && (int)it.y > hnode) || !(t == t)) : (t < ht || (int)it.y > hnode || !(t == t)))) {
+                if (TIE) tied = hnode >= 0 && t * TIE_W >= ht;
                 ht = t;
                 hnode = (int)it.y;
                 hkp = it.x + (cube_side << NK_BITS);
                 r.best = ray32_best(t);
-            } else if (TIE && got && (int)it.y < hnode) {  // t == ht and the candidate is the earlier party
+            } else if (TIE && got && (int)it.y < hnode) {  // within the tie margin of ht and the candidate is the earlier party
                 tied = true;
             }
         }
@@ -2432,14 +2463,14 @@ DEV void blas_pass_q(const ServeCtx& X, bool act, AS_L uint32_t* stk, const int 
             const D3 pb = mk((double)__uint_as_float(a.w), (double)__uint_as_float(b.x), (double)__uint_as_float(b.y));
             const D3 pc = mk((double)__uint_as_float(b.z), (double)__uint_as_float(b.w), (double)__uint_as_float(c.x));
             double t = 0., b1, b2;
-            const bool got = tri_hit_v(pa, sub(pb, pa), sub(pc, pa), o, d, t_min, ht, t, b1, b2);
-            if (got && (t < ht || (int)c.y > hnode || !(t == t))) {
-                if (TIE) tied = t == ht && hnode >= 0;
+            const bool got = tri_hit_v(pa, sub(pb, pa), sub(pc, pa), o, d, t_min, TIE ? ht * TIE_W : ht, t, b1, b2);  // (TIE: see TIE_W)
+            if (got && (TIE ? (t < ht || (t == ht && (int)c.y > hnode) || !(t == t)) : (t < ht || (int)c.y > hnode || !(t == t)))) {
+                if (TIE) tied = hnode >= 0 && t * TIE_W >= ht;
                 ht = t;
                 hnode = (int)c.y;
                 hkp = c.z;
                 r.best = ray32_best(t);
-            } else if (TIE && got && (int)c.y < hnode) {  // t == ht and the triangle is the earlier party
+            } else if (TIE && got && (int)c.y < hnode) {  // within the tie margin of ht and the triangle is the earlier party
                 tied = true;
             }
         }
@@ -2880,10 +2911,9 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
         if (__ballot(alive && !ready && pend == (PEND)0) != 0ull) COOP_STAT(2, __ballot(alive && !ready && pend == (PEND)0));
         if (alive && !ready && pend == (PEND)0) {  // (pend != 0: a path between two deferred instances of one segment)
             h = traverse2<true, true, true, false, PEND, false, MIXED, false, false, TIE>(A, stk, stk_stride, o, d, rk.t_min, INFINITY, &pend);
-            if (TIE && tie_flagged(h.xf)) {  // two world-level objects share the best t: the reference-order walk answers for the whole ray
-                h = tie_resolve<1>(A, o, d, rk.t_min, INFINITY, h);
-                pend = (PEND)0;
-            }
+            // two world-level objects share the best t (TIE_FLAG in h.xf): the reference-order walk will answer for the whole ray, instances
+            // included -- right before the shading, the one call site of this kernel
+            if (TIE && tie_flagged(h.xf)) pend = (PEND)0;
             if (pend == (PEND)0) ready = true;
         }
         COOP_TIME(1);
@@ -2971,8 +3001,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
                 // pool exhausted (rare): walk the deferred instances in this lane, sparsely, as the plain kernel does
                 if (__ballot(need && id < 0) != 0ull) {
                     if (need && id < 0) {
-                        h = coop_walk_inline<TIE>(cargs, smem, stk, o, d, h, pend);
-                        if (TIE && tie_flagged(h.xf)) h = tie_resolve<1>(A, o, d, rk.t_min, INFINITY, h);
+                        h = coop_walk_inline<TIE>(cargs, smem, stk, o, d, h, pend);  // (TIE: a tie comes back as TIE_FLAG in h.xf)
                         pend = (PEND)0;
                         ready = true;
                     }
@@ -3034,7 +3063,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
                         alive = true;
                         ready = true;
                         freed = true;
-                        if (a_tied) h = tie_resolve<1>(A, o, d, rk.t_min, INFINITY, h);
+                        if (a_tied) h.xf ^= TIE_FLAG;  // settled right before the shading
                     }
                 }
                 COOP_STAT(7, __ballot(hit_inside));
@@ -3054,6 +3083,9 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel_coop(FlatView sv, CamK cam
         if (__ballot(alive && ready) != 0ull) COOP_STAT(3, __ballot(alive && ready));
         if (alive && ready) {
             bool done = true;
+            // an exact or near tie was noted on this segment (by the world-space walk, an object-space walk or the in-lane fallback): the
+            // reference's own walk decides ("EXACT ties" above traverse<>)
+            if (TIE && tie_flagged(h.xf)) h = tie_resolve_view(A.tie_view, o.x, o.y, o.z, d.x, d.y, d.z, rk.t_min, INFINITY);
             if (h.node >= 0 && depth > 0) {
                 depth -= 1;
                 Rec rec = materialize<true>(A, h, o, d, err);

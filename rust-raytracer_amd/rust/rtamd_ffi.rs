@@ -550,6 +550,11 @@ pub trait DescribeMaterial {
 }
 pub trait DescribeHitable {
     fn describe_hitable(&self, b: &mut SceneBuilder) -> Result<Id, RtError>;
+    /// The one material of a primitive (a sphere, a rectangle, a triangle), `None` for containers.  `Cube` keeps its six sides as
+    /// `Arc<dyn Hitable>` and no material of its own (cube.rs:9-13): its impl asks the first side through this accessor.
+    fn describe_own_material(&self, _b: &mut SceneBuilder) -> Result<Option<Id>, RtError> {
+        Ok(None)
+    }
 }
 
 // material.rs:48-84
@@ -610,6 +615,9 @@ impl DescribeHitable for Sphere {
         let m = b.material(self.material.as_ref())?;
         b.sphere(&self.center, self.radius, m)
     }
+    fn describe_own_material(&self, b: &mut SceneBuilder) -> Result<Option<Id>, RtError> {
+        Ok(Some(b.material(self.material.as_ref())?))
+    }
 }
 // objects/rectangle.rs:7-12, 44-49, 82-87
 impl DescribeHitable for XYRectangle {
@@ -617,11 +625,17 @@ impl DescribeHitable for XYRectangle {
         let m = b.material(self.material.as_ref())?;
         b.rect_xy(self.xy0, self.xy1, self.z, m)
     }
+    fn describe_own_material(&self, b: &mut SceneBuilder) -> Result<Option<Id>, RtError> {
+        Ok(Some(b.material(self.material.as_ref())?))
+    }
 }
 impl DescribeHitable for XZRectangle {
     fn describe_hitable(&self, b: &mut SceneBuilder) -> Result<Id, RtError> {
         let m = b.material(self.material.as_ref())?;
         b.rect_xz(self.xz0, self.xz1, self.y, m)
+    }
+    fn describe_own_material(&self, b: &mut SceneBuilder) -> Result<Option<Id>, RtError> {
+        Ok(Some(b.material(self.material.as_ref())?))
     }
 }
 impl DescribeHitable for YZRectangle {
@@ -629,15 +643,23 @@ impl DescribeHitable for YZRectangle {
         let m = b.material(self.material.as_ref())?;
         b.rect_yz(self.yz0, self.yz1, self.x, m)
     }
+    fn describe_own_material(&self, b: &mut SceneBuilder) -> Result<Option<Id>, RtError> {
+        Ok(Some(b.material(self.material.as_ref())?))
+    }
 }
-// objects/cube.rs:9-62: the six sides are rectangles sharing one material; describe them as the list they are
+// objects/cube.rs:9-70.  A Cube goes over as Cube::new's arguments -- rt_object_cube -- NOT as the list of its six sides: its
+// bounding_box is exactly (box_min, box_max) (cube.rs:67-69), while a list of six rectangles has the union of six boxes that are
+// padded by 1e-4 along their normals (rectangle.rs:36,74,111) -- and the reference's BVHNode culls by that box (bvh.rs:88: a ray that has
+// hit something at exactly the box's entry never visits the cube, aabb.rs:28-30), so the box is part of what is rendered.  The sides
+// share one material (Cube::new clones `mat` into each, cube.rs:17-54); the struct does not keep it, the first side does.
 impl DescribeHitable for Cube {
     fn describe_hitable(&self, b: &mut SceneBuilder) -> Result<Id, RtError> {
-        let mut ids = Vec::with_capacity(self.sides.len());
-        for s in self.sides.iter() {
-            ids.push(b.hitable(s.as_ref())?);
-        }
-        b.list(&ids) // Cube::hit is `self.sides.hit(...)` (cube.rs:64-66)
+        let m = match self.sides.first() {
+            Some(side) => side.describe_own_material(b)?,
+            None => None,
+        };
+        let m = m.ok_or_else(|| RtError { code: -1, message: "Cube without sides: no material to describe".to_string() })?;
+        b.cube(&self.box_min, &self.box_max, m) // Cube::hit = the scan over the six sides in Cube::new's order (cube.rs:64-66): cube_hit on the device
     }
 }
 // impl Hitable for Vec<Arc<dyn Hitable>>, objects/hit.rs:56-93
@@ -664,6 +686,9 @@ impl DescribeHitable for Triangle {
         let mesh = b.mesh_data(&self.positions, &self.normals)?;
         let m = b.material(self.material.as_ref())?;
         b.triangle(mesh, self.a, self.b, self.c, m)
+    }
+    fn describe_own_material(&self, b: &mut SceneBuilder) -> Result<Option<Id>, RtError> {
+        Ok(Some(b.material(self.material.as_ref())?))
     }
 }
 // objects/mesh.rs:144-146 (needs `pub(crate) bvh`)
@@ -732,13 +757,13 @@ pub struct RenderConfig {
     pub seed: u64,
     /// 0 = sample_ray with the Diffuse continuation (photon_mapper.rs:346-347); 1 = light/cosine mixture pdf
     pub integrator: i32,
-    /// GPUs of this node the frame is spread over (image tiles dealt round-robin, RCCL gather); 0 = every visible GPU.  The image does
-    /// not depend on it.
+    /// GPUs of this node the frame is spread over (image tiles dealt round-robin, RCCL gather); 0 = every visible GPU; default 1 (as the
+    /// C++ host's Config) until a run over two or more distinct devices is on record.  The image does not depend on it.
     pub gpus: usize,
 }
 impl RenderConfig {
     pub fn new(width: usize, height: usize) -> Self {
-        Self { width, height, sample_per_pixel: 256, max_depth: 50, t_min: 0.001, seed: 1, integrator: 0, gpus: 0 }
+        Self { width, height, sample_per_pixel: 256, max_depth: 50, t_min: 0.001, seed: 1, integrator: 0, gpus: 1 }
     }
     fn params(&self) -> rt_params {
         let mut p = rt_params::default();

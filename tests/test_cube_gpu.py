@@ -260,6 +260,14 @@ def test_instance_service_walks_follow_the_reference_on_exact_ties(variant):
     planes = [{0.0, 2.0, 4.0, -3.0, -1.0, 5.0, 6.0, 7.0, 8.0}, {0.0, 1.0, 1.5, 2.0, 2.5, 3.0, 3.5}, {0.0, 1.0, 2.0, -1.0, -2.0, -3.0, 5.0, 6.0}]
     ok = np.array([not any(r[3 + a] == 0.0 and r[a] in planes[a] for a in range(3)) for r in rays])
     outs = {k: world.debug_hit(rays, t_min=1e-3, kernel=k) for k in (1, 2, 5, 6)}
+    # A lattice ray can pass EXACTLY through an edge of a cube (two coordinates of the hit point on box planes): the reference's box test
+    # sees an interval that is one point and culls the cube (aabb.rs:28-30) although the side's own test accepts the hit -- the
+    # "grazes a reference box" caveat of the accel kernels (their padded boxes keep such a hit; measure zero for camera rays,
+    # not for this lattice).  Not what this test is about: such rays are left out.
+    for k in (1, 2):
+        on_plane = np.stack([np.isin(outs[k][:, 2 + a], list(planes[a])) for a in range(3)], axis=1).sum(axis=1)
+        ok &= ~((outs[k][:, 0] > 0) & (on_plane >= 2))
+    assert ok.sum() > len(rays) * 2 // 3
     ties = 0
     for i, r in enumerate(rays):
         if not ok[i]:
