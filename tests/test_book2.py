@@ -263,9 +263,10 @@ def test_final_scene_as_named_bit_exact(kernel):
 
 @pytest.mark.gpu
 def test_final_scene_as_named_full_size_windows_match_the_oracle():
-    """C5 as BASELINE words it at its own frame size (1600 x 1600, shutter [0, 1); 500 of its 4 000 spp, what the configuration table times):
-    five 8 x 8 windows spread over the frame equal the oracle's values bit for bit
-    (the in-kernel fold in sample order at this size, the time draws, the MEDIA + book-2 kernel variant with the tables in L2)."""
+    """C5 exactly as BASELINE words it: 1600 x 1600, 4 000 spp, shutter [0, 1) -- 10.24 G samples in ONE launch.  Five 8 x 8 windows spread over
+    the frame equal the oracle's values bit for bit (the in-kernel fold in sample order at this size and length, the time draws, the
+    MEDIA + book-2 kernel variant with the tables in L2); and the same frame rendered in eight instalments of 500 samples through the
+    resumable entry point with the state held by the host (rt_render_accumulate / rt_accum_finalize) is that frame, bit for bit."""
     import oracle
     import rtamd
     from rtamd import shapes
@@ -276,9 +277,15 @@ def test_final_scene_as_named_full_size_windows_match_the_oracle():
     o.Camera(*shapes.FINAL_SCENE_CAMERA)
     o.set_shutter(*shapes.FINAL_SCENE_SHUTTER)
     f, t, up, vfov, asp, ap, fd = shapes.FINAL_SCENE_CAMERA
-    img, st = w.render(rtamd.Camera((f, t), up, vfov, asp, ap, fd), width=1600, height=1600, spp=500, seed=1, shutter=shapes.FINAL_SCENE_SHUTTER)
-    assert st["samples"] == 1600 * 1600 * 500 and st["kernel_used"] == 2 and np.isfinite(img).all()
+    cam = rtamd.Camera((f, t), up, vfov, asp, ap, fd)
+    img, st = w.render(cam, width=1600, height=1600, spp=4000, seed=1, shutter=shapes.FINAL_SCENE_SHUTTER)
+    assert st["samples"] == 1600 * 1600 * 4000 and st["kernel_used"] == 2 and st["launches"] == 1 and np.isfinite(img).all()
     for (x0, y0) in [(560, 440), (1040, 1000), (800, 1400), (320, 160), (1200, 600)]:
-        exp, _ = o.render(1600, 1600, 500, seed=1, window=(x0, y0, x0 + 8, y0 + 8), n_jobs=8)
+        exp, _ = o.render(1600, 1600, 4000, seed=1, window=(x0, y0, x0 + 8, y0 + 8), n_jobs=16)
         assert np.array_equal(img[y0:y0 + 8, x0:x0 + 8], exp), "window at (%d, %d)" % (x0, y0)
-
+    p = rtamd.default_params(width=1600, height=1600, spp=4000, seed=1, time0=shapes.FINAL_SCENE_SHUTTER[0], time1=shapes.FINAL_SCENE_SHUTTER[1])
+    state = None
+    for k in range(8):
+        state, sk = w.render_accumulate(cam, p, 500 * k, 500 * (k + 1), state)
+        assert sk["samples"] == 1600 * 1600 * 500
+    assert np.array_equal(rtamd.accum_finalize(p, state), img)

@@ -1,6 +1,6 @@
 """Throughput of the BASELINE.json configurations C1..C4 on one GPU with the library's automatic kernel, each with the three objects
 of the bench line: `roofline` (VALU issue, per-sample counts carried over from the configuration's own PMC model under
-profiles/r04/model_<config>.json), `roofline_contract` (algorithmic bytes in the REFERENCE's traversal order, tests/golden/
+profiles/r05/model_<config>.json), `roofline_contract` (algorithmic bytes in the REFERENCE's traversal order, tests/golden/
 alg_bytes_<config>.json, against the HBM peak) and `roofline_hbm` (physical traffic).  Kernel time is measured in this run.
 usage: python tools/config_bench.py [scale]   (scale < 1 shrinks spp for a quick look) -> gpurun_out/config_bench.json"""
 import os, sys, json
@@ -15,14 +15,12 @@ rows = []
 for key in ("scene_10", "scene_500_c2", "scene_500", "cornell", "cornell_mix", "c4", "c5r", "c5"):
     label, W, H, spp_cfg, _ = configs.CONFIGS[key]
     spp = max(1, int(spp_cfg * scale))
-    if key in ("c5r", "c5"):
-        spp = max(1, spp // 8)  # 1600x1600x4000 = 10.2 G samples is the 8-GPU configuration: one GPU measures 500 spp of it
     world, cam = configs.product(key)
     integ = configs.INTEGRATOR.get(key, 0)
     world.render(cam, width=W, height=H, spp=min(spp, 4), seed=1, integrator=integ, shutter=configs.SHUTTER.get(key, (0.0, 0.0)))  # warm-up (workspace, code load)
     _, st = world.render(cam, width=W, height=H, spp=spp, seed=1, integrator=integ, shutter=configs.SHUTTER.get(key, (0.0, 0.0)))
     acc = {"kernel_ms": st["kernel_ms"], "launches": st["launches"], "samples": st["samples"]}
-    model = os.path.join(ROOT, "profiles", "pt_kernel_model.json") if key == "scene_500" else os.path.join(ROOT, "profiles", "r04", "model_%s.json" % key)
+    model = os.path.join(ROOT, "profiles", "pt_kernel_model.json") if key == "scene_500" else os.path.join(ROOT, "profiles", "r05", "model_%s.json" % key)
     roof, contract, hbm = bench.roofline_objects(acc, st["kernel_ms"] * 1e-3, model_path=model,
                                                  alg_path=os.path.join(ROOT, "tests", "golden", "alg_bytes_%s.json" % key))
     row = dict(config=label, key=key, width=W, height=H, spp=spp, integrator=integ, kernel=st["kernel_used"], lds=st["scene_in_lds"],

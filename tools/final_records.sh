@@ -15,7 +15,7 @@ if [ "$1" = collect ]; then
     [ -f gpurun_out/pmc_$c/model_$c.json ] && cp gpurun_out/pmc_$c/model_$c.json gpurun_out/pmc_$c/pmc_summary_$c.csv $R/
   done
   cp gpurun_out/final/*.json gpurun_out/final/*.csv gpurun_out/final/*.txt $R/ 2>/dev/null
-  [ -d gpurun_out/r04_phase ] && for f in gpurun_out/r04_phase/*.txt; do cp $f $R/phase_$(basename $f); done
+  [ -d gpurun_out/r05_phase ] && for f in gpurun_out/r05_phase/*.txt; do cp $f $R/phase_$(basename $f); done
   ls $R | wc -l
   exit 0
 fi
@@ -24,7 +24,7 @@ if [ "$STAGE" = all ] || [ "$STAGE" = pmc ]; then
 rm -rf $OUT; mkdir -p $OUT
 echo "== headline PMC (the bench workload itself, 1000 spp)"; tools/pmc_passes.sh headline 2>&1 | tail -1 || exit 1
 mkdir -p profiles; cp gpurun_out/pmc_headline/model_headline.json profiles/pt_kernel_model.json   # (so that the bench lines below carry this build's model)
-echo "== config PMC"; for c in scene_10 scene_500_c2 cornell cornell_mix c4 c5r c5; do tools/pmc_passes.sh $c 2>&1 | tail -1 || exit 1; mkdir -p profiles/r04; cp gpurun_out/pmc_$c/model_$c.json profiles/r04/model_$c.json; done
+echo "== config PMC"; for c in scene_10 scene_500_c2 cornell cornell_mix c4 c5r c5; do tools/pmc_passes.sh $c 2>&1 | tail -1 || exit 1; mkdir -p profiles/r05; cp gpurun_out/pmc_$c/model_$c.json profiles/r05/model_$c.json; done
 fi
 [ "$STAGE" = pmc ] && exit 0
 mkdir -p $OUT

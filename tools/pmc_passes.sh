@@ -8,7 +8,7 @@ set -o pipefail
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 NAME=$1
-declare -A SPP=( [headline]=1000 [scene_10]=100 [scene_500_c2]=500 [cornell]=2000 [cornell_mix]=2000 [c4]=1000 [c5r]=500 [c5]=500 )
+declare -A SPP=( [headline]=1000 [scene_10]=100 [scene_500_c2]=500 [cornell]=2000 [cornell_mix]=2000 [c4]=1000 [c5r]=4000 [c5]=4000 )
 declare -A PIX=( [headline]=$((1200*1200)) [scene_10]=$((400*225)) [scene_500_c2]=$((1200*800)) [cornell]=$((800*800)) [cornell_mix]=$((800*800)) [c4]=$((1200*1200)) [c5r]=$((1600*1600)) [c5]=$((1600*1600)) )
 S=${2:-${SPP[$NAME]}}
 OUT=gpurun_out/pmc_$NAME; rm -rf $OUT; mkdir -p $OUT
@@ -21,6 +21,6 @@ for SET in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCL
   timeout -k 10 400 rocprofv3 --pmc $SET -d $OUT/pmc_$C --output-format csv -- $CMD > $OUT/pmc_$C.json 2>>$OUT/err.log || { tail -5 $OUT/err.log; exit 1; }
 done
 python3 tools/pmc_summary.py $OUT/pmc_* > $OUT/pmc_summary_$NAME.csv
-python3 tools/make_pt_model.py --samples $N --source "profiles/r04/pmc_summary_$NAME.csv (rocprofv3 --pmc, separate passes: $CMD)" --out $OUT/model_$NAME.json $OUT/pmc_* \
+python3 tools/make_pt_model.py --samples $N --source "profiles/r05/pmc_summary_$NAME.csv (rocprofv3 --pmc, separate passes: $CMD)" --out $OUT/model_$NAME.json $OUT/pmc_* \
   | grep -E "valu_insts_per_sample|lane_util|valu_busy_measured|kernel_ms|hbm_bytes_per|share_sq_wait_any" | tr '\n' ' '
 echo " <- $NAME"
