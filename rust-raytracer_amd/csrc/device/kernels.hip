@@ -830,23 +830,48 @@ DEV double track_bound(const MediaTrack& K, double best) {
 // for the NK_INSTANCE_INLINE items of scenes that have any: compiling the enter path into their world-space walk costs C4 6 %).
 // RESOLVE: an exact tie (TIE_FLAG) is settled before returning; false: the caller does it (traverse2_media: one call site for its two walks).
 // TIEDEF: a DEFER walk (kernels 5 / 6) notes exact ties among the world-level items as well; its caller settles them (RESOLVE is false there).
+// SLICE (round 5; the MEDIA variants of kernel 2): the walk can be SUSPENDED.  A wave stays in this loop until its longest ray is through:
+// on the book-2 final scene 7.9 descend-and-leaf rounds per walk where a lane needs 1.8 (phase statistics) -- a few rays cross
+// the 1000-sphere cluster or skim the ground boxes while the rest of the wave waits.  With SLICE the lanes that are still walking leave the
+// loop together as soon as fewer than `slice_th` of them are left (a wave-uniform test once per round); what a walk needs to go on -- the
+// node to continue at, the stack pointer (the stack itself stays in the lane's LDS column), the instance it is inside of; the best hit so
+// far goes back to the caller as the result -- is handed back in *ws, the finished lanes shade and start their next segment, and the
+// next call continues the suspended walks beside the fresh ones.  The walk itself is unchanged: same nodes, same order, same candidates,
+// hence the same hit.  (On the LDS-resident scenes the rounds' tail is short -- 3.5 rounds against 1.5 on the headline scene -- and the
+// slicing only costs registers: measured -1.4 % there, -21 % on the Cornell box; the switch RT_SLICE_TH compiles it into the MEDIA variants
+// alone, and it is OFF in the product: no gain there either, see RT_SLICE_TH.)
+struct WalkState {
+    uint32_t cur;  // node / leaf to continue at; REF_DONE: no walk in progress
+    uint32_t sp;   // stack offset in words (WIDE: the LDS byte address)
+    int cur_xf;    // the instance the walk is inside of (xform index), -1: world space
+};
 template <int GENERAL, bool DEFER = false, bool TOP = true, bool WIDE = false, class PEND = uint32_t, bool LIMIT = false, bool ENTER = !DEFER, bool TRACK = false, bool RESOLVE = true,
-          bool TIEDEF = false>
+          bool TIEDEF = false, bool SLICE = false>
 DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, double t_min, double t_max, PEND* pend = nullptr, uint32_t order_limit = 0xFFFFFFFFu,
-                  MediaTrack* track = nullptr) {
+                  MediaTrack* track = nullptr, WalkState* ws = nullptr, const Hit* h_in = nullptr, int slice_th = 0) {
     D3 o = wo, d = wd;
-    double a = sqlen(d);
     Hit h;
     h.t = t_max;
     h.node = -1;
     h.xf = -1;
     h.kp = 0;
     int cur_xf = -1;
+    const bool resume = SLICE && ws->cur != REF_DONE;
+    if (resume) {  // a suspended walk goes on: its best hit so far, and the ray in the space of the instance it is inside of
+        h = *h_in;
+        cur_xf = ws->cur_xf;
+        if (GENERAL && cur_xf >= 0) {
+            const double* Minv = A.xforms + 32 * cur_xf;
+            o = xf_point(Minv, wo);
+            d = xf_dir(Minv, wd);
+        }
+    }
+    double a = sqlen(d);
     // exact ties are noted here unless the walk sees only a part of the scene (LIMIT: only t is used); a walk that defers instances
     // (kernels 5 / 6) notes them in its TIE variants (TIEDEF)
     constexpr bool TIE = TIE_RULE && GENERAL != 0 && (!DEFER || TIEDEF) && !LIMIT && !(TRACK && RT_TIE_NOTRACK);
-    Ray32 r = make_ray32(o, d, t_min, t_max);
-    float best_all32 = r.best;  // TRACK: the best hit's own (outward-rounded) t, beside r.best = the track bound
+    Ray32 r = make_ray32(o, d, t_min, (SLICE && TRACK) ? track_bound(*track, h.t) : (SLICE ? h.t : t_max));
+    float best_all32 = SLICE ? ray32_best(h.t) : r.best;  // TRACK: the best hit's own (outward-rounded) t, beside r.best = the track bound
     if (WIDE) ray32_wide_addr(r, A.n2w_lds);
     int sp = 0;  // stack offset in words (a multiple of stride): avoids an integer multiply per push/pop
     // WIDE: the stack pointer is the LDS byte address itself (one add per push / pop instead of shift-add + add)
@@ -854,7 +879,17 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
     const uint32_t spw_step = 4u * (uint32_t)stride;
     uint32_t spw = spw0;
     uint32_t cur = WIDE ? wide_ref(A.root2) : A.root2;
+    if (resume) {
+        cur = ws->cur;
+        if (WIDE) spw = ws->sp;
+        else sp = (int)ws->sp;
+    }
+    bool suspended = false;
     for (;;) {
+        if (SLICE && (int)__popcll(__ballot(1)) < slice_th) {  // (the lanes whose walks are over have left the loop: the ballot counts the walkers)
+            suspended = true;
+            break;
+        }
         while ((cur >> REF_TAG_SHIFT) == 0u) {  // inner node: test both children
             PH_EV(10);
             if (WIDE) {
@@ -1046,6 +1081,12 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
         }
         PH_END(9, ph_leaf0);
     }
+    if (SLICE) {
+        ws->cur = suspended ? cur : REF_DONE;
+        ws->sp = WIDE ? spw : (uint32_t)sp;
+        ws->cur_xf = cur_xf;
+        if (suspended) return h;  // (its flag, if any, travels in h.xf)
+    }
     // the last exact tie noted, if its later party is still the hit: would the reference have visited that object at all?
     if (TIE && RESOLVE && tie_flagged(h.xf)) h = tie_resolve<GENERAL>(A, wo, wd, t_min, t_max, h);
     return h;
@@ -1112,8 +1153,12 @@ DEV bool medium_boundary(const Acc& A, const MediumDev& M, D3 o, D3 d, double& t
     t_b = r2h.t;
     return true;
 }
-template <int GENERAL, bool TOP, bool WIDE>
-DEV Hit traverse2_media(const Acc& A, uint32_t n_media, uint32_t* stk, const int stride, D3 o, D3 d, double t_min, Rng& rng) {
+// SLICE: the accel walk of step 2 may come back SUSPENDED (traverse2's SLICE: ws->cur != REF_DONE; the result is then its best hit so far and
+// t_save[] the two tracked minima): the caller skips the shading and calls again next iteration; step 1 is then repeated (it draws no random
+// number and its results depend on the ray alone), the walk resumes, and steps 3 run once, when the walk is over.
+template <int GENERAL, bool TOP, bool WIDE, bool SLICE = false>
+DEV Hit traverse2_media(const Acc& A, uint32_t n_media, uint32_t* stk, const int stride, D3 o, D3 d, double t_min, Rng& rng, WalkState* ws = nullptr, const Hit* h_in = nullptr,
+                        double* t_save = nullptr, int slice_th = 0) {
     // 1. the boundary queries of the media (no random number is drawn here); the first two media the ray crosses are TRACKED by the
     //    accel walk (MediaTrack), so that one walk yields the closest surface S and, for each of the two, the closest surface the
     //    reference visits before it.  (A second, order-restricted walk per medium -- the first version -- cost more than the
@@ -1139,8 +1184,18 @@ DEV Hit traverse2_media(const Acc& A, uint32_t n_media, uint32_t* stk, const int
         }
     }
     // 2. the accel walk
-    Hit S = (tk0 != 0xFFFFFFFFu) ? traverse2<GENERAL, false, TOP, WIDE, uint32_t, false, true, true, false>(A, stk, stride, o, d, t_min, INFINITY, nullptr, 0xFFFFFFFFu, &K)
-                                 : traverse2<GENERAL, false, TOP, WIDE, uint32_t, false, true, false, false>(A, stk, stride, o, d, t_min, INFINITY);
+    if (SLICE && ws->cur != REF_DONE) {  // a suspended walk goes on: what it had tracked so far
+        K.T[0] = t_save[0];
+        K.T[1] = t_save[1];
+    }
+    Hit S = (tk0 != 0xFFFFFFFFu)
+                ? traverse2<GENERAL, false, TOP, WIDE, uint32_t, false, true, true, false, false, SLICE>(A, stk, stride, o, d, t_min, INFINITY, nullptr, 0xFFFFFFFFu, &K, ws, h_in, slice_th)
+                : traverse2<GENERAL, false, TOP, WIDE, uint32_t, false, true, false, false, false, SLICE>(A, stk, stride, o, d, t_min, INFINITY, nullptr, 0xFFFFFFFFu, nullptr, ws, h_in, slice_th);
+    if (SLICE && ws->cur != REF_DONE) {  // suspended: the rest happens when the walk is over
+        t_save[0] = K.T[0];
+        t_save[1] = K.T[1];
+        return S;
+    }
     if (TIE_RULE && GENERAL && tie_flagged(S.xf)) S = tie_resolve<GENERAL>(A, o, d, t_min, INFINITY, S);  // two surfaces share the best t ("EXACT ties" above)
     // 3. the media in the reference's order
     Hit best = S;
@@ -1888,6 +1943,14 @@ __device__ __attribute__((noinline)) UnitInfo next_unit(uint32_t* wst_, uint32_t
 }
 
 // GENERAL: 0 = spheres under BVH nodes only, 1 = every primitive of the reference, 2 = 1 + the book-2 extensions (D9: moving spheres, noise textures, an open shutter)
+// A/B switch, OFF in the product (measured and rejected in round 5): with -DRT_SLICE_TH=N the MEDIA variants of kernel 2 suspend
+// their accel walks (traverse2's SLICE) once fewer than N lanes of the wave are still walking -- at most half of those that entered the walk,
+// so that a wave with few paths left (the end of a launch) still moves.  Reduced book-2 scene, N = 24: 34 instead of 55 node steps and 3.6 instead
+// of 7.9 leaf sections per iteration, 20 % more iterations, shading at 41 instead of 50 lanes, 25 more spilled registers: 836 against 849
+// Msamples/s (N = 12: 859; C5 as named 608 / 625 against 686) -- profiles/r05/phase_c5r_sliced_th24.txt.
+#ifndef RT_SLICE_TH
+#define RT_SLICE_TH 0
+#endif
 template <bool LDS, int GENERAL, int ACCEL, int INTEG, bool MEDIA = false, bool POOL = false>
 __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, RenderK rk, double* __restrict__ ring, double* accum,
                                                       unsigned int* tickets, unsigned int* __restrict__ counter, int* __restrict__ err) {
@@ -1995,6 +2058,14 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
     const unsigned long long tail_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
     int fold_wait = 0;  // iterations until the head of the ring is looked at again (wave-uniform)
+    constexpr bool SLICE = ACCEL == 2 && MEDIA && RT_SLICE_TH > 0;
+    WalkState ws;  // SLICE: this lane's suspended walk (cur == REF_DONE: none), its best hit so far and the two tracked minima
+    ws.cur = REF_DONE;
+    ws.sp = 0u;
+    ws.cur_xf = -1;
+    Hit hs;
+    hs.t = INFINITY; hs.node = -1; hs.xf = -1; hs.kp = 0;
+    double ws_t[2] = {INFINITY, INFINITY};
 #ifdef RTAMD_PHASE_STATS
     if (threadIdx.x < 48) s_ph[threadIdx.x] = 0ull;
     __syncthreads();
@@ -2082,10 +2153,18 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
             if (alive) {
                 PH_EV(13);
                 PH_BEGIN(ph_t0);
-                Hit h = (ACCEL == 2) ? (MEDIA ? traverse2_media<GENERAL, !LDS, LDS>(A, sv.n_media, stk, stk_stride, o, d, rk.t_min, rng)
+                Hit h;
+                if (SLICE) {  // the walk goes on until fewer than slice_th lanes are left in it; those come back next iteration (ws.cur != REF_DONE)
+                    const int n_walk = (int)__popcll(__ballot(1));
+                    h = traverse2_media<GENERAL, !LDS, LDS, true>(A, sv.n_media, stk, stk_stride, o, d, rk.t_min, rng, &ws, &hs, ws_t, min((int)RT_SLICE_TH, n_walk >> 1));
+                    hs = h;
+                } else {
+                    h = (ACCEL == 2) ? (MEDIA ? traverse2_media<GENERAL, !LDS, LDS>(A, sv.n_media, stk, stk_stride, o, d, rk.t_min, rng)
                                                : traverse2<GENERAL, false, !LDS, LDS>(A, stk, stk_stride, o, d, rk.t_min, INFINITY))
                                      : traverse<GENERAL, MEDIA>(A, o, d, rk.t_min, INFINITY, &rng);
+                }
                 PH_END(1, ph_t0);
+              if (!SLICE || ws.cur == REF_DONE) {
                 PH_BEGIN(ph_p0);
                 bool done = true;
                 if (h.node >= 0 && depth > 0) {  // Q12: depth test after the hit, before emission
@@ -2128,6 +2207,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_kernel(FlatView sv, CamK cam, Ren
                     alive = false;
                 }
                 PH_END(8, ph_p0);
+              }
             }
         }
     }
