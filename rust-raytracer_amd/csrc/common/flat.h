@@ -175,7 +175,8 @@ struct NodeQ {
 };
 struct Tri32 {
     float pa[3], pb[3], pc[3];
-    uint32_t order, kp, pad;
+    uint32_t order, kp;
+    float me;  // >= max |component| of the edges pb - pa, pc - pa (rounded up): scales the error bounds of the f32 pre-test (tri_miss32, kernels.hip)
 };
 struct QGrid {
     double mn[3], k[3], shift, pad;

@@ -297,10 +297,30 @@ DEV bool aabb_hit(const double2* b, D3 o, D3 inv, double t_min, double t_max) {
     return !(mx <= mn);
 }
 // Sphere::hit's root selection, sphere.rs:24-43 ; a = |dir|^2 hoisted per ray
+// RT_SPHERE_F32_REJECT (A/B switch, off; round 5's experiment for the headline scene): the sign of the discriminant decided in f32 where it is
+// certain.  oc comes from the f64 subtraction the reference makes anyway; with oc32, d32 = its and the direction's f32 roundings (relative
+// error e = 2^-24 per component), M = max |oc_i|, D = max |d_i|, r32 the radius rounded:  hb32 is within 9 e M D of half_b, c32 within 9 e M^2
+// + 3 e r^2 of c, a32 within 9 e D^2 of a, hence disc32 = hb32^2 - a32 c32 within 64 e D^2 (M + r)^2 of disc; the test uses 2^-17 D^2 (M + r)^2.
+// Bit-exact (parity tests green with it) and SLOWER: headline 2 704 against 2 812 Msamples/s, C2 2 803 / 2 911, Cornell 2 441 / 2 490 (two runs
+// each): a miss saves the 15 f64 operations between oc and the discriminant (60 issue cycles) and pays 7 conversions + 19 f32 operations for them,
+// a hit pays them on top.
+#ifndef RT_SPHERE_F32_REJECT
+#define RT_SPHERE_F32_REJECT 0
+#endif
 DEV bool sphere_hit(const double2* s, D3 o, D3 d, double a, double t_min, double t_max, double& t_out) {
     double2 c0 = s[0], c1 = s[1];
     D3 oc = mk(o.x - c0.x, o.y - c0.y, o.z - c1.x);
     double radius = c1.y;
+    if (RT_SPHERE_F32_REJECT) {
+        const float x = (float)oc.x, y = (float)oc.y, z = (float)oc.z, dx = (float)d.x, dy = (float)d.y, dz = (float)d.z, r32 = (float)radius;
+        const float hb = __builtin_fmaf(z, dz, __builtin_fmaf(y, dy, x * dx));
+        const float a32 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+        const float c32 = __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x)) - r32 * r32;
+        const float disc32 = __builtin_fmaf(hb, hb, -(a32 * c32));
+        const float m = fmaxf(fmaxf(fabsf(x), fabsf(y)), fabsf(z)) + fabsf(r32), dm = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz));
+        const float bound = 7.62939453125e-06f * (dm * m) * (dm * m);  // 2^-17 D^2 (M + r)^2
+        if (disc32 < -bound) return false;  // disc < 0 for certain (NaN / inf: the comparison fails, the f64 test decides)
+    }
     double half_b = dot(oc, d);
     double c = sqlen(oc) - radius * radius;
     double disc = half_b * half_b - a * c;
@@ -2493,6 +2513,56 @@ struct ServeCtx {
 // `act`: descend to a leaf, test its triangles.  NodeQ boxes are grid integers and `r` is the ray in grid coordinates; triangles
 // come as f32 vertices with order and kind|payload in the record; (o, d) is the object-space ray.  cur == REF_DONE afterwards
 // means the walk is complete.
+// Conservative f32 pre-test in front of the f64 Triangle::hit of the compact records (round 5).  true ONLY IF tri_hit_v below certainly returns
+// false -- through one of its barycentric rejects -- so a skipped triangle changes nothing.  Moeller-Trumbore (mesh.rs:57-102) divides three
+// numerators by one determinant:  b1 = N1 / dd,  b2 = N2 / dd  with  dd = (dir x e1) . e0,  N1 = (o - pa) . (dir x e1),  N2 = dir . ((o - pa) x e0),
+// and rejects b1 < 0, b1 > 1, b2 < 0, b1 + b2 > 1.  The f32 evaluation here differs from the f64 values the reference computes by at most
+//   |dd32 - dd| <= 80 e Mr Me^2,      |N1,2_32 - N1,2| <= 70 e (Mo + Dm) Mr Me,      e = 2^-24,
+// with Mo = max |o_i|, Mr = max |dir_i|, Me = max |edge component| (Tri32::me, from the host), Dm = max |(o32 - pa)_i|:
+//   inputs: o32, dir32 are off by e Mo, e Mr; the vertices are f32 values (exact); v = o32 - pa is off by e (Mo + Dm), an edge by e Me;
+//   a cross-product component (two products, one sum; factors bounded by the M's) adds 3 e of its 2 M M' magnitude to the 2 (dM M' + M dM')
+//   it inherits: s0 = dir x e1 within 10 e Mr Me, s1 = v x e0 within 10 e (Mo + Dm) Me;  a dot product of three terms adds 5 e of its 3 x
+//   magnitude to the 3 (da |b| + |a| db) it inherits: the bounds above; the f64 roundings of the reference's own values are 2^-29 of these.
+// Both bounds are taken with the factor 256 e = 2^-16 (more than three times what the analysis needs: it also covers the roundings of the bounds
+// themselves and of the final comparisons, each below 6 e of the same magnitudes) and floored at 1e-30 (products of f32 denormals).  Decisions:
+//   |dd32| <= Ed: the sign of dd is not known -> no verdict;      otherwise sign(dd) is that of dd32, and
+//   |N1_32| > E and its sign differs from dd32's  =>  N1 / dd < 0: the reference's b1 = fl(N1 fl(1 / dd)) is negative      (reject b1 < 0)
+//   |N2_32| > E and its sign differs               =>  b2 < 0;  it is reached only if b1 passed, and rejects                (reject b2 < 0)
+//   |N1_32| - E > |dd32| + Ed  =>  |b1| > 1 by a relative margin above 2^-22 (the slack of the bounds): b1 > 1 or b1 < 0       (either rejects)
+//   |N1_32 + N2_32| - 2 E > |dd32| + Ed  =>  |b1 + b2| > 1 likewise:  b1 + b2 > 1, or b1 + b2 < -1 and then b1 < 0 or b2 < 0 (all reject).
+// NaN or infinite inputs fail every `>` (no verdict).  Magnitudes stay far inside f32's range: coordinates are below 2^36 (flatten.cpp).
+DEV bool tri_miss32(float ox, float oy, float oz, float dx, float dy, float dz, float mo, float mrk, float pax, float pay, float paz, float pbx, float pby,
+                    float pbz, float pcx, float pcy, float pcz, float me) {
+    const float vx = ox - pax, vy = oy - pay, vz = oz - paz;
+    const float e0x = pbx - pax, e0y = pby - pay, e0z = pbz - paz;
+    const float e1x = pcx - pax, e1y = pcy - pay, e1z = pcz - paz;
+    const float s0x = __builtin_fmaf(dy, e1z, -(dz * e1y)), s0y = __builtin_fmaf(dz, e1x, -(dx * e1z)), s0z = __builtin_fmaf(dx, e1y, -(dy * e1x));
+    const float dd = __builtin_fmaf(s0z, e0z, __builtin_fmaf(s0y, e0y, s0x * e0x));
+    const float n1 = __builtin_fmaf(vz, s0z, __builtin_fmaf(vy, s0y, vx * s0x));
+    const float s1x = __builtin_fmaf(vy, e0z, -(vz * e0y)), s1y = __builtin_fmaf(vz, e0x, -(vx * e0z)), s1z = __builtin_fmaf(vx, e0y, -(vy * e0x));
+    const float n2 = __builtin_fmaf(dz, s1z, __builtin_fmaf(dy, s1y, dx * s1x));
+    const float dm = fmaxf(fmaxf(fabsf(vx), fabsf(vy)), fabsf(vz));
+    const float mm = mrk * me;                          // 2^-16 Mr Me
+    const float en = fmaxf((mo + dm) * mm, 1e-30f);     // >= |N1_32 - N1|, |N2_32 - N2|
+    const float ed = fmaxf(mm * me, 1e-30f);            // >= |dd32 - dd|
+    const float add = fabsf(dd), an1 = fabsf(n1), an2 = fabsf(n2);
+    if (!(add > ed)) return false;
+    const bool dneg = dd < 0.f;
+    const bool out1 = an1 > en && ((n1 < 0.f) != dneg);
+    const bool out2 = an2 > en && ((n2 < 0.f) != dneg);
+    const float lim = add + ed;
+    const bool big1 = an1 - en > lim;
+    const bool big12 = fabsf(n1 + n2) - (en + en) > lim;
+    return out1 || out2 || big1 || big12;
+}
+// MEASURED AND REJECTED (round 5, profiles/r05/c4_audit.md): with the pre-test C4 runs at 614 Msamples/s, without it at 847.  The f64 test is
+// staged -- 30 VALU (nine of them the vertex conversions) up to its first reject, 22, 18 and 9 for the later stages -- and most candidates
+// of a leaf leave at the first stage, so there are ~120 issue cycles to save per rejected triangle; the pre-test costs 50 VALU in five
+// basic blocks (~150 cycles) for EVERY candidate.  Kept as an A/B switch, off.
+#ifndef RT_TRI_F32_REJECT
+#define RT_TRI_F32_REJECT 0
+#endif
+
 template <bool TIE>
 DEV void blas_pass_q(const ServeCtx& X, bool act, AS_L uint32_t* stk, const int stride, D3 o, D3 d, double t_min, Ray32& r, double& ht, int& hnode,
                      uint32_t& hkp, uint32_t& cur, int& sp, bool& tied) {
@@ -2536,9 +2606,17 @@ DEV void blas_pass_q(const ServeCtx& X, bool act, AS_L uint32_t* stk, const int 
     }
     if (act && (cur >> REF_TAG_SHIFT) == 1u) {  // leaf: Triangle::hit in f64 (mesh.rs:57-102), tie rule as in traverse2
         const uint32_t first = cur & REF_LEAF_FIRST_MASK, cnt = ((cur >> REF_LEAF_COUNT_SHIFT) & 7u) + 1u;
+        // the ray in f32 and its magnitudes, for tri_miss32 (per leaf: the lane's registers are worth more than the six conversions)
+        const float ox32 = (float)o.x, oy32 = (float)o.y, oz32 = (float)o.z, dx32 = (float)d.x, dy32 = (float)d.y, dz32 = (float)d.z;
+        const float mo32 = fmaxf(fmaxf(fabsf(ox32), fabsf(oy32)), fabsf(oz32));
+        const float mrk32 = fmaxf(fmaxf(fabsf(dx32), fabsf(dy32)), fabsf(dz32)) * 1.52587890625e-05f;  // 2^-16 Mr
         for (uint32_t i = 0; i < cnt; i++) {
             const AS_G u32x4* p = X.tri32 + 3 * (size_t)(first + i);
             const u32x4 a = p[0], b = p[1], c = p[2];
+            if (RT_TRI_F32_REJECT &&
+                tri_miss32(ox32, oy32, oz32, dx32, dy32, dz32, mo32, mrk32, __uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w),
+                           __uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), __uint_as_float(b.w), __uint_as_float(c.x), __uint_as_float(c.w)))
+                continue;  // Triangle::hit certainly returns None
             const D3 pa = mk((double)__uint_as_float(a.x), (double)__uint_as_float(a.y), (double)__uint_as_float(a.z));
             const D3 pb = mk((double)__uint_as_float(a.w), (double)__uint_as_float(b.x), (double)__uint_as_float(b.y));
             const D3 pc = mk((double)__uint_as_float(b.z), (double)__uint_as_float(b.w), (double)__uint_as_float(c.x));

@@ -633,6 +633,13 @@ void flatten(rt_scene& s) {
                             }
                             tr.order = ab.items[2 * j + 1];
                             tr.kp = kp;
+                            {   // the largest edge component, rounded up to f32 (tri_miss32's error scale)
+                                double me = 0.;
+                                for (int a = 0; a < 3; a++) me = std::fmax(me, std::fmax(std::fabs(pre[3 + a]), std::fabs(pre[6 + a])));
+                                float mf = (float)me;
+                                if ((double)mf < me) mf = std::nextafterf(mf, INFINITY);
+                                tr.me = mf;
+                            }
                             tri32[j] = tr;
                         }
                     }
