@@ -181,7 +181,7 @@ def roofline_objects(stats_acc, dt_kernel_s, clock_note=None, model_path=None, a
     hbm = None
     if model:
         ipc = model["valu_insts_per_sample"]            # VALU wave-instructions per sample (SQ_INSTS_VALU / samples)
-        cyc = model["valu_issue_cycles_per_inst"]       # minimum SIMD cycles per wave64 instruction of the kernel's own mix (f32 2, f64 4, transcendental 8 / 16, ...: tools/make_pt_model.py)
+        cyc = model["valu_issue_cycles_per_inst"]       # minimum SIMD cycles per wave64 instruction of the kernel's own mix (measured class costs: tools/make_pt_model.py)
         clk = MAX_CLOCK_GHZ                             # (the PMC pass itself held model["clock_ghz"], 2.37: profiled passes clock lower)
         achieved = sps * ipc / 1e9
         peak = N_SIMDS * clk / cyc
@@ -190,14 +190,15 @@ def roofline_objects(stats_acc, dt_kernel_s, clock_note=None, model_path=None, a
                      # the counter that does not depend on any cycle table: 4 * SQ_ACTIVE_INST_VALU / SIMD cycles of the PMC pass
                      "valu_busy_measured": model.get("valu_busy_measured"),
                      "cost_table": {"cycles_per_wave64_instruction": model.get("valu_class_cycles"),
-                                    "measured_classes": "ns per wave-instruction per SIMD converted with f64 fma = 4 cycles: f32 add/mul/fma 2.5, f64 add/mul/fma/ldexp/div_fixup 4.0, "
-                                                        "conversions 3.8 (SDWA halves 3.5), v_mul_lo_u32 3.9, integer add/xor/and/or/shift/alignbit/lshl_add/bfe 3.2-3.3, "
-                                                        "compare 3.5, v_cndmask 3.6 (3.25 paired with a compare), f32 min/max 3.7, min3/max3 3.6, v_mov 2.2, "
-                                                        "v_readlane / v_writelane 3.5, 64-bit add 2 x 3.7, f32 rcp/rsq/sqrt 7.0, f64 rcp/rsq/sqrt 13.7 "
-                                                        "(tools/microbench/valu_cost.hip, profiles/r04/valu_cost_microbench.txt; 1024 threads per CU, independent streams)",
-                                    "other_class": "the model's 'other' (SQ_INSTS_VALU minus the typed counters: moves, compares, selects, integer and address "
-                                                   "arithmetic, min/max, lane moves) is priced at 3.5 cycles; every member is measured since round 4 and lies "
-                                                   "between 2.2 (v_mov) and 3.7; at an average of 3.3 the headline's frac would read 0.86 instead of 0.89"},
+                                    "anchor": model.get("valu_cost_anchor", "rounds 3-4: ratios anchored at f64 fma = 4 cycles"),
+                                    "measured_classes": "GRBM cycles per wave-instruction per SIMD at 4 waves per SIMD, 2.38 GHz held: f32 add/mul/fma 2.56, f64 add/mul/fma/ldexp/div_fixup 4.25, "
+                                                        "conversions 4.25, v_mul_lo_u32 4.26, integer add/xor/and/or/shift/alignbit/lshl_add/bfe 3.65, compare + select pair 3.67 each, "
+                                                        "lone v_cmp / v_cndmask_e64 / f32 min/max / min3/max3 / v_readlane / v_writelane 4.25, v_mov 2.55, 64-bit add 2 x 4.29, "
+                                                        "f32 rcp/rsq/sqrt 8.28, f64 rcp/rsq/sqrt 16.3; one wave per SIMD: 5.1 for all but the transcendentals "
+                                                        "(tools/microbench/valu_cost.hip, profiles/r05/valu_cost_microbench.txt)",
+                                    "other_class": "the model's 'other' (SQ_INSTS_VALU minus the typed counters: compares, selects, min/max, logic, moves, lane moves) is "
+                                                   "priced at 3.65 cycles, its cheapest members besides v_mov (2.55); compares / selects / min-max cost 4.25: the class's true "
+                                                   "cost is higher, the peak lower and frac higher than stated"},
                      "useful_frac": frac * model["lane_utilisation"] if frac else None,
                      "valu_insts_per_sample": ipc, "valu_issue_cycles_per_inst": cyc, "clock_ghz": clk, "clock_ghz_in_pmc_pass": model["clock_ghz"],
                      "valu_mix_per_sample": model.get("valu_mix_per_sample"),

@@ -7,15 +7,20 @@ pt_kernel dispatches of ONE pass (every pass runs the same command).
 Formulas:
   valu_insts_per_sample      = SQ_INSTS_VALU / N
   valu_issue_cycles_per_inst = sum_class(count_class * cycles_class) / SQ_INSTS_VALU, the SIMD cycles the kernel's own instruction
-                               mix needs per wave64 instruction.  Round 3: the class costs are MEASURED on the MI355X
-                               (tools/microbench/valu_cost.hip, profiles/r03/valu_cost_microbench.txt: streams of independent
-                               instructions at this kernel's occupancy, 4 waves per SIMD; f64 fma anchored at 4 cycles = the 78.6
-                               TFLOP/s f64 vector peak): f32 add/mul/fma 2.5, f64 add/mul/fma/ldexp/div_fixup 4, conversions 4,
-                               f32 transcendental 7, f64 rcp/rsq/sqrt 14, 64-bit integer 6.6 (two 32-bit halves), everything else 3.5
-                               (measured: integer add/xor/shift/alignbit 3.3, compare + select 3.3, f32 min/max 3.9, v_mul_lo_u32 4.0).
-                               Rounds 1-2 priced f32 and "other" at 2 cycles (the 157 TFLOP/s f32 figure needs packed
-                               instructions): that put the peak 1.4x too high.  Classes from SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F{32,64},
-                               _INT64, _CVT; "other" = SQ_INSTS_VALU minus their sum.
+                               mix needs per wave64 instruction.  Round 5: the class costs are MEASURED IN CYCLES on the MI355X
+                               (tools/microbench/valu_cost.hip + valu_cost_cycles.py, profiles/r05/valu_cost_microbench.txt: dispatches
+                               of >= 20 ms of independent instructions at this kernel's occupancy, 4 waves per SIMD; cycles =
+                               GRBM_GUI_ACTIVE / 8 of the dispatch, which held 2.38 GHz -- s_memtime against s_memrealtime gives the
+                               same clock): f32 add/mul/fma 2.56 (the one stream under which the clock drops, to 2.0-2.1 GHz),
+                               f64 add/mul/fma/ldexp/div_fixup 4.25, conversions 4.25, v_mul_lo_u32 4.26, integer add/xor/and/or/
+                               shift/alignbit/lshl_add/bfe 3.65, compare + select pairs 3.67, lone v_cmp / v_cndmask_e64 / f32 min/max /
+                               min3/max3 / v_readlane / v_writelane 4.25, v_mov 2.55, 64-bit add 2 x 4.29, f32 rcp/rsq/sqrt 8.28,
+                               f64 rcp/rsq/sqrt 16.3.  (One wave per SIMD: 5.1 cycles for everything but the transcendentals, 9.2 / 17.2.)
+                               Rounds 3-4 measured the same ratios on 0.2-0.7 ms dispatches and ANCHORED them at "f64 fma = 4 cycles";
+                               the measured 4.25 moves every cost up by 6 %.  Classes from SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F{32,64},
+                               _INT32, _INT64, _CVT; "other" = SQ_INSTS_VALU minus their sum (compares, selects, min/max, logic, moves,
+                               lane moves), priced at 3.65 = its cheapest members besides v_mov: a LOWER bound of the class's cost for
+                               these kernels, so the peak is an upper bound and `frac` a lower bound.
   valu_busy_measured         = 4 * SQ_ACTIVE_INST_VALU / (1024 SIMDs * GRBM_GUI_ACTIVE / 8)   (can exceed 1: active intervals of the
                                waves of one SIMD overlap)
   lane_utilisation           = SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU)
@@ -69,10 +74,12 @@ for d in a.dirs:
 N = a.samples
 m = {"kernel": sorted(names), "samples_in_pass": N, "source": a.source, "kernel_source_sha16": kernel_source_sha16(),
      "counters": {k: tot[k] for k in sorted(tot)}}
-OTHER_CYCLES = 3.5
-CLASS_CYCLES = {"SQ_INSTS_VALU_ADD_F32": 2.5, "SQ_INSTS_VALU_MUL_F32": 2.5, "SQ_INSTS_VALU_FMA_F32": 2.5, "SQ_INSTS_VALU_TRANS_F32": 7,
-                "SQ_INSTS_VALU_ADD_F64": 4, "SQ_INSTS_VALU_MUL_F64": 4, "SQ_INSTS_VALU_FMA_F64": 4, "SQ_INSTS_VALU_TRANS_F64": 14,
-                "SQ_INSTS_VALU_INT64": 6.6, "SQ_INSTS_VALU_CVT": 4}
+OTHER_CYCLES = 3.65
+CLASS_CYCLES = {"SQ_INSTS_VALU_ADD_F32": 2.56, "SQ_INSTS_VALU_MUL_F32": 2.56, "SQ_INSTS_VALU_FMA_F32": 2.56, "SQ_INSTS_VALU_TRANS_F32": 8.28,
+                "SQ_INSTS_VALU_ADD_F64": 4.25, "SQ_INSTS_VALU_MUL_F64": 4.25, "SQ_INSTS_VALU_FMA_F64": 4.25, "SQ_INSTS_VALU_TRANS_F64": 16.3,
+                "SQ_INSTS_VALU_INT64": 8.58, "SQ_INSTS_VALU_CVT": 4.25, "SQ_INSTS_VALU_INT32": 3.65}
+COST_ANCHOR = ("cycles = GRBM_GUI_ACTIVE / 8 of >= 20 ms dispatches of independent instructions at 4 waves per SIMD, clock held 2.38 GHz "
+               "(profiles/r05/valu_cost_microbench.txt); 'other' at its cheapest members besides v_mov (3.65): frac is a lower bound")
 if "SQ_INSTS_VALU" in tot:
     m["valu_insts_per_sample"] = tot["SQ_INSTS_VALU"] / N
     if all(c in tot for c in CLASS_CYCLES):
@@ -83,6 +90,7 @@ if "SQ_INSTS_VALU" in tot:
         m["valu_mix_per_sample"]["other"] = (tot["SQ_INSTS_VALU"] - classed) / N
         m["valu_class_cycles"] = {c.replace("SQ_INSTS_VALU_", "").lower(): k for c, k in CLASS_CYCLES.items()}
         m["valu_class_cycles"]["other"] = OTHER_CYCLES
+        m["valu_cost_anchor"] = COST_ANCHOR
     if "SQ_ACTIVE_INST_VALU" in tot:
         m["valu_active_cycles_per_inst_measured"] = 4.0 * tot["SQ_ACTIVE_INST_VALU"] / tot["SQ_INSTS_VALU"]
 if "SQ_THREAD_CYCLES_VALU" in tot and "SQ_ACTIVE_INST_VALU" in tot:

@@ -1,18 +1,23 @@
-// Issue cost of VALU instructions on gfx950 at the occupancy of the path-tracing kernels (1024-thread workgroup per CU = 4 waves per
-// SIMD): shader cycles per wave64 instruction PER SIMD (all four waves of a SIMD run the same stream of independent instructions).
-// Build / run: hipcc --offload-arch=gfx950 -O2 tools/microbench/valu_cost.hip -o /tmp/valu_cost && /tmp/valu_cost
+// Issue cost of VALU instructions on gfx950: time and shader cycles per wave64 instruction PER SIMD, at one wave per SIMD (256-thread
+// workgroup per CU) and at the occupancy of the path-tracing kernels (1024 threads per CU = 4 waves per SIMD; all waves of a SIMD run the
+// same stream of independent instructions).  Round 5: every measurement is a dispatch of >= 20 ms (the iteration count is calibrated
+// per instruction; round 4's 0.2-0.7 ms dispatches left the absolute scale open), timed three ways -- HIP events around the dispatch,
+// s_memrealtime (the constant 100 MHz counter) and s_memtime inside the kernel -- and the cycles come from GRBM_GUI_ACTIVE / 8 of the
+// same dispatches (run the binary under rocprofv3 --pmc GRBM_GUI_ACTIVE; tools/microbench/valu_cost_cycles.py joins the two outputs).
+// Build / run: hipcc --offload-arch=gfx950 -O2 tools/microbench/valu_cost.hip -o tools/microbench/valu_cost.bin && tools/microbench/valu_cost.bin
 // Basis of the roofline's cycle table (tools/make_pt_model.py).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
 #define REP8(x) x x x x x x x x
 #define REP64(x) REP8(REP8(x))
-template <int OP>
+template <int OP, int WPS>  // WPS: waves per SIMD = blockDim / 256 (part of the kernel's name for the counter pass)
 __global__ void __launch_bounds__(1024) k(unsigned long long* out, int iters, double seed) {
     double a = seed + threadIdx.x, b = seed * 3.0 + 1.0, c0 = 1.0, c1 = 2.0, c2 = 3.0, c3 = 4.0;
     float fa = (float)a, fb = (float)b, f0 = 1.f, f1 = 2.f, f2 = 3.f, f3 = 4.f;
     unsigned int ua = (unsigned)threadIdx.x * 2654435761u + 12345u, u0 = 1, u1 = 2, u2 = 3, u3 = 4;
     __syncthreads();
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int i = 0; i < iters; i++) {
         if (OP == 0) { REP64(asm volatile("v_fma_f32 %0, %4, %5, %0\n v_fma_f32 %1, %4, %5, %1\n v_fma_f32 %2, %4, %5, %2\n v_fma_f32 %3, %4, %5, %3" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3) : "v"(fa), "v"(fb));) }
@@ -38,34 +43,54 @@ __global__ void __launch_bounds__(1024) k(unsigned long long* out, int iters, do
         if (OP == 19) { REP64(asm volatile("v_cvt_f32_u32_sdwa %0, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n v_cvt_f32_u32_sdwa %1, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n v_cvt_f32_u32_sdwa %2, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n v_cvt_f32_u32_sdwa %3, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : "v"(ua));) }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-    if ((threadIdx.x & 63) == 0) out[(blockIdx.x * 16 + (threadIdx.x >> 6)) * 2] = t1 - t0;
-    if (c0 + c1 + c2 + c3 + f0 + f1 + f2 + f3 + (double)(u0 ^ u1 ^ u2 ^ u3) == 1.2345) out[1] = 1;
+    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+    if ((threadIdx.x & 63) == 0) {
+        out[(blockIdx.x * 16 + (threadIdx.x >> 6)) * 2] = t1 - t0;
+        out[(blockIdx.x * 16 + (threadIdx.x >> 6)) * 2 + 1] = r1 - r0;
+    }
+    if (c0 + c1 + c2 + c3 + f0 + f1 + f2 + f3 + (double)(u0 ^ u1 ^ u2 ^ u3) == 1.2345) out[0] = 1;
+}
+template <int OP, int WPS>
+static void run_one(const char* name) {
+    const int blocks = 256, threads = 256 * WPS;
+    unsigned long long* d;
+    hipMalloc(&d, blocks * 16 * 2 * 8);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    // calibration (short), then the measurement: as many iterations as make the dispatch last >= 20 ms
+    int iters = 200;
+    float ms = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        hipMemset(d, 0, blocks * 16 * 2 * 8);
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((k<OP, WPS>), dim3(blocks), dim3(threads), 0, 0, d, iters, 1.5);
+        hipEventRecord(e1);
+        hipDeviceSynchronize();
+        hipEventElapsedTime(&ms, e0, e1);
+        if (pass == 0) iters = (int)(iters * 25.0 / (ms > 1e-3f ? ms : 1e-3f)) + 1;
+    }
+    std::vector<unsigned long long> h(blocks * 16 * 2);
+    hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
+    double mt = 0, rt = 0;
+    const int waves = blocks * threads / 64;
+    for (int b = 0; b < blocks; b++)
+        for (int w = 0; w < threads / 64; w++) {
+            mt += (double)h[(b * 16 + w) * 2];
+            rt += (double)h[(b * 16 + w) * 2 + 1];
+        }
+    mt /= waves;
+    rt /= waves;
+    const double n_inst = (double)iters * 64 * 4;  // per wave; WPS waves share a SIMD
+    // one line per measurement, machine-readable: valu_cost_cycles.py joins it with the GRBM_GUI_ACTIVE of the dispatch named k<OP, WPS>
+    printf("VALU_COST op=%d wps=%d name=\"%s\" iters=%d inst_per_wave=%.0f event_ms=%.3f realtime_ns=%.0f memtime_ticks=%.0f ns_per_inst_per_simd_event=%.4f ns_per_inst_per_simd_realtime=%.4f "
+           "memtime_ticks_per_ns=%.4f\n",
+           OP, WPS, name, iters, n_inst, ms, rt * 10.0, mt, ms * 1e6 / (WPS * n_inst), rt * 10.0 / (WPS * n_inst), mt / (rt * 10.0));
+    hipFree(d);
 }
 template <int OP>
 static void run(const char* name) {
-    const int blocks = 256, iters = 200;
-    unsigned long long* d;
-    hipMalloc(&d, blocks * 16 * 2 * 8);
-    hipMemset(d, 0, blocks * 16 * 2 * 8);
-    hipEvent_t e0, e1;
-    hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(1024), 0, 0, d, 10, 1.5);
-    hipEventRecord(e0);
-    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(1024), 0, 0, d, iters, 1.5);
-    hipEventRecord(e1);
-    hipDeviceSynchronize();
-    float ms = 0;
-    hipEventElapsedTime(&ms, e0, e1);
-    std::vector<unsigned long long> h(blocks * 16 * 2);
-    hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
-    double mean = 0;
-    for (int i = 0; i < blocks * 16; i++) mean += (double)h[2 * i];
-    mean /= blocks * 16;
-    const double n_inst = (double)iters * 64 * 4;           // per wave
-    // 4 waves share a SIMD: SIMD cycles per wave-instruction = wave's elapsed cycles / (4 waves * n_inst)
-    printf("%-44s %8.3f s_memtime ticks per wave-instruction per SIMD   (kernel %.3f ms -> %.3f ns per wave-instruction per SIMD)\n", name, mean / (4.0 * n_inst), ms,
-           ms * 1e6 / (4.0 * n_inst));
-    hipFree(d);
+    run_one<OP, 1>(name);
+    run_one<OP, 4>(name);
 }
 int main() {
     run<0>("v_fma_f32");
