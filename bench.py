@@ -233,17 +233,22 @@ def single_process(args):
         raise SystemExit("bench.py: device ordinal %d asked for, %d HIP device(s) visible" % (max(devices), n_dev))
     world, cam = rtamd.load_scene_file(SCENE)
     kw = dict(devices=devices, width=args.width, height=args.height, spp=args.spp, max_depth=50, t_min=1e-3, seed=args.seed, kernel=args.kernel)
+    first_st = None   # the first call: scene uploads (one per device) and the creation of the communicators
     for _ in range(args.warmup):
-        world.render_multi(cam, **kw)
-    acc = [{"kernel_ms": 0.0, "samples": 0, "launches": 0} for _ in devices]
+        _, stw = world.render_multi(cam, **kw)
+        first_st = first_st or stw
+    acc = [{"kernel_ms": 0.0, "samples": 0, "launches": 0, "posted_ms": 0.0} for _ in devices]
     exch = 0.0
+    stitch = 0.0
     rows = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         img, st = world.render_multi(cam, **kw)
+        first_st = first_st or st
         for a, s in zip(acc, st):
-            a["kernel_ms"] += s["kernel_ms"]; a["samples"] += s["samples"]; a["launches"] += s["launches"]
+            a["kernel_ms"] += s["kernel_ms"]; a["samples"] += s["samples"]; a["launches"] += s["launches"]; a["posted_ms"] += s["posted_ms"]
         exch += st[0]["exchange_seconds"]
+        stitch += st[0]["stitch_copy_ms"]
         rows = st[0]["rows_through_rccl"]
     dt = time.perf_counter() - t0
     total = args.width * args.height * args.spp * args.steps
@@ -257,7 +262,10 @@ def single_process(args):
                       "parallelism": "rt_render_multi: image tiles 8x8 dealt round-robin to %d rank(s) on HIP devices %s, one host thread per rank, RCCL gather inside librtamd" % (len(devices), devices)},
            "launch": "single-process", "wall_s": dt, "rccl_version": rtamd.lib().rt_rccl_version(), "rows_through_rccl_per_step": rows,
            "includes": "host copy of the stitched frame (PCIe) in every step",
-           "ranks": [{"rank": i, "device": d, "samples": a["samples"], "kernel_ms": a["kernel_ms"], "kernel_ms_per_step": a["kernel_ms"] / max(1, args.steps)}
+           "devices": devices, "comm_init_ms_first_call": first_st[0]["comm_init_ms"],
+           "exchange_ms_per_step": exch * 1e3 / max(1, args.steps), "stitch_and_host_copy_ms_per_step": stitch / max(1, args.steps),
+           "ranks": [{"rank": i, "device": d, "samples": a["samples"], "kernel_ms": a["kernel_ms"], "kernel_ms_per_step": a["kernel_ms"] / max(1, args.steps),
+                      "rows_posted_ms_after_call_began_per_step": a["posted_ms"] / max(1, args.steps), "scene_upload_ms": first_st[i]["upload_ms"]}
                      for i, (d, a) in enumerate(zip(devices, acc))],
            "exchange_stitch_copy_ms_per_step": exch / max(1, args.steps) * 1e3,
            "roofline": roof, "roofline_contract": contract}
@@ -322,6 +330,7 @@ def main():
     torch.cuda.set_device(dev_index)  # before the process group: RCCL binds the communicator to the current device
     dev = torch.device("cuda", dev_index)
     dist = None
+    pg_init_s = 0.0
     force_pg = world_size == 1 and (args.force_pg or os.environ.get("RTAMD_BENCH_FORCE_PG") == "1")
     backend = None
     json_fd = None
@@ -339,7 +348,9 @@ def main():
             os.environ["MASTER_PORT"] = str(s.getsockname()[1])
             s.close()
         backend = "gloo" if rehearse else "nccl"
+        t_pg = time.perf_counter()
         dist.init_process_group(backend=backend, rank=rank, world_size=world_size)
+        pg_init_s = time.perf_counter() - t_pg
 
     world, cam = rtamd.load_scene_file(SCENE)
     params = rtamd.default_params(width=args.width, height=args.height, spp=args.spp, max_depth=50, t_min=1e-3, seed=args.seed,
@@ -355,6 +366,7 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
 
     stats_acc = {"kernel_ms": 0.0, "launches": 0, "samples": 0}
+    first = {}   # the stats of this rank's first render: the one that uploads the scene to its device (rt_stats.upload_ms)
     last = {}
     ex_events = []  # (before the gather, after the stitch) per timed step, on the step's stream
 
@@ -375,6 +387,8 @@ def main():
             stats_acc["launches"] += st["launches"]
             stats_acc["samples"] += st["samples"]
         last.update(st)
+        if not first:
+            first.update(st)
 
     def sync():
         torch.cuda.synchronize()
@@ -391,7 +405,9 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     # per-rank record: [tiles owned, samples, pt_kernel ms (HIP events in librtamd), gather + stitch ms (HIP events), wall s of the timed loop]
-    mine = [float(layout.owned(rank)), float(stats_acc["samples"]), stats_acc["kernel_ms"], sum(a.elapsed_time(b) for a, b in ex_events), dt]
+    # ... device ordinal, scene upload ms (first render of the process), process-group init s
+    mine = [float(layout.owned(rank)), float(stats_acc["samples"]), stats_acc["kernel_ms"], sum(a.elapsed_time(b) for a, b in ex_events), dt,
+            float(dev_index), float(first.get("upload_ms", 0.0)), pg_init_s]
     per_rank = [mine]
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else dev)
@@ -425,10 +441,20 @@ def main():
         if hbm is not None:
             out["roofline_hbm"] = hbm
         out["launch"] = "one process per GPU (torch.distributed)" if world_size > 1 or force_pg else "one process"
-        out["ranks"] = [{"rank": i, "tiles": int(r[0]), "samples": int(r[1]), "kernel_ms": r[2], "exchange_ms": r[3], "loop_wall_s": r[4],
-                         "kernel_ms_per_step": r[2] / max(1, args.steps), "exchange_ms_per_step": r[3] / max(1, args.steps)} for i, r in enumerate(per_rank)]
+        # per rank: what a first SCALE line needs to tell init cost from render from exchange
+        out["ranks"] = [{"rank": i, "device": int(r[5]), "tiles": int(r[0]), "samples": int(r[1]), "kernel_ms": r[2], "exchange_ms": r[3], "loop_wall_s": r[4],
+                         "kernel_ms_per_step": r[2] / max(1, args.steps), "exchange_ms_per_step": r[3] / max(1, args.steps),
+                         "scene_upload_ms": r[6], "process_group_init_s": r[7]} for i, r in enumerate(per_rank)]
+        out["devices"] = [int(r[5]) for r in per_rank]
+        out["rccl_version"] = rtamd.lib().rt_rccl_version()   # the RCCL librtamd is linked with (rt_render_multi); torch's own is in process_group
         if backend is not None:
+            nccl_v = None
+            try:
+                nccl_v = ".".join(str(x) for x in torch.cuda.nccl.version())
+            except Exception:
+                pass
             out["process_group"] = {"backend": backend + (" (RCCL)" if backend == "nccl" else ""), "world": world_size, "forced_at_world_1": bool(force_pg),
+                                    "torch_rccl_version": nccl_v, "init_s_max": max(r[7] for r in per_rank),
                                     "calls": ["init_process_group", "gather", "barrier", "all_reduce(MAX)", "all_gather"]}
         if args.frame_out:
             import numpy as np

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RTAMD_ABI_VERSION 1
+#define RTAMD_ABI_VERSION 2   /* 2 (round 5): rt_stats grew by five f64 fields behind reserved[] */
 
 typedef enum rt_status {
     RT_OK = 0,
@@ -119,7 +119,16 @@ typedef struct rt_stats {
     int32_t grid_blocks;
     int32_t spp_chunk;
     uint64_t scene_bytes;    /* flattened scene size */
-    uint64_t reserved[4];    /* [0] SPPM pre-pass microseconds, [1] render workspace bytes on the device */
+    uint64_t reserved[4];    /* [0] SPPM pre-pass microseconds, [1] render workspace bytes on the device; rt_render_multi, entry 0: [2] microseconds from
+                                the last rank's finish until every row had arrived on the root device (the exchange proper: no stitch, no host copy),
+                                [3] rows that travelled through RCCL */
+    /* ABI version 2: */
+    double upload_ms;        /* copying the scene to this call's device (0 when a copy was already there: uploads happen once per scene and device) */
+    double posted_ms;        /* rt_render_multi, entry i: when rank i's rows were handed to the exchange, ms after the call began (its own finish time;
+                                0 for rows rendered in place on the root device) */
+    double stitch_copy_ms;   /* rt_render_multi, entry 0: the stitch on the root device and the copy of the frame to out_rgb */
+    double comm_init_ms;     /* rt_render_multi, entry 0: creating the RCCL communicators of this device list (0 when they were cached) */
+    double exchange_ms;      /* rt_render_multi, entry 0: reserved[2] in ms */
 } rt_stats;
 
 /* ---- library ------------------------------------------------------------ */
@@ -148,7 +157,8 @@ void rt_tuning_default(rt_tuning* t);
 int rt_tuning_set(const rt_tuning* t);
 /* The render entry points keep a workspace per device for the life of the process (unit rings of the resident waves, ~0.3 GB,
  * accumulator, tickets: no hipMalloc on the hot path), rt_render_multi also its RCCL communicators and its frame-sized buffers (gathered
- * rows, stitched frame, the ranks' rows: up to 4 idle ones per device and size).  This frees the idle ones;
+ * rows, stitched frame, the ranks' rows: up to 4 idle ones per device and size and at most 1 GiB of idle buffers in all -- beyond that
+ * the least recently returned ones are freed).  This frees the idle ones;
  * returns the bytes released. */
 int64_t rt_release_workspaces(void);
 
@@ -270,6 +280,12 @@ typedef struct rt_scene_info {
     int32_t accel_ok, accel_nodes, accel_items, accel_instances, accel_stack, accel_compact;  /* accel_compact: 1 if the compact object-space copies kernel 5 needs were built */
 } rt_scene_info;
 int rt_scene_info_get(const rt_scene* s, rt_scene_info* out);
+/* What a saved accumulator state (rt_render_accumulate) belongs to, beside its rt_params: a 64-bit fingerprint of the committed scene (FNV-1a
+ * over the flattened blob: geometry, materials, textures, BVH wiring; 0 for a scene that is not committed) and the version of everything
+ * that decides the bits of an image -- RNG, deterministic ln / sin, sampling order (a string such as "rtamd-image-5 rng-3 ln-1 sin-1").
+ * A checkpoint written by another build or for another scene must not be resumed: the host compares both (host_cpp/rtamd.hpp does). */
+uint64_t rt_scene_fingerprint(const rt_scene* s);
+const char* rt_spec_version(void);
 
 /* ---- the hot path -------------------------------------------------------- */
 /* Camera::capture_image (camera.rs:66-128) minus the u8 conversion: linear radiance (sum/spp), f64 RGB,
@@ -347,9 +363,13 @@ int rt_assemble_frame_device(const rt_params* p, const double* d_gathered, int64
  *   device_ids: HIP ordinals, one per rank; an ordinal may repeat (its ranks share that device).  NULL = 0 .. n_devices-1.
  *   n_devices:  number of ranks; 0 = one per visible device.
  *   p->rank / p->world must be 0 / 1 (the call partitions the frame itself); p->device is ignored.
- *   stats:      NULL or n_devices entries, entry i = rank i's render (kernel_ms, samples, ...).  stats[0].seconds = wall time of the
- *               whole call, stats[0].reserved[2] = microseconds spent in the exchange + stitch + copy to the host,
- *               stats[0].reserved[3] = number of rows that travelled through RCCL.
+ *   stats:      NULL or n_devices entries, entry i = rank i's render (kernel_ms, samples, upload_ms, posted_ms ...).  stats[0].seconds = wall
+ *               time of the whole call, stats[0].exchange_ms (= reserved[2] in microseconds) = from the last rank's finish until every row
+ *               had arrived on the root device, stats[0].stitch_copy_ms = stitch + copy to the host, stats[0].comm_init_ms = creating the
+ *               communicators (first call with a device list), stats[0].reserved[3] = number of rows that travelled through RCCL.
+ *               A rank's rows are handed to RCCL (ncclSend on its device, the matching ncclRecv on the root's) by the rank's own host thread
+ *               the moment its render has finished -- not after all ranks have joined -- so the rows of early ranks travel while the others
+ *               still render.
  * Errors of any rank come back as that rank's rt_status (first failing rank wins); nothing aborts. */
 int rt_render_multi(const rt_scene* s, const rt_camera* cam, const rt_params* p, int n_devices, const int* device_ids, double* out_rgb,
                     rt_stats* stats);

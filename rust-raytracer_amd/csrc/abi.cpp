@@ -88,52 +88,100 @@ void rt_default_params(rt_params* p) {
 int rt_device_count(void) { return device_count(); }
 // Frame-sized device buffers of rt_render_multi (the gathered rows, the stitched frame, the ranks' own rows) are kept between calls:
 // allocating and freeing them cost every frame about a millisecond (hipFree waits for the device).  Per (device, size): at most
-// FRAME_POOL_KEEP idle buffers; rt_release_workspaces frees them all.
+// FRAME_POOL_KEEP idle buffers, and FRAME_POOL_BYTES of idle buffers in all -- a host that renders many resolutions or rank counts does
+// not pile up a frame per shape: beyond the cap the least recently returned buffers are freed; rt_release_workspaces frees them all.
 namespace {
 const size_t FRAME_POOL_KEEP = 4;
+const size_t FRAME_POOL_BYTES = size_t(1) << 30;
+struct IdleFrame {
+    int dev;
+    size_t bytes;
+    void* p;
+};
 std::mutex g_frame_pool_mu;
-std::map<std::pair<int, size_t>, std::vector<void*>> g_frame_pool;
+std::vector<IdleFrame> g_frame_pool;  // in the order they were returned: the front is the least recently used
 void* frame_pool_take(int dev, size_t bytes) {
     {
         std::lock_guard<std::mutex> g(g_frame_pool_mu);
-        auto it = g_frame_pool.find({dev, bytes});
-        if (it != g_frame_pool.end() && !it->second.empty()) {
-            void* p = it->second.back();
-            it->second.pop_back();
-            return p;
-        }
+        for (size_t i = g_frame_pool.size(); i-- > 0;)
+            if (g_frame_pool[i].dev == dev && g_frame_pool[i].bytes == bytes) {
+                void* p = g_frame_pool[i].p;
+                g_frame_pool.erase(g_frame_pool.begin() + (ptrdiff_t)i);
+                return p;
+            }
     }
     return dev_alloc(bytes);  // (the caller has made `dev` current)
 }
 void frame_pool_give(int dev, size_t bytes, void* p) {  // the caller has made `dev` current
+    std::vector<IdleFrame> drop;
     {
         std::lock_guard<std::mutex> g(g_frame_pool_mu);
-        auto& v = g_frame_pool[{dev, bytes}];
-        if (v.size() < FRAME_POOL_KEEP) {
-            v.push_back(p);
-            return;
+        size_t same = 0, total = bytes;
+        for (const IdleFrame& f : g_frame_pool) {
+            same += (f.dev == dev && f.bytes == bytes) ? 1 : 0;
+            total += f.bytes;
+        }
+        if (same >= FRAME_POOL_KEEP || bytes > FRAME_POOL_BYTES) {
+            drop.push_back(IdleFrame{dev, bytes, p});
+        } else {
+            g_frame_pool.push_back(IdleFrame{dev, bytes, p});
+            while (total > FRAME_POOL_BYTES && g_frame_pool.size() > 1) {  // evict the least recently returned
+                total -= g_frame_pool.front().bytes;
+                drop.push_back(g_frame_pool.front());
+                g_frame_pool.erase(g_frame_pool.begin());
+            }
         }
     }
-    dev_free(p);
+    for (const IdleFrame& f : drop) {
+        try {
+            if (f.dev != dev) dev_set_device(f.dev);
+            dev_free(f.p);
+        } catch (...) {
+        }
+    }
+    if (!drop.empty()) {
+        try {
+            dev_set_device(dev);
+        } catch (...) {
+        }
+    }
 }
 size_t frame_pool_release() {
-    std::map<std::pair<int, size_t>, std::vector<void*>> all;
+    std::vector<IdleFrame> all;
     {
         std::lock_guard<std::mutex> g(g_frame_pool_mu);
         all.swap(g_frame_pool);
     }
     size_t freed = 0;
-    for (auto& kv : all)
-        for (void* p : kv.second) {
-            try {
-                dev_set_device(kv.first.first);
-                dev_free(p);
-                freed += kv.first.second;
-            } catch (...) {
-            }
+    for (const IdleFrame& f : all) {
+        try {
+            dev_set_device(f.dev);
+            dev_free(f.p);
+            freed += f.bytes;
+        } catch (...) {
         }
+    }
     return freed;
 }
+// rt_params.device >= 0 makes that device current for the call only: the caller's current device comes back
+struct DeviceScope {
+    int prev = -1;
+    explicit DeviceScope(int want) {
+        if (want < 0) return;
+        prev = dev_get_device();
+        if (prev != want) dev_set_device(want);
+        else prev = -1;
+    }
+    ~DeviceScope() {
+        if (prev < 0) return;
+        try {
+            dev_set_device(prev);
+        } catch (...) {
+        }
+    }
+    DeviceScope(const DeviceScope&) = delete;
+    DeviceScope& operator=(const DeviceScope&) = delete;
+};
 }  // namespace
 
 int64_t rt_release_workspaces(void) {
@@ -525,6 +573,17 @@ int rt_scene_commit(rt_scene* s) {
         return (int)RT_OK;
     });
 }
+uint64_t rt_scene_fingerprint(const rt_scene* s) {
+    if (!s || !s->committed) return 0;
+    uint64_t h = 1469598103934665603ull;  // FNV-1a, 64 bit
+    for (unsigned char c : s->flat.blob) {
+        h ^= (uint64_t)c;
+        h *= 1099511628211ull;
+    }
+    return h ? h : 1;
+}
+// bumped whenever an image's bits may change for unchanged inputs (round 5: near ties go to the reference-order walk; rng-3 since round 4)
+const char* rt_spec_version(void) { return "rtamd-image-5 rng-3 ln-1 sin-1"; }
 int rt_scene_info_get(const rt_scene* s, rt_scene_info* out) {
     return guard([&] {
         REQUIRE(s && out, "null argument");
@@ -597,7 +656,7 @@ int rt_render_tiles_device(const rt_scene* s, const rt_camera* cam, const rt_par
         if (device_count() < 1) throw RtError(RT_ERR_NO_DEVICE, "no HIP device: librtamd has no CPU fallback");
         auto t0 = std::chrono::steady_clock::now();
         RenderPlan pl = make_plan(p);
-        if (p->device >= 0) dev_set_device(p->device);  // (d_tiles and hip_stream must belong to it)
+        DeviceScope dev_scope(p->device);  // (d_tiles and hip_stream must belong to it; the caller's current device is restored)
         CameraDev cd = make_camera(*cam);
         if (stats) std::memset(stats, 0, sizeof(*stats));
         render_tiles(*s, cd, pl, d_tiles, hip_stream, stats);
@@ -630,7 +689,7 @@ int rt_render_accumulate_device(const rt_scene* s, const rt_camera* cam, const r
         pl.s_first = sample_begin;
         pl.s_last = sample_end;
         pl.ext_accum = d_accum;
-        if (p->device >= 0) dev_set_device(p->device);  // (d_accum and hip_stream must belong to it)
+        DeviceScope dev_scope(p->device);  // (d_accum and hip_stream must belong to it)
         CameraDev cd = make_camera(*cam);
         if (stats) std::memset(stats, 0, sizeof(*stats));
         render_tiles(*s, cd, pl, nullptr, hip_stream, stats);
@@ -652,7 +711,7 @@ int rt_accum_finalize_device(const rt_params* p, const double* d_accum, double* 
         REQUIRE(p && d_accum && d_tiles, "null argument");
         if (device_count() < 1) throw RtError(RT_ERR_NO_DEVICE, "no HIP device: librtamd has no CPU fallback");
         const RenderPlan pl = make_plan(p);
-        if (p->device >= 0) dev_set_device(p->device);
+        DeviceScope dev_scope(p->device);
         finalize_tiles(pl, d_accum, d_tiles, hip_stream);
         return (int)RT_OK;
     });
@@ -677,10 +736,13 @@ int rt_render_accumulate(const rt_scene* s, const rt_camera* cam, const rt_param
         if (device_count() < 1) throw RtError(RT_ERR_NO_DEVICE, "no HIP device: librtamd has no CPU fallback");
         const int64_t n = rt_accum_state_doubles(p);
         REQUIRE(n > 0, "bad image size or partition");
-        if (p->device >= 0) dev_set_device(p->device);
+        DeviceScope dev_scope(p->device);
         DevBuf acc;
         acc.p = dev_alloc((size_t)n * sizeof(double));
-        if (sample_begin > 0) dev_copy_to_device(acc.p, accum_state, (size_t)n * sizeof(double));
+        // the state always goes to the device: a rank that owns no tile (more ranks than tiles) launches nothing, and what comes back must
+        // be what went in -- zeros at sample_begin == 0 -- not uninitialised device memory
+        if (sample_begin == 0) std::memset(accum_state, 0, (size_t)n * sizeof(double));
+        dev_copy_to_device(acc.p, accum_state, (size_t)n * sizeof(double));
         const int rc = rt_render_accumulate_device(s, cam, p, sample_begin, sample_end, (double*)acc.p, nullptr, stats);
         if (rc != RT_OK) return rc;
         dev_copy_to_host(accum_state, acc.p, (size_t)n * sizeof(double));
@@ -694,7 +756,7 @@ int rt_accum_finalize(const rt_params* p, const double* accum_state, double* out
         if (device_count() < 1) throw RtError(RT_ERR_NO_DEVICE, "no HIP device: librtamd has no CPU fallback");
         const RenderPlan pl = make_plan(p);
         const size_t n = (size_t)std::max<int64_t>(1, pl.tiles_owned) * TILE_PIX * 3, frame_bytes = (size_t)pl.width * pl.height * 3 * sizeof(double);
-        if (p->device >= 0) dev_set_device(p->device);
+        DeviceScope dev_scope(p->device);
         DevBuf acc, tiles, frame;
         acc.p = dev_alloc(n * sizeof(double));
         tiles.p = dev_alloc(n * sizeof(double));
@@ -718,7 +780,7 @@ int rt_render_sppm_tiles_device(const rt_scene* s, const rt_camera* cam, const r
         rt_params q = *p;
         q.integrator = 0;
         RenderPlan pl = make_plan(&q);
-        if (p->device >= 0) dev_set_device(p->device);
+        DeviceScope dev_scope(p->device);
         CameraDev cd = make_camera(*cam);
         rt_stats st{};
         render_sppm(*s, cd, pl, *cfg, d_tiles, nullptr, hip_stream, &st, nullptr);
@@ -782,7 +844,7 @@ static int render_host(const rt_scene* s, const CameraDev& cd, const rt_params* 
         if (!s->committed) throw RtError(RT_ERR_NOT_COMMITTED, "rt_scene_commit has not been called");
         if (device_count() < 1) throw RtError(RT_ERR_NO_DEVICE, "no HIP device: librtamd has no CPU fallback");
         auto t0 = std::chrono::steady_clock::now();
-        if (p->device >= 0) dev_set_device(p->device);
+        DeviceScope dev_scope(p->device);
         RenderPlan pl = make_plan(p);
         if (stats) std::memset(stats, 0, sizeof(*stats));
         struct Buf {
@@ -858,7 +920,8 @@ struct DevMem {  // device memory that remembers which device it lives on
 };
 struct ExchangeLease {
     Exchange* e = nullptr;
-    ~ExchangeLease() { exchange_close(e); }
+    bool failed = false;  // an exchange call threw: the communicators are destroyed instead of going back into the cache
+    ~ExchangeLease() { exchange_close(e, failed); }
 };
 }  // namespace
 
@@ -880,6 +943,7 @@ static int render_fanout(const rt_params* p, int n_devices, const int* device_id
                                                 std::to_string(visible) + " device(s))");
     }
     const auto t0 = std::chrono::steady_clock::now();
+    auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(t - t0).count(); };
     const int caller_device = dev_get_device();
     struct Restore {
         int d;
@@ -910,6 +974,16 @@ static int render_fanout(const rt_params* p, int n_devices, const int* device_id
     // exchange is forced) into a row of their own on their device, which then travels
     std::vector<DevMem> rows((size_t)n);
     std::vector<double*> dst((size_t)n);
+    std::vector<int> uniq;  // comm rank r = uniq[r]; the root's device first
+    auto comm_rank = [&](int dev) {
+        for (size_t r = 0; r < uniq.size(); r++)
+            if (uniq[r] == dev) return (int)r;
+        uniq.push_back(dev);
+        return (int)uniq.size() - 1;
+    };
+    comm_rank(root);
+    std::vector<RowMove> moves((size_t)n, RowMove{0, nullptr, 0, nullptr, 0});  // moves[i].count == 0: rank i's rows stay where they are rendered
+    size_t n_moves = 0;
     for (int i = 0; i < n; i++) {
         double* slot = (double*)gathered.p + (size_t)i * row_doubles;
         if (ids[(size_t)i] == root && !force) {
@@ -917,16 +991,42 @@ static int render_fanout(const rt_params* p, int n_devices, const int* device_id
         } else {
             rows[(size_t)i].alloc(ids[(size_t)i], row_doubles * sizeof(double));
             dst[(size_t)i] = (double*)rows[(size_t)i].p;
+            const size_t count = (size_t)plans[(size_t)i].tiles_owned * TILE_PIX * 3;
+            if (count) {
+                moves[(size_t)i] = RowMove{comm_rank(ids[(size_t)i]), (const double*)rows[(size_t)i].p, 0, slot, count};
+                n_moves++;
+            }
         }
     }
+    // the communicators BEFORE the renders start (creating them is the expensive part of a first call and no part of the exchange)
+    ExchangeLease lease;
+    double comm_init_ms = 0.;
+    if (n_moves) {
+        const auto tc = std::chrono::steady_clock::now();
+        bool created = false;
+        lease.e = exchange_open(uniq, &created);
+        if (created) comm_init_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc).count();
+    }
+    std::mutex post_mu;  // one rank at a time drives the communicators (exchange_post)
     std::vector<rt_stats> st((size_t)n);
     std::vector<int> rc((size_t)n, (int)RT_OK);
     std::vector<std::string> msg((size_t)n);
+    std::vector<double> posted_ms((size_t)n, 0.);
     auto work = [&](int i) {
         try {
             dev_set_device(ids[(size_t)i]);
             std::memset(&st[(size_t)i], 0, sizeof(rt_stats));
             per_rank(plans[(size_t)i], dst[(size_t)i], &st[(size_t)i]);
+            if (moves[(size_t)i].count) {  // this rank's rows leave NOW: the ranks still rendering do not hold them up
+                std::lock_guard<std::mutex> g(post_mu);
+                try {
+                    exchange_post(lease.e, moves[(size_t)i]);
+                } catch (...) {
+                    lease.failed = true;
+                    throw;
+                }
+                posted_ms[(size_t)i] = ms_since(std::chrono::steady_clock::now());
+            }
         } catch (const RtError& e) {
             rc[(size_t)i] = e.code;
             msg[(size_t)i] = e.msg;
@@ -944,36 +1044,27 @@ static int render_fanout(const rt_params* p, int n_devices, const int* device_id
         work(0);  // rank 0 on the calling thread, as the reference's caller blocks in capture_image
         for (auto& t : th) t.join();
     }
+    const auto t1 = std::chrono::steady_clock::now();
+    // ---- the exchange: every posted row has to arrive in its slot on the root device (also after a failed rank: nothing may still be in
+    //      flight when the buffers go back to the pool)
+    if (lease.e) {
+        try {
+            exchange_wait(lease.e);
+        } catch (...) {
+            lease.failed = true;
+            throw;
+        }
+    }
     for (int i = 0; i < n; i++)
         if (rc[(size_t)i] != RT_OK) throw RtError(rc[(size_t)i], "rank " + std::to_string(i) + " (device " + std::to_string(ids[(size_t)i]) + "): " + msg[(size_t)i]);
-    const auto t1 = std::chrono::steady_clock::now();
-    // ---- the exchange: rows -> their slots on the root device
-    std::vector<int> uniq;  // comm rank r = uniq[r]; the root's device first
-    auto comm_rank = [&](int dev) {
-        for (size_t r = 0; r < uniq.size(); r++)
-            if (uniq[r] == dev) return (int)r;
-        uniq.push_back(dev);
-        return (int)uniq.size() - 1;
-    };
-    comm_rank(root);
-    std::vector<RowMove> moves;
-    for (int i = 0; i < n; i++)
-        if (rows[(size_t)i].p) {
-            const size_t count = (size_t)plans[(size_t)i].tiles_owned * TILE_PIX * 3;
-            if (count) moves.push_back(RowMove{comm_rank(ids[(size_t)i]), (const double*)rows[(size_t)i].p, 0, (double*)gathered.p + (size_t)i * row_doubles, count});
-        }
-    if (!moves.empty()) {
-        ExchangeLease lease;
-        lease.e = exchange_open(uniq);
-        exchange_rows(lease.e, moves.data(), moves.size());
-    }
+    const auto t2 = std::chrono::steady_clock::now();
     dev_set_device(root);
     rt_params whole = *p;
     whole.rank = 0;
     whole.world = n;
     assemble_frame(make_plan(&whole), (const double*)gathered.p, stride, (double*)frame.p, nullptr);
     dev_copy_to_host(out_rgb, frame.p, frame_bytes);
-    const auto t2 = std::chrono::steady_clock::now();
+    const auto t3 = std::chrono::steady_clock::now();
     if (stats) {
         for (int i = 0; i < n; i++) {
             stats[i] = st[(size_t)i];
@@ -985,10 +1076,14 @@ static int render_fanout(const rt_params* p, int n_devices, const int* device_id
                 px += (uint64_t)std::min(TILE_W, pl.width - tx * TILE_W) * std::min(TILE_H, pl.height - ty * TILE_H);
             }
             stats[i].samples = px * (uint64_t)pl.spp;
+            stats[i].posted_ms = posted_ms[(size_t)i];
         }
-        stats[0].seconds = std::chrono::duration<double>(t2 - t0).count();
-        stats[0].reserved[2] = (uint64_t)(std::chrono::duration<double>(t2 - t1).count() * 1e6);
-        stats[0].reserved[3] = (uint64_t)moves.size();
+        stats[0].seconds = std::chrono::duration<double>(t3 - t0).count();
+        stats[0].exchange_ms = std::chrono::duration<double, std::milli>(t2 - t1).count();  // the last rank's finish (the join) -> all rows on the root
+        stats[0].reserved[2] = (uint64_t)(stats[0].exchange_ms * 1e3);
+        stats[0].reserved[3] = (uint64_t)n_moves;
+        stats[0].stitch_copy_ms = std::chrono::duration<double, std::milli>(t3 - t2).count();
+        stats[0].comm_init_ms = comm_init_ms;
     }
     return (int)RT_OK;
 }
@@ -1054,7 +1149,7 @@ int rt_render_sppm(const rt_scene* s, const rt_camera* cam, const rt_params* p, 
         if (!s->committed) throw RtError(RT_ERR_NOT_COMMITTED, "rt_scene_commit has not been called");
         if (device_count() < 1) throw RtError(RT_ERR_NO_DEVICE, "no HIP device: librtamd has no CPU fallback");
         auto t0 = std::chrono::steady_clock::now();
-        if (p->device >= 0) dev_set_device(p->device);
+        DeviceScope dev_scope(p->device);
         rt_params q = *p;
         if (q.spp == 0) q.spp = 1;  // make_plan wants a positive spp; the pre-pass-only case never launches the render
         q.integrator = 0;

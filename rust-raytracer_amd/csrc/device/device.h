@@ -63,9 +63,12 @@ struct RowMove {  // `count` f64 from `src` on comm rank src_rank's device to `d
     double* dst;
     size_t count;
 };
-Exchange* exchange_open(const std::vector<int>& devices);  // comm rank r = devices[r] (distinct ordinals); ncclCommInitAll on first use
-void exchange_close(Exchange* e);                          // returns the lease; the communicators stay cached
-void exchange_rows(Exchange* e, const RowMove* moves, size_t n_moves);  // grouped ncclSend / ncclRecv; returns when the rows have arrived
+Exchange* exchange_open(const std::vector<int>& devices, bool* created = nullptr);  // comm rank r = devices[r] (distinct ordinals); ncclCommInitAll on first use (*created)
+void exchange_close(Exchange* e, bool failed = false);     // returns the lease; the communicators stay cached -- unless an exchange on them failed: then they are destroyed
+// One row: ncclSend on the source rank's communicator + the matching ncclRecv on the destination's, as one group, enqueued on the two ranks'
+// exchange streams; returns without waiting.  Calls on one Exchange must not overlap (rt_render_multi's rank threads take a mutex).
+void exchange_post(Exchange* e, const RowMove& move);
+void exchange_wait(Exchange* e);                           // returns when every posted row has arrived
 size_t exchange_release_idle();                            // destroys the idle cached communicators; returns how many sets
 int exchange_library_version();                            // ncclGetVersion
 

@@ -1,8 +1,9 @@
 // The one data-path exchange of the multi-GPU frame (camera.rs:113-123 is its CPU form: the row bands travel
 // through a channel and are stitched by the caller): every rank's tile-major rows go to the root device, over xGMI, through
 // RCCL.  One process drives all devices (rt_render_multi, abi.cpp): the communicators come from ncclCommInitAll and live in
-// a per-process cache keyed by the device list (creating them costs far more than the exchange); rows travel as grouped
-// ncclSend / ncclRecv pairs -- each peer's row crosses its own direct link to the root, 7 links in parallel on an 8-GPU node --
+// a per-process cache keyed by the device list (creating them costs far more than the exchange); a row travels as one grouped
+// ncclSend / ncclRecv pair, posted the moment its rank has finished rendering (round 5; round 4 posted all rows in one group after
+// the ranks had joined) -- each peer's row crosses its own direct link to the root, 7 links in parallel on an 8-GPU node --
 // on one non-blocking stream per device.  Rows that already sit on the root device never get here unless a test asks for it
 // (rt_tuning.multi_force_rccl): then they are sent from a rank to itself through the same calls.
 // Host code only (no kernels); compiled by hipcc for the HIP and RCCL headers.
@@ -34,6 +35,7 @@ struct Exchange {
     std::vector<int> devices;  // comm rank r lives on devices[r]
     std::vector<ncclComm_t> comms;
     std::vector<hipStream_t> streams;
+    std::vector<char> used;  // streams with rows in flight (exchange_post .. exchange_wait)
     bool busy = false;
 };
 static std::mutex g_ex_mu;
@@ -60,8 +62,9 @@ static void destroy(Exchange* e) {
     delete e;
 }
 
-Exchange* exchange_open(const std::vector<int>& devices) {
+Exchange* exchange_open(const std::vector<int>& devices, bool* created) {
     if (devices.empty()) throw RtError(RT_ERR_ARG, "exchange over no device");
+    if (created) *created = false;
     {
         std::lock_guard<std::mutex> g(g_ex_mu);
         for (Exchange* e : g_ex)
@@ -70,11 +73,13 @@ Exchange* exchange_open(const std::vector<int>& devices) {
                 return e;
             }
     }
+    if (created) *created = true;
     DeviceGuard guard;
     Exchange* e = new Exchange();
     e->devices = devices;
     e->comms.assign(devices.size(), nullptr);
     e->streams.assign(devices.size(), nullptr);
+    e->used.assign(devices.size(), 0);
     try {
         EX_NCCL(ncclCommInitAll(e->comms.data(), (int)devices.size(), devices.data()));
         for (size_t r = 0; r < devices.size(); r++) {
@@ -91,8 +96,23 @@ Exchange* exchange_open(const std::vector<int>& devices) {
     return e;
 }
 
-void exchange_close(Exchange* e) {
+void exchange_close(Exchange* e, bool failed) {
     if (!e) return;
+    if (failed) {  // a send / receive / group failed on these communicators: RCCL leaves them in an undefined state -- never hand them out again
+        DeviceGuard guard;
+        {
+            std::lock_guard<std::mutex> g(g_ex_mu);
+            for (auto it = g_ex.begin(); it != g_ex.end(); ++it)
+                if (*it == e) {
+                    g_ex.erase(it);
+                    break;
+                }
+        }
+        for (size_t r = 0; r < e->devices.size(); r++)  // (what is still queued on the exchange streams must be over before they go)
+            if (e->streams[r] && hipSetDevice(e->devices[r]) == hipSuccess) (void)hipStreamSynchronize(e->streams[r]);
+        destroy(e);
+        return;
+    }
     std::lock_guard<std::mutex> g(g_ex_mu);
     e->busy = false;
 }
@@ -113,31 +133,32 @@ size_t exchange_release_idle() {
     return n;
 }
 
-// All moves as ONE group: for every row an ncclSend on the source rank's communicator and the matching ncclRecv on the
-// destination's (several rows between the same pair are matched in issue order).  Returns when every involved stream is idle.
-void exchange_rows(Exchange* e, const RowMove* moves, size_t n_moves) {
-    if (!e || n_moves == 0) return;
+// One row as one group: an ncclSend on the source rank's communicator and the matching ncclRecv on the destination's (rows between the
+// same pair are matched in issue order), enqueued on the two ranks' exchange streams.  The rank threads of rt_render_multi call this one
+// at a time (a communicator may be driven by several threads, not concurrently), each the moment its render is over: a peer's row then
+// crosses its xGMI link while the other ranks still render; the root's receive kernels run as soon as its own render leaves them a CU.
+void exchange_post(Exchange* e, const RowMove& m) {
+    if (!e) throw RtError(RT_ERR_ARG, "exchange_post: no exchange");
     const int n = (int)e->devices.size();
-    for (size_t i = 0; i < n_moves; i++)
-        if (moves[i].src_rank < 0 || moves[i].src_rank >= n || moves[i].dst_rank < 0 || moves[i].dst_rank >= n || !moves[i].src || !moves[i].dst)
-            throw RtError(RT_ERR_ARG, "exchange_rows: bad move");
+    if (m.src_rank < 0 || m.src_rank >= n || m.dst_rank < 0 || m.dst_rank >= n || !m.src || !m.dst) throw RtError(RT_ERR_ARG, "exchange_post: bad move");
+    if (m.count == 0) return;
     DeviceGuard guard;
-    std::vector<char> used((size_t)n, 0);
-    ncclResult_t first = ncclSuccess;
+    e->used[(size_t)m.src_rank] = e->used[(size_t)m.dst_rank] = 1;
     EX_NCCL(ncclGroupStart());
-    for (size_t i = 0; i < n_moves && first == ncclSuccess; i++) {
-        const RowMove& m = moves[i];
-        used[(size_t)m.src_rank] = used[(size_t)m.dst_rank] = 1;
-        first = ncclSend(m.src, m.count, ncclDouble, m.dst_rank, e->comms[(size_t)m.src_rank], e->streams[(size_t)m.src_rank]);
-        if (first == ncclSuccess) first = ncclRecv(m.dst, m.count, ncclDouble, m.src_rank, e->comms[(size_t)m.dst_rank], e->streams[(size_t)m.dst_rank]);
-    }
+    ncclResult_t first = ncclSend(m.src, m.count, ncclDouble, m.dst_rank, e->comms[(size_t)m.src_rank], e->streams[(size_t)m.src_rank]);
+    if (first == ncclSuccess) first = ncclRecv(m.dst, m.count, ncclDouble, m.src_rank, e->comms[(size_t)m.dst_rank], e->streams[(size_t)m.dst_rank]);
     const ncclResult_t end = ncclGroupEnd();  // always closed, also after a failed call inside the group
     if (first != ncclSuccess) throw RtError(RT_ERR_HIP, std::string("ncclSend / ncclRecv: ") + ncclGetErrorString(first));
     if (end != ncclSuccess) throw RtError(RT_ERR_HIP, std::string("ncclGroupEnd: ") + ncclGetErrorString(end));
-    for (int r = 0; r < n; r++)
-        if (used[(size_t)r]) {
-            EX_HIP(hipSetDevice(e->devices[(size_t)r]));
-            EX_HIP(hipStreamSynchronize(e->streams[(size_t)r]));
+}
+void exchange_wait(Exchange* e) {
+    if (!e) return;
+    DeviceGuard guard;
+    for (size_t r = 0; r < e->devices.size(); r++)
+        if (e->used[r]) {
+            e->used[r] = 0;
+            EX_HIP(hipSetDevice(e->devices[r]));
+            EX_HIP(hipStreamSynchronize(e->streams[r]));
         }
 }
 

@@ -3490,10 +3490,18 @@ void dev_copy_to_host(void* dst, const void* src, size_t n) { HIP_CHECK(hipMemcp
 void dev_copy_to_device(void* dst, const void* src, size_t n) { HIP_CHECK(hipMemcpy(dst, src, n, hipMemcpyHostToDevice)); }
 void dev_set_device(int d) { HIP_CHECK(hipSetDevice(d)); }
 
-static const char* device_blob(const rt_scene& s, int dev) {
+static const char* device_blob(const rt_scene& s, int dev, double* upload_ms = nullptr) {
     std::lock_guard<std::mutex> g(s.dev_mu);
     for (auto& c : s.dev)
         if (c.device == dev) return (const char*)c.d_blob;
+    const auto t0 = std::chrono::steady_clock::now();
+    struct Timed {  // the one upload of this scene to this device (rt_stats.upload_ms of the call that made it)
+        double* out;
+        std::chrono::steady_clock::time_point t0;
+        ~Timed() {
+            if (out) *out = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        }
+    } timed{upload_ms, t0};
     DeviceCopy c;
     c.device = dev;
     HIP_CHECK(hipMalloc(&c.d_blob, s.flat.blob.size()));
@@ -3704,7 +3712,9 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
     const DevInfo& di = dev_info(dev);
 
     FlatView view = s.flat.view;
-    view.base = device_blob(s, dev);
+    double upload_ms = 0.;
+    view.base = device_blob(s, dev, &upload_ms);
+    if (st) st->upload_ms = upload_ms;
     const bool moving = (view.kinds_mask & (1u << NK_MSPHERE)) != 0;  // D9: the paths' times live in LDS, 8 bytes per lane
     // D9: moving spheres, noise textures and an open shutter (every sample draws a time) live in their own kernel variants (GENERAL == 2,
     // kernels 1 / 2, integrator 0): nothing of them is compiled into the others

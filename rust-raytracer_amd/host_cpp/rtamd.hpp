@@ -24,6 +24,8 @@
 #include <utility>
 #include <vector>
 
+#include <unistd.h>  // fsync: a checkpoint is on disk before it replaces the previous one
+
 #include "rtamd.h"
 
 namespace rtamd_host {
@@ -407,13 +409,25 @@ class World {
         rt_default_params(&p);
         p.width = cfg.width; p.height = cfg.height; p.spp = cfg.sample_per_pixel; p.max_depth = cfg.max_depth;
         p.t_min = cfg.t_min; p.seed = cfg.seed; p.integrator = cfg.integrator;
+        // what the state belongs to: the frame (rt_params), the scene and the camera (fingerprints), and the library's image spec
+        // (RNG / ln / sin / sampling-order version) -- a state of another scene or build must not be resumed under a bit-identity claim
         struct Header {
             char magic[8];
             int32_t width, height, spp, max_depth, integrator, next_sample;
             uint64_t seed;
             double t_min;
             int64_t n_doubles;
-        } want = {{'R', 'T', 'A', 'M', 'D', 'C', 'K', '1'}, p.width, p.height, p.spp, p.max_depth, p.integrator, 0, p.seed, p.t_min, rt_accum_state_doubles(&p)};
+            uint64_t scene_fingerprint, camera_fingerprint;
+            char spec[48];
+        } want = {{'R', 'T', 'A', 'M', 'D', 'C', 'K', '2'}, p.width, p.height, p.spp, p.max_depth, p.integrator, 0, p.seed, p.t_min, rt_accum_state_doubles(&p),
+                  rt_scene_fingerprint(s_), 0, {0}};
+        {
+            uint64_t h = 1469598103934665603ull;  // FNV-1a over Camera::new's arguments
+            const unsigned char* cb = (const unsigned char*)&cam.c;
+            for (size_t i = 0; i < sizeof(cam.c); i++) h = (h ^ cb[i]) * 1099511628211ull;
+            want.camera_fingerprint = h;
+            std::strncpy(want.spec, rt_spec_version(), sizeof(want.spec) - 1);
+        }
         if (want.n_doubles <= 0 || run_samples < 1) throw Error(RT_ERR_ARG, "capture_image_resumable: bad frame size or instalment");
         std::vector<double> state((size_t)want.n_doubles, 0.);
         Header h = want;
@@ -423,7 +437,8 @@ class World {
             Header cmp = h;
             cmp.next_sample = 0;
             if (!ok || std::memcmp(&cmp, &want, sizeof(Header)) != 0 || h.next_sample < 0 || h.next_sample > p.spp)
-                throw Error(RT_ERR_ARG, "capture_image_resumable: " + state_file + " is not the state of this frame");
+                throw Error(RT_ERR_ARG, "capture_image_resumable: " + state_file + " is not the state of this frame (frame parameters, scene, camera or library spec \"" +
+                                            std::string(want.spec) + "\" differ)");
         }
         if (h.next_sample < p.spp) {
             const int end = std::min(p.spp, h.next_sample + run_samples);
@@ -432,7 +447,8 @@ class World {
             const std::string tmp = state_file + ".tmp";  // written beside, then renamed: a kill never leaves half a state
             FILE* f = std::fopen(tmp.c_str(), "wb");
             if (!f) throw Error(RT_ERR_IO, "cannot write " + tmp);
-            const bool ok = std::fwrite(&h, sizeof(h), 1, f) == 1 && std::fwrite(state.data(), sizeof(double), state.size(), f) == state.size();
+            bool ok = std::fwrite(&h, sizeof(h), 1, f) == 1 && std::fwrite(state.data(), sizeof(double), state.size(), f) == state.size();
+            ok = ok && std::fflush(f) == 0 && ::fsync(::fileno(f)) == 0;  // on disk before it takes the old state's name
             if (std::fclose(f) != 0 || !ok || std::rename(tmp.c_str(), state_file.c_str()) != 0) throw Error(RT_ERR_IO, "cannot write " + state_file);
         }
         if (done_samples) *done_samples = h.next_sample;

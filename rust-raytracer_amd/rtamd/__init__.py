@@ -49,7 +49,9 @@ class rt_params(C.Structure):
 class rt_stats(C.Structure):
     _fields_ = [("seconds", C.c_double), ("kernel_ms", C.c_double), ("reduce_ms", C.c_double), ("samples", C.c_uint64),
                 ("launches", C.c_int32), ("kernel_used", C.c_int32), ("scene_in_lds", C.c_int32), ("block_threads", C.c_int32),
-                ("grid_blocks", C.c_int32), ("spp_chunk", C.c_int32), ("scene_bytes", C.c_uint64), ("reserved", C.c_uint64 * 4)]
+                ("grid_blocks", C.c_int32), ("spp_chunk", C.c_int32), ("scene_bytes", C.c_uint64), ("reserved", C.c_uint64 * 4),
+                ("upload_ms", C.c_double), ("posted_ms", C.c_double), ("stitch_copy_ms", C.c_double), ("comm_init_ms", C.c_double),
+                ("exchange_ms", C.c_double)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
@@ -137,6 +139,8 @@ _SIGS = [
     ("rt_scene_load_file", C.c_int, [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(rt_camera)]),
     ("rt_scene_commit", C.c_int, [C.c_void_p]),
     ("rt_scene_info_get", C.c_int, [C.c_void_p, C.POINTER(rt_scene_info)]),
+    ("rt_scene_fingerprint", C.c_uint64, [C.c_void_p]),
+    ("rt_spec_version", C.c_char_p, []),
     ("rt_render", C.c_int, [C.c_void_p, C.POINTER(rt_camera), C.POINTER(rt_params), _dp, C.POINTER(rt_stats)]),
     ("rt_render_camera_frame", C.c_int, [C.c_void_p, C.POINTER(rt_camera_frame), C.POINTER(rt_params), _dp, C.POINTER(rt_stats)]),
     ("rt_camera_frame_from", C.c_int, [C.POINTER(rt_camera), C.POINTER(rt_camera_frame)]),

@@ -107,6 +107,11 @@ pub struct rt_stats {
     pub spp_chunk: i32,
     pub scene_bytes: u64,
     pub reserved: [u64; 4],
+    pub upload_ms: c_double,
+    pub posted_ms: c_double,
+    pub stitch_copy_ms: c_double,
+    pub comm_init_ms: c_double,
+    pub exchange_ms: c_double,
 }
 
 #[repr(C)]
@@ -233,6 +238,8 @@ extern "C" {
     pub fn rt_scene_load_file(path: *const c_char, out: *mut *mut rt_scene, cam_out: *mut rt_camera) -> c_int;
     pub fn rt_scene_commit(s: *mut rt_scene) -> c_int;
     pub fn rt_scene_info_get(s: *const rt_scene, out: *mut rt_scene_info) -> c_int;
+    pub fn rt_scene_fingerprint(s: *const rt_scene) -> u64;
+    pub fn rt_spec_version() -> *const c_char;
     // the hot path
     pub fn rt_render(s: *const rt_scene, cam: *const rt_camera, p: *const rt_params, out_rgb: *mut c_double, stats: *mut rt_stats) -> c_int;
     pub fn rt_render_camera_frame(s: *const rt_scene, frame: *const rt_camera_frame, p: *const rt_params, out_rgb: *mut c_double, stats: *mut rt_stats) -> c_int;
@@ -511,6 +518,10 @@ impl Scene {
         }
         let n = n64 as usize;
         if state.len() != n {
+            if begin > 0 {
+                // a state of another size cannot be the sums of samples [0, begin) of THIS frame: refusing beats silently starting over
+                return Err(RtError { code: -1, message: format!("render_accumulate: state has {} values, this frame needs {} (begin = {})", state.len(), n, begin) });
+            }
             state.clear();
             state.resize(n, 0.0);
         }

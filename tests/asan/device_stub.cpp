@@ -7,13 +7,16 @@
 // test stub -- the product reads no environment variable) the stub models N "devices" whose memory is host memory:
 //   render_tiles   fills the rank's tile-major rows with a PATTERN that depends only on (global tile index, pixel in tile, channel,
 //                  seed) -- value(t, pix, c) below -- so a stitched frame is right iff every tile went through the right slot;
-//   exchange_rows  copies rows (what the grouped ncclSend / ncclRecv do) and counts them;
+//   exchange_post  copies one row (what a grouped ncclSend / ncclRecv pair does), counts it and refuses overlapping calls;
+//                  RTAMD_STUB_STAGGER_MS=k makes rank r's render take k * r milliseconds, so the ranks finish one after the other;
 //   assemble_frame is the stitch of camera.rs:115-123 restated on the host (tile t of rank r sits at row r, slot t / world).
 // Device memory is malloc'ed per allocation, so a slot computed wrongly is a heap overflow that ASan reports.
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <thread>
 
 #include "device/device.h"
 namespace rtamd {
@@ -65,6 +68,7 @@ void render_tiles(const rt_scene&, const CameraDev&, const RenderPlan& pl, doubl
         for (int pix = 0; pix < TILE_PIX; pix++)
             for (int c = 0; c < 3; c++) d_tiles[((size_t)lt * TILE_PIX + pix) * 3 + c] = stub_value(t, pix, c, pl.seed);
     }
+    if (const char* e = std::getenv("RTAMD_STUB_STAGGER_MS")) std::this_thread::sleep_for(std::chrono::milliseconds(std::atoi(e) * pl.rank));
     if (st) {
         st->kernel_ms = 1.0;
         st->launches = 1;
@@ -129,35 +133,76 @@ size_t release_workspaces() { return 0; }
 
 struct Exchange {
     std::vector<int> devices;
+    bool posting = false;  // exchange_post calls on ONE communicator set must not overlap (several rank threads drive it)
 };
-Exchange* exchange_open(const std::vector<int>& devices) {
+static int g_ex_open = 0, g_ex_created = 0, g_ex_destroyed = 0;
+static std::vector<std::vector<int>> g_ex_cache;  // device lists whose communicators "exist" (the real cache keeps them between calls)
+Exchange* exchange_open(const std::vector<int>& devices, bool* created) {
     for (size_t i = 0; i < devices.size(); i++)
         for (size_t j = 0; j < i; j++)
             if (devices[i] == devices[j]) throw RtError(RT_ERR_ARG, "stub: a communicator holds a device once (ncclCommInitAll would refuse)");
-    return new Exchange{devices};
+    std::lock_guard<std::mutex> g(g_stub_mu);
+    bool found = false;
+    for (auto& d : g_ex_cache) found = found || d == devices;
+    if (!found) {
+        g_ex_cache.push_back(devices);
+        g_ex_created++;
+    }
+    if (created) *created = !found;
+    g_ex_open++;
+    Exchange* e = new Exchange();
+    e->devices = devices;
+    return e;
 }
-void exchange_close(Exchange* e) { delete e; }
-void exchange_rows(Exchange* e, const RowMove* m, size_t n) {
-    for (size_t i = 0; i < n; i++) {
-        if (m[i].src_rank < 0 || m[i].src_rank >= (int)e->devices.size() || m[i].dst_rank < 0 || m[i].dst_rank >= (int)e->devices.size())
-            throw RtError(RT_ERR_ARG, "stub: bad comm rank");
-        {   // a row leaves the device of its source rank and lands on the device of its destination rank
-            std::lock_guard<std::mutex> g(g_stub_mu);
-            auto owner = [&](const void* q) {
-                for (auto& kv : g_owner)
-                    if ((const char*)q >= (const char*)kv.first && (const char*)q < (const char*)kv.first + kv.second.bytes) return kv.second.device;
-                return -1;
-            };
-            if (owner(m[i].src) != e->devices[(size_t)m[i].src_rank] || owner(m[i].dst) != e->devices[(size_t)m[i].dst_rank])
-                throw RtError(RT_ERR_INTERNAL, "stub: a row's buffer is not on its communicator rank's device");
-        }
-        std::memcpy(m[i].dst, m[i].src, m[i].count * sizeof(double));
-        {
-            std::lock_guard<std::mutex> g(g_stub_mu);
-            g_rows_moved++;
+void exchange_close(Exchange* e, bool failed) {
+    if (!e) return;
+    {
+        std::lock_guard<std::mutex> g(g_stub_mu);
+        g_ex_open--;
+        if (failed) {  // the product destroys the communicators of a failed exchange instead of caching them
+            for (auto it = g_ex_cache.begin(); it != g_ex_cache.end(); ++it)
+                if (*it == e->devices) {
+                    g_ex_cache.erase(it);
+                    break;
+                }
+            g_ex_destroyed++;
         }
     }
+    delete e;
 }
+void exchange_post(Exchange* e, const RowMove& m) {
+    {
+        std::lock_guard<std::mutex> g(g_stub_mu);
+        if (e->posting) throw RtError(RT_ERR_INTERNAL, "stub: two exchange_post calls on one communicator set at once");
+        e->posting = true;
+    }
+    struct Done {
+        Exchange* e;
+        ~Done() {
+            std::lock_guard<std::mutex> g(g_stub_mu);
+            e->posting = false;
+        }
+    } done{e};
+    std::this_thread::sleep_for(std::chrono::microseconds(200));  // (a window in which an unserialised second post would be caught)
+    if (const char* f = std::getenv("RTAMD_STUB_FAIL_POST"))  // "fail the post of rows from this comm rank": the error path of a failed exchange
+        if (std::atoi(f) == m.src_rank) throw RtError(RT_ERR_HIP, "stub: ncclSend failed (asked for by RTAMD_STUB_FAIL_POST)");
+    if (m.src_rank < 0 || m.src_rank >= (int)e->devices.size() || m.dst_rank < 0 || m.dst_rank >= (int)e->devices.size())
+        throw RtError(RT_ERR_ARG, "stub: bad comm rank");
+    {   // a row leaves the device of its source rank and lands on the device of its destination rank
+        std::lock_guard<std::mutex> g(g_stub_mu);
+        auto owner = [&](const void* q) {
+            for (auto& kv : g_owner)
+                if ((const char*)q >= (const char*)kv.first && (const char*)q < (const char*)kv.first + kv.second.bytes) return kv.second.device;
+            return -1;
+        };
+        if (owner(m.src) != e->devices[(size_t)m.src_rank] || owner(m.dst) != e->devices[(size_t)m.dst_rank])
+            throw RtError(RT_ERR_INTERNAL, "stub: a row's buffer is not on its communicator rank's device");
+    }
+    std::memcpy(m.dst, m.src, m.count * sizeof(double));
+    std::lock_guard<std::mutex> g(g_stub_mu);
+    g_rows_moved++;
+}
+void exchange_wait(Exchange*) {}
 size_t exchange_release_idle() { return 0; }
 int exchange_library_version() { return 0; }
 }  // namespace rtamd

@@ -73,14 +73,14 @@ def test_library_exports_every_declared_symbol():
     L = ctypes.CDLL(rtamd.LIB_PATH)
     for name in declared_symbols():
         assert hasattr(L, name), "librtamd.so does not export %s" % name
-    assert rtamd.lib().rt_abi_version() == 1
+    assert rtamd.lib().rt_abi_version() == 2
 
 
 def test_struct_layouts_match_header_sizes():
     import rtamd
     assert ctypes.sizeof(rtamd.rt_camera) == 13 * 8
     assert ctypes.sizeof(rtamd.rt_params) == 4 * 4 + 8 + 8 + 6 * 4 + 2 * 8
-    assert ctypes.sizeof(rtamd.rt_stats) == 3 * 8 + 8 + 6 * 4 + 8 + 4 * 8
+    assert ctypes.sizeof(rtamd.rt_stats) == 3 * 8 + 8 + 6 * 4 + 8 + 4 * 8 + 5 * 8   # ABI version 2: five f64 behind reserved[]
     p = rtamd.default_params()
     assert (p.width, p.height, p.spp, p.max_depth, p.t_min, p.world) == (800, 800, 256, 50, 0.001, 1)   # main.rs:34-45, camera.rs:73
 

@@ -73,3 +73,8 @@ def test_cpp_main_resumes_a_frame_from_its_checkpoint_file(tmp_path):
     assert open(plain, "rb").read() == open(resumed, "rb").read()
     r = run(*common[:-2], "--seed", "4", "-o", resumed, "--checkpoint", ck)
     assert r.returncode == 1 and "not the state of this frame" in r.stderr
+    # ... and so is the state of the same frame parameters over ANOTHER scene (the header carries a fingerprint of the committed scene, one of
+    # the camera and the library's image-spec version: ADVICE r04)
+    other = ["--scene", scene_path("scene_200_no_bvh.json")] + common[2:]
+    r = run(*other, "-o", resumed, "--checkpoint", ck)
+    assert r.returncode == 1 and "not the state of this frame" in r.stderr and "rtamd-image-" in r.stderr

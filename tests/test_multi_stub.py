@@ -107,3 +107,36 @@ def test_resumable_render_with_host_held_state_on_the_stub():
     with pytest.raises(rtamd.RtError):
         rtamd.accum_finalize(rtamd.default_params(width=52, height=28, spp=16, rank=1, world=2), state)
 
+
+
+def test_rows_travel_as_their_ranks_finish_not_after_the_join(monkeypatch):
+    """RTAMD_STUB_STAGGER_MS makes rank r's (stub) render take 30 r ms: a rank's rows are handed to the exchange by its own thread the moment
+    it is done (rt_stats.posted_ms = ms after the call began), so the early ranks' rows are on their way long before the last rank has
+    finished -- round 4 posted all rows in one group after the join.  The exchange figure counts from the join only."""
+    monkeypatch.setenv("RTAMD_STUB_STAGGER_MS", "30")
+    world, cam = _world()
+    img, st = world.render_multi(cam, devices=[0, 1, 2, 3], width=64, height=40, spp=1, seed=3)
+    assert np.array_equal(img, _expected(64, 40, 3))
+    posted = [s["posted_ms"] for s in st]
+    assert posted[0] == 0.0                                         # rendered in place on the root's device
+    assert 20.0 < posted[1] < posted[2] < posted[3]                 # each about when its own render ended ...
+    assert posted[1] < posted[3] - 40.0 and posted[2] < posted[3] - 15.0   # ... not all together behind the slowest rank
+    assert st[0]["seconds"] * 1e3 >= posted[3] and st[0]["exchange_ms"] < 25.0 and st[0]["rows_through_rccl"] == 3
+    assert st[0]["stitch_copy_ms"] >= 0.0 and st[0]["comm_init_ms"] >= 0.0
+
+
+def test_a_failed_exchange_is_an_error_and_its_communicators_are_not_reused(monkeypatch):
+    """a send that fails inside a rank's thread comes back as that rank's status; the communicator set is destroyed, not cached (the next
+    call creates a new one: comm_init_ms > 0 only then)"""
+    import rtamd
+    world, cam = _world()
+    _, st = world.render_multi(cam, devices=[0, 2], width=32, height=16, spp=1)          # creates (or reuses) the set for [0, 2]
+    _, st = world.render_multi(cam, devices=[0, 2], width=32, height=16, spp=1)
+    assert st[0]["comm_init_ms"] == 0.0                                                     # cached
+    monkeypatch.setenv("RTAMD_STUB_FAIL_POST", "1")
+    with pytest.raises(rtamd.RtError) as e:
+        world.render_multi(cam, devices=[0, 2], width=32, height=16, spp=1)
+    assert "rank 1" in str(e.value) and "ncclSend failed" in str(e.value)
+    monkeypatch.delenv("RTAMD_STUB_FAIL_POST")
+    img, st = world.render_multi(cam, devices=[0, 2], width=32, height=16, spp=1, seed=2)
+    assert np.array_equal(img, _expected(32, 16, 2)) and st[0]["comm_init_ms"] > 0.0       # a NEW set was made
