@@ -289,3 +289,25 @@ def test_final_scene_as_named_full_size_windows_match_the_oracle():
         state, sk = w.render_accumulate(cam, p, 500 * k, 500 * (k + 1), state)
         assert sk["samples"] == 1600 * 1600 * 500
     assert np.array_equal(rtamd.accum_finalize(p, state), img)
+
+
+@pytest.mark.gpu
+def test_moving_sphere_shutter_outside_its_time_range_is_refused():
+    """A moving sphere's box is the union of its boxes at ITS time0 and time1 (scene.cpp: add_moving_sphere); a ray time outside that range would
+    move the centre out of the committed box and the BVH boxes (kernel 1) / accel boxes (kernel 2) would clip it, each in its own way.
+    The render is refused instead: the shutter -- or the closed shutter's single time -- must lie inside [time0, time1] of every moving sphere."""
+    import rtamd
+    w = rtamd.World()
+    m = w.Lambertian(w.ConstantTexture((0.7, 0.3, 0.1)))
+    w.new([w.MovingSphere((0.0, 0.0, 0.0), (4.0, 0.0, 0.0), 0.25, 0.75, 1.0, m),
+           w.MovingSphere((0.0, 3.0, 0.0), (0.0, 3.0, 2.0), 0.0, 1.0, 0.5, m),
+           w.Sphere((0.0, -100.0, 0.0), 99.0, m)], bvh_seed=1)
+    cam = rtamd.Camera(((2.0, 1.0, -12.0), (2.0, 1.0, 0.0)), (0.0, 1.0, 0.0), 40.0, 1.0, 0.0, 10.0)
+    for kernel in (1, 2):
+        img, _ = w.render(cam, width=32, height=32, spp=2, seed=1, kernel=kernel, shutter=(0.25, 0.75))      # the common range itself
+        assert np.isfinite(img).all()
+        w.render(cam, width=32, height=32, spp=2, seed=1, kernel=kernel, shutter=(0.5, 0.5))                # closed, inside
+        for shutter in [(0.0, 1.0), (0.25, 0.8), (0.2, 0.5), (0.0, 0.0), (0.9, 0.9)]:                        # open beyond an end; closed outside
+            with pytest.raises(rtamd.RtError) as e:
+                w.render(cam, width=32, height=32, spp=2, seed=1, kernel=kernel, shutter=shutter)
+            assert e.value.code == -1 and "must lie inside" in str(e.value), shutter
