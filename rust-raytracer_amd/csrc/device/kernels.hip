@@ -56,7 +56,7 @@ namespace rtamd {
 // lanes that execute it (the clock is scalar: one value per wave), and booked by the first active lane.
 // phases: 0 regeneration, 1 traverse (all of it), 2 materialize, 3 shade (all of it), 4 Lambertian / DiffuseLight branch, 5 Isotropic,
 // 6 Metal, 7 Dielectric, 8 what follows traverse in a segment (materialize + shade + radiance + mixture / store), 9 leaf sections of
-// the traversal; events only: 10 inner-node steps, 11 leaf items, 12 cube tests, 13 segments (alive lanes), 14 mixture step
+// the traversal; events only: 10 inner-node steps, 11 leaf items, 12 cube tests, 13 segments (alive lanes), 14 mixture step, 15 inner-node steps inside an instance
 #ifdef RTAMD_PHASE_STATS
 __shared__ unsigned long long s_ph[48];
 __device__ unsigned long long g_phase[48];
@@ -912,6 +912,9 @@ DEV Hit traverse2(const Acc& A, uint32_t* stk, const int stride, D3 wo, D3 wd, d
         }
         while ((cur >> REF_TAG_SHIFT) == 0u) {  // inner node: test both children
             PH_EV(10);
+#ifdef RTAMD_PHASE_STATS
+            if (GENERAL && cur_xf >= 0) PH_EV(15);  // ... of which inside an instance's object-space BVH
+#endif
             if (WIDE) {
                 const uint32_t axx = cur + r.ax, ayy = cur + r.ay, azz = cur + r.az;
                 // seven 8-byte LDS reads, spelled out: left to itself the compiler pairs them into ds_read2_b64 / ds_read2st64_b64
@@ -3954,12 +3957,12 @@ void render_tiles(const rt_scene& s, const CameraDev& cam, const RenderPlan& pla
         HIP_CHECK(hipMemcpyFromSymbol(hp, HIP_SYMBOL(g_phase), sizeof(hp)));
         HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z)));
         const double tot = (double)(hp[0] + hp[1] + hp[8]);
-        const char* nm[15] = {"regeneration", "traverse (all)", "materialize", "shade (all)", "  Lambertian / light branch", "  Isotropic branch", "  Metal branch",
+        const char* nm[16] = {"regeneration", "traverse (all)", "materialize", "shade (all)", "  Lambertian / light branch", "  Isotropic branch", "  Metal branch",
                               "  Dielectric branch", "after traverse (all)", "  leaf sections of traverse", "inner-node steps", "leaf items", "cube tests",
-                              "segments", "mixture steps"};
+                              "segments", "mixture steps", "  node steps inside an instance"};
         fprintf(stderr, "[phase] kernel %d lds %d  wave clocks per segment-iteration %.0f (iterations %llu)\n", kernel, lds ? 1 : 0, hp[16] ? tot / (double)hp[16] : 0.,
                 hp[16]);
-        for (int i = 0; i < 15; i++)
+        for (int i = 0; i < 16; i++)
             fprintf(stderr, "[phase] %-30s time %6.3f  wave-exec/iter %8.3f  lanes/exec %5.1f  (util %.3f)\n", nm[i], i < 10 ? (double)hp[i] / tot : 0.,
                     hp[16] ? (double)hp[16 + i] / (double)hp[16] : 0., hp[16 + i] ? (double)hp[32 + i] / (double)hp[16 + i] : 0.,
                     hp[16 + i] ? (double)hp[32 + i] / (64. * (double)hp[16 + i]) : 0.);

@@ -11,6 +11,6 @@ declare -A SPP=( [scene_10]=100 [scene_500]=64 [cornell]=128 [cornell_mix]=128 [
 for CFG in ${@:-scene_500 cornell cornell_mix c5r}; do
   RTAMD_LIB=$PWD/rust-raytracer_amd/variants/librtamd_phase.so timeout -k 10 300 python3 tools/config_run.py $CFG ${SPP[$CFG]} 2> $OUT/$CFG.err > $OUT/$CFG.json || { tail -5 $OUT/$CFG.err; exit 1; }
   # the warm-up render prints a block too: keep the last one
-  grep "^\[phase\]" $OUT/$CFG.err | tail -17 > $OUT/$CFG.txt
+  grep "^\[phase\]" $OUT/$CFG.err | tail -18 > $OUT/$CFG.txt
   echo "== $CFG"; cat $OUT/$CFG.txt
 done
