@@ -513,11 +513,16 @@ DEV bool tie_flagged(int xf) { return (((uint32_t)xf >> 30) & 1u) != ((uint32_t)
 // the later object Y (exact box, entered through the face in question) and the earlier object X lie in ONE plane, the reference visits Y iff
 // fl((k - o) * fl(1 / d)) < t_X, and that differs from "t_Y <= t_X" (what a closest-hit walk decides) whenever t_X falls into the one or two
 // ulps between t_Y and Y's box entry: 1 ray in 10 000 on a mesh face lying on a cube face (tools/tie_soak.py inst, round 5: 0.26382042861594929
-// for the triangle, ...923 for the cube side; the reference keeps the triangle).  So the walks flag every pair of candidates whose t differ by
-// at most TIE_W - 1 (8 ulps: the box entry is within 1.5 ulps of t_Y), whichever of the two is closer, and let the reference-order walk decide:
+// for the triangle, ...923 for the cube side; the reference keeps the triangle).  Under a Transform the window is wider: the cube's t comes out
+// of the object-space ray M^-1 o, whose rounding is an ulp of |o|, not of the distance travelled -- t is off by up to 2^-53 |o| / (t |d_axis|)
+// relatively (cubes translated by lattice steps: 2-9 of 150 000 rays per scene differed with a window of 8 ulps).  So the walks flag every pair
+// of candidates whose t differ by at most TIE_W - 1 = 2^-40 relatively (covers |o| up to 4 096 times the distance travelled along the face's
+// axis; untransformed boxes need 1.5 ulps), whichever of the two is closer, and let the reference-order walk decide:
 // the primitive tests see [t_min, best * TIE_W] in the TIE variants, a candidate beyond `best` is never accepted, only noted.  A flag that was
-// not needed costs a re-walk and returns the same hit.
-#define TIE_W (1.0 + 1.7763568394002505e-15)
+// not needed -- two surfaces within 10^-12 of each other along the ray: contact lines, nothing else -- costs a re-walk and returns the same hit.
+#ifndef TIE_W
+#define TIE_W (1.0 + 9.094947017729282e-13)  // 1 + 2^-40
+#endif
 
 // World::hit -> BVHNode::hit / Vec::hit / Transform::hit, flattened (common/flat.h).
 // Visits nodes in the reference's own order; a leaf is accepted when t_min <= t <= best

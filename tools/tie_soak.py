@@ -3,7 +3,7 @@ nested cubes, rectangles lying on cube faces -- and rays that start inside and o
 hits is an EXACT tie between two or three objects.  Closest-hit records of the accel walks (kernel 2's global node form and its LDS node
 table, with the flag + reference-order re-walk) against the reference-order walk (kernel 1), all 12 fields incl. the winning leaf's program
 index, bit for bit.  64 top-level objects per scene (a power of two: BVHNode::new then emits no object twice, so the index is comparable).
-With `inst` (round 5) eight of the 64 objects are MESH instances on the same lattice -- closed boxes and flat sheets of >= 128 triangles under
+With `inst` (round 5) every fifth cube sits under a Transform (a translation by lattice steps) and eight of the 64 objects are MESH instances on the same lattice -- closed boxes and flat sheets of >= 128 triangles under
 translations, their faces coplanar with cube faces and rectangles -- and the walks of the instance service (rt_debug_hit_device 5 / 6: world-
 space walk with the instances deferred + their object-space walks over the Node2 / compact NodeQ records, tie bit, re-walk) are compared as
 well; every scene is also RENDERED from inside the lattice (glass cubes, depth 12) with kernels 5 and 6 against kernel 1: pt_kernel_coop's /
@@ -29,7 +29,13 @@ for sc in range(scenes):
     for k in range(48 - (8 if inst else 0)):
         lo = rng.integers(0, 6, 3)
         ext = rng.integers(1, 3, 3)
-        items.append(w.Cube(tuple(float(v) for v in lo), tuple(float(v) for v in lo + ext), (glass if k % 3 == 0 else lamp if k % 7 == 1 else m) if inst else m))
+        mat = (glass if k % 3 == 0 else lamp if k % 7 == 1 else m) if inst else m
+        if inst and k % 5 == 4:   # the same cube under a Transform (a translation by lattice steps): its hits come out of the object-space ray, its box is the transformed one
+            off = rng.integers(-3, 4, 3)
+            items.append(w.Transform((0.0, 0.0, 0.0), (1.0, 1.0, 1.0), tuple(float(v) for v in off),
+                                     w.Cube(tuple(float(v) for v in lo - off), tuple(float(v) for v in lo + ext - off), mat)))
+        else:
+            items.append(w.Cube(tuple(float(v) for v in lo), tuple(float(v) for v in lo + ext), mat))
     for k in range(8 if inst else 0):          # mesh instances on the lattice: boxes (closed) and sheets (flat), translated by integers
         lo = rng.integers(0, 6, 3)
         ext = rng.integers(1, 3, 3)
