@@ -113,3 +113,24 @@ def test_cpp_host_renders_across_devices_in_one_capture_image(tmp_path):
     assert r3.returncode == 0 and np.array_equal(np.asarray(Image.open(one)), np.asarray(Image.open(many)))
     r4 = subprocess.run([exe, *args, "--devices", "0,9", "-o", many], capture_output=True, text=True, timeout=300)
     assert r4.returncode == 1 and "error -9" in r4.stderr
+
+
+def test_multi_stats_tell_upload_init_render_exchange_and_copy_apart(tuning):
+    """rt_stats (ABI version 2) of one rt_render_multi call: the scene upload of the first render on a device, the creation of the
+    communicators on the first call with a device list (and after rt_release_workspaces), when each rank's rows were handed to RCCL --
+    by the rank's own thread, right after its render --, the exchange proper (last rank's finish -> rows on the root) and the stitch +
+    host copy.  What a first run on N > 1 devices needs to tell init cost from render from exchange."""
+    import rtamd
+    rtamd.lib().rt_release_workspaces()                              # drops cached communicators: the next forced exchange creates them
+    world, cam = rtamd.load_scene_file(scene_path("scene_10.json"))  # a fresh scene: its first render uploads it
+    tuning(multi_force_rccl=1)
+    img, st = world.render_multi(cam, devices=[0, 0, 0], width=96, height=64, spp=4, seed=2)
+    assert sum(1 for s in st if s["upload_ms"] > 0.0) == 1
+    assert st[0]["comm_init_ms"] > 0.0                               # ncclCommInitAll happened in this call, before the renders
+    assert all(s["posted_ms"] > 0.0 for s in st)                     # every rank's rows went through the exchange, each posted by its rank
+    assert all(s["posted_ms"] <= st[0]["seconds"] * 1e3 for s in st)
+    assert st[0]["exchange_ms"] >= 0.0 and abs(st[0]["exchange_seconds"] * 1e3 - st[0]["exchange_ms"]) < 1e-2
+    assert st[0]["stitch_copy_ms"] > 0.0 and st[0]["rows_through_rccl"] == 3
+    img2, st2 = world.render_multi(cam, devices=[0, 0, 0], width=96, height=64, spp=4, seed=2)
+    assert np.array_equal(img, img2)
+    assert st2[0]["comm_init_ms"] == 0.0 and all(s["upload_ms"] == 0.0 for s in st2)   # cached communicators, scene already on the device

@@ -140,3 +140,17 @@ def test_a_failed_exchange_is_an_error_and_its_communicators_are_not_reused(monk
     monkeypatch.delenv("RTAMD_STUB_FAIL_POST")
     img, st = world.render_multi(cam, devices=[0, 2], width=32, height=16, spp=1, seed=2)
     assert np.array_equal(img, _expected(32, 16, 2)) and st[0]["comm_init_ms"] > 0.0       # a NEW set was made
+
+
+def test_idle_frame_buffers_are_capped(monkeypatch):
+    """rt_render_multi keeps its frame-sized device buffers between calls; a host that renders many resolutions must not pile up one set per
+    shape: at most 1 GiB of idle buffers (least recently returned freed first), and rt_release_workspaces frees what is left."""
+    import rtamd
+    world, cam = _world()
+    rtamd.lib().rt_release_workspaces()
+    for k in range(9):                                               # 9 shapes x (gathered + frame + a rank's row) of ~ 3 x 48 MB each = 1.3 GB
+        w = 1400 + 8 * k
+        img, _ = world.render_multi(cam, devices=[0, 1], width=w, height=1400, spp=1, seed=1)
+        assert img.shape == (1400, w, 3)
+    freed = rtamd.lib().rt_release_workspaces()
+    assert (1 << 29) < freed <= (1 << 30), freed                    # without the cap: everything, 1.3 GB
