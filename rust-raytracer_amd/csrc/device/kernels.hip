@@ -516,12 +516,14 @@ DEV bool tie_flagged(int xf) { return (((uint32_t)xf >> 30) & 1u) != ((uint32_t)
 // for the triangle, ...923 for the cube side; the reference keeps the triangle).  Under a Transform the window is wider: the cube's t comes out
 // of the object-space ray M^-1 o, whose rounding is an ulp of |o|, not of the distance travelled -- t is off by up to 2^-53 |o| / (t |d_axis|)
 // relatively (cubes translated by lattice steps: 2-9 of 150 000 rays per scene differed with a window of 8 ulps).  So the walks flag every pair
-// of candidates whose t differ by at most TIE_W - 1 = 2^-40 relatively (covers |o| up to 4 096 times the distance travelled along the face's
-// axis; untransformed boxes need 1.5 ulps), whichever of the two is closer, and let the reference-order walk decide:
+// of candidates whose t differ by at most TIE_W - 1 = 2^-32 relatively (covers |o| up to a million times the distance travelled along the
+// face's axis; untransformed boxes need 1.5 ulps; with 2^-40 ONE ray of 5 000 000 on the soak's lattices still differed: it started 1.7e-4 from
+// the plane it grazed at 1.4 degrees, 2.6e4 times closer than it was to the origin), whichever of the two is closer, and let the
+// reference-order walk decide:
 // the primitive tests see [t_min, best * TIE_W] in the TIE variants, a candidate beyond `best` is never accepted, only noted.  A flag that was
 // not needed -- two surfaces within 10^-12 of each other along the ray: contact lines, nothing else -- costs a re-walk and returns the same hit.
 #ifndef TIE_W
-#define TIE_W (1.0 + 9.094947017729282e-13)  // 1 + 2^-40
+#define TIE_W (1.0 + 2.3283064365386963e-10)  // 1 + 2^-32
 #endif
 
 // World::hit -> BVHNode::hit / Vec::hit / Transform::hit, flattened (common/flat.h).
